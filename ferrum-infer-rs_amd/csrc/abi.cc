@@ -1,0 +1,449 @@
+// C-ABI layer (include/ferrum_hip.h) over the gfx950 kernels: argument validation, handles,
+// memory, and the native-operator descriptor.  Host-only code; compiled with hipcc.
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "../../include/ferrum_hip.h"
+#include "block_allocator.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace fh {
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+}  // namespace fh
+
+using namespace fh;
+
+struct FerrumHipWorkspace {
+    float* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct FerrumHipGptq {
+    W4Device dev;
+    bool symmetric = true;
+    __half* gather_scratch = nullptr;   // act-order input gather buffer [m_cap, K]
+    int gather_rows = 0;
+};
+
+#define H(p) reinterpret_cast<__half*>(p)
+#define CH(p) reinterpret_cast<const __half*>(p)
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+// ── native operator artifact ────────────────────────────────────────────────
+static const FerrumNativeOperatorDescriptor g_desc = {1u, "ferrum_hip_decode", "1"};
+int ferrum_native_op_init(void) { return 0; }
+const FerrumNativeOperatorDescriptor* ferrum_native_op_descriptor(void) { return &g_desc; }
+
+const char* ferrum_hip_last_error(void) { return fh::last_error(); }
+
+int ferrum_hip_device_count(int* count) {
+    FH_REQUIRE(count, "device_count: null output");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { *count = 0; fh::set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return 1; }
+    return 0;
+}
+int ferrum_hip_set_device(int ordinal) { FH_CHECK_HIP(hipSetDevice(ordinal)); return 0; }
+int ferrum_hip_stream_create(void** stream) {
+    FH_REQUIRE(stream, "stream_create: null output");
+    hipStream_t s;
+    FH_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return 0;
+}
+int ferrum_hip_stream_destroy(void* stream) { FH_CHECK_HIP(hipStreamDestroy(ST(stream))); return 0; }
+int ferrum_hip_stream_synchronize(void* stream) { FH_CHECK_HIP(hipStreamSynchronize(ST(stream))); return 0; }
+int ferrum_hip_alloc(void** dev_ptr, size_t bytes) {
+    FH_REQUIRE(dev_ptr, "alloc: null output");
+    *dev_ptr = nullptr;
+    if (bytes == 0) return 0;
+    FH_CHECK_HIP(hipMalloc(dev_ptr, bytes));
+    FH_CHECK_HIP(hipMemset(*dev_ptr, 0, bytes));
+    return 0;
+}
+int ferrum_hip_free(void* dev_ptr) { if (dev_ptr) FH_CHECK_HIP(hipFree(dev_ptr)); return 0; }
+int ferrum_hip_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ST(stream)));
+    FH_CHECK_HIP(hipStreamSynchronize(ST(stream)));
+    return 0;
+}
+int ferrum_hip_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ST(stream)));
+    FH_CHECK_HIP(hipStreamSynchronize(ST(stream)));
+    return 0;
+}
+int ferrum_hip_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FH_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ST(stream)));
+    return 0;
+}
+int ferrum_hip_memset_zero(void* p, size_t bytes, void* stream) {
+    if (bytes == 0) return 0;
+    FH_CHECK_HIP(hipMemsetAsync(p, 0, bytes, ST(stream)));
+    return 0;
+}
+
+int ferrum_hip_workspace_create(FerrumHipWorkspace** ws, size_t bytes) {
+    FH_REQUIRE(ws, "workspace_create: null output");
+    auto* w = new FerrumHipWorkspace();
+    if (bytes) {
+        hipError_t e = hipMalloc((void**)&w->ptr, bytes);
+        if (e != hipSuccess) { delete w; fh::set_error("workspace hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return 1; }
+    }
+    w->bytes = bytes;
+    *ws = w;
+    return 0;
+}
+int ferrum_hip_workspace_destroy(FerrumHipWorkspace* ws) {
+    if (!ws) return 0;
+    if (ws->ptr) (void)hipFree(ws->ptr);
+    delete ws;
+    return 0;
+}
+
+// ── norms / elementwise ─────────────────────────────────────────────────────
+int ferrum_hip_rms_norm_f16(const void* x, const void* w, float eps, void* out, int tokens, int dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (x && w && out), "rms_norm: null buffer");
+    return rms_norm_f16(CH(x), CH(w), eps, H(out), tokens, dim, ST(stream));
+}
+int ferrum_hip_fused_add_rms_norm_f16(void* residual, const void* x, const void* w, float eps, void* out,
+                                      int tokens, int dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (residual && x && w && out), "fused_add_rms_norm: null buffer");
+    return fused_add_rms_norm_f16(H(residual), CH(x), CH(w), eps, H(out), tokens, dim, ST(stream));
+}
+int ferrum_hip_embedding_lookup_f16(const void* table, const uint32_t* ids, void* out, int n_ids, int dim, void* stream) {
+    FH_REQUIRE(n_ids == 0 || (table && ids && out), "embedding_lookup: null buffer");
+    return embedding_lookup_f16(CH(table), ids, H(out), n_ids, dim, ST(stream));
+}
+int ferrum_hip_fused_silu_mul_split_f16(const void* gate_up, void* out, int tokens, int im, void* stream) {
+    return fused_silu_mul_split_f16(CH(gate_up), H(out), tokens, im, ST(stream));
+}
+int ferrum_hip_fused_gelu_tanh_mul_split_f16(const void* gate_up, void* out, int tokens, int im, void* stream) {
+    return fused_gelu_tanh_mul_split_f16(CH(gate_up), H(out), tokens, im, ST(stream));
+}
+int ferrum_hip_scale_inplace_f16(void* buf, float scale, size_t len, void* stream) {
+    return scale_inplace_f16(H(buf), scale, (long)len, ST(stream));
+}
+int ferrum_hip_add_inplace_f16(void* residual, const void* x, size_t len, void* stream) {
+    return add_inplace_f16(H(residual), CH(x), (long)len, ST(stream));
+}
+int ferrum_hip_add_bias_f16(void* data, const void* bias, int rows, int cols, void* stream) {
+    return add_bias_f16(H(data), CH(bias), rows, cols, ST(stream));
+}
+
+// ── dense GEMM ──────────────────────────────────────────────────────────────
+int ferrum_hip_gemm_f16(const void* a, const void* b, void* out, int m, int n, int k, FerrumHipWorkspace* ws, void* stream) {
+    FH_REQUIRE(m == 0 || (a && b && out), "gemm: null buffer");
+    return f16_gemm(CH(a), CH(b), H(out), m, n, k, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+}
+int ferrum_hip_gemm_f16_f32out(const void* a, const void* b, float* out, int m, int n, int k, FerrumHipWorkspace* ws,
+                               void* stream) {
+    FH_REQUIRE(m == 0 || (a && b && out), "gemm: null buffer");
+    return f16_gemm_f32out(CH(a), CH(b), out, m, n, k, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+}
+
+// ── GPTQ ────────────────────────────────────────────────────────────────────
+static int upload(const void* host, size_t bytes, void** dev) {
+    *dev = nullptr;
+    if (!bytes) return 0;
+    FH_CHECK_HIP(hipMalloc(dev, bytes));
+    FH_CHECK_HIP(hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+static int check_gptq_args(int bits, int group_size, int k, int n) {
+    if (bits != 4) { fh::set_error("gptq: only bits=4 supported (got %d)", bits); return FERRUM_HIP_UNSUPPORTED; }
+    if (k <= 0 || n <= 0 || k % 128 != 0 || n % 8 != 0) {
+        fh::set_error("gptq: unsupported shape K=%d N=%d (K %% 128, N %% 8 required)", k, n);
+        return FERRUM_HIP_UNSUPPORTED;
+    }
+    if (group_size <= 0 || group_size % 128 != 0 || k % group_size != 0) {
+        fh::set_error("gptq: unsupported group_size=%d for K=%d (multiple of 128 required)", group_size, k);
+        return FERRUM_HIP_UNSUPPORTED;
+    }
+    return 0;
+}
+
+int ferrum_hip_gptq_load(FerrumHipGptq** handle, const int32_t* qweight, const float* scales, const int32_t* qzeros,
+                         const int32_t* g_idx, const float* bias, int bits, int group_size, int k, int n) {
+    FH_REQUIRE(handle && qweight && scales && qzeros, "gptq_load: null argument");
+    if (int rc = check_gptq_args(bits, group_size, k, n)) return rc;
+    W4HostPacked hp;
+    if (int rc = w4_repack_host(qweight, scales, qzeros, g_idx, nullptr, group_size, k, n, &hp)) return rc;
+    auto* g = new FerrumHipGptq();
+    g->symmetric = hp.symmetric;
+    g->dev.k = k; g->dev.n = n; g->dev.n64 = hp.n64; g->dev.G = hp.G; g->dev.num_experts = 1;
+    int rc = upload(hp.qw.data(), hp.qw.size() * 4, (void**)&g->dev.qw);
+    if (!rc) rc = upload(hp.sc.data(), hp.sc.size() * 2, (void**)&g->dev.sc);
+    if (!rc && !hp.symmetric) rc = upload(hp.zp.data(), hp.zp.size() * 2, (void**)&g->dev.zp);
+    if (!rc && !hp.perm.empty()) rc = upload(hp.perm.data(), hp.perm.size() * 4, (void**)&g->dev.perm);
+    if (!rc && bias) {
+        std::vector<uint16_t> bh(n);
+        for (int i = 0; i < n; i++) { _Float16 h = (_Float16)bias[i]; memcpy(&bh[i], &h, 2); }
+        rc = upload(bh.data(), bh.size() * 2, (void**)&g->dev.bias);
+    }
+    if (rc) { ferrum_hip_gptq_free(g); return rc; }
+    *handle = g;
+    return 0;
+}
+
+int ferrum_hip_gptq_load_stacked(FerrumHipGptq** handle, const int32_t* const* qweights, const float* const* scales,
+                                 const int32_t* const* qzeros, const int32_t* g_idx, int bits, int group_size, int k,
+                                 int n_per_expert, int num_experts, int fuse_gate_up) {
+    FH_REQUIRE(handle && qweights && scales && qzeros && num_experts > 0, "gptq_load_stacked: null argument");
+    if (int rc = check_gptq_args(bits, group_size, k, n_per_expert)) return rc;
+    if (g_idx) { fh::set_error("gptq_load_stacked: act-order experts are not supported"); return FERRUM_HIP_UNSUPPORTED; }
+    const int n = n_per_expert;
+    std::vector<int32_t> col_perm;
+    if (fuse_gate_up) {
+        if (n % 64 != 0) { fh::set_error("gptq_load_stacked: fused gate_up needs N %% 64 == 0 (N=%d)", n); return FERRUM_HIP_UNSUPPORTED; }
+        // supertile st = [gate 32st..32st+31 | up I+32st..I+32st+31]
+        const int I = n / 2;
+        col_perm.resize(n);
+        for (int st = 0; st < n / 64; st++)
+            for (int c = 0; c < 64; c++) col_perm[st * 64 + c] = c < 32 ? st * 32 + c : I + st * 32 + (c - 32);
+    }
+    auto* g = new FerrumHipGptq();
+    g->dev.k = k; g->dev.n = n; g->dev.num_experts = num_experts; g->dev.fused_gate_up = fuse_gate_up != 0;
+    std::vector<uint32_t> all_qw;
+    std::vector<uint16_t> all_sc, all_zp;
+    bool any_asym = false;
+    std::vector<W4HostPacked> packed(num_experts);
+    for (int e = 0; e < num_experts; e++) {
+        if (int rc = w4_repack_host(qweights[e], scales[e], qzeros[e], nullptr, fuse_gate_up ? col_perm.data() : nullptr,
+                                    group_size, k, n, &packed[e])) { delete g; return rc; }
+        any_asym |= !packed[e].symmetric;
+    }
+    g->symmetric = !any_asym;
+    g->dev.n64 = packed[0].n64; g->dev.G = packed[0].G;
+    for (int e = 0; e < num_experts; e++) {
+        all_qw.insert(all_qw.end(), packed[e].qw.begin(), packed[e].qw.end());
+        all_sc.insert(all_sc.end(), packed[e].sc.begin(), packed[e].sc.end());
+        if (any_asym) {
+            if (packed[e].symmetric) {   // materialise zero point 8
+                _Float16 h8 = (_Float16)8.0f; uint16_t u; memcpy(&u, &h8, 2);
+                all_zp.insert(all_zp.end(), packed[e].sc.size(), u);
+            } else {
+                all_zp.insert(all_zp.end(), packed[e].zp.begin(), packed[e].zp.end());
+            }
+        }
+    }
+    int rc = upload(all_qw.data(), all_qw.size() * 4, (void**)&g->dev.qw);
+    if (!rc) rc = upload(all_sc.data(), all_sc.size() * 2, (void**)&g->dev.sc);
+    if (!rc && any_asym) rc = upload(all_zp.data(), all_zp.size() * 2, (void**)&g->dev.zp);
+    if (rc) { ferrum_hip_gptq_free(g); return rc; }
+    *handle = g;
+    return 0;
+}
+
+int ferrum_hip_gptq_free(FerrumHipGptq* g) {
+    if (!g) return 0;
+    if (g->dev.qw) (void)hipFree(g->dev.qw);
+    if (g->dev.sc) (void)hipFree(g->dev.sc);
+    if (g->dev.zp) (void)hipFree(g->dev.zp);
+    if (g->dev.perm) (void)hipFree(g->dev.perm);
+    if (g->dev.bias) (void)hipFree(g->dev.bias);
+    if (g->gather_scratch) (void)hipFree(g->gather_scratch);
+    delete g;
+    return 0;
+}
+
+int ferrum_hip_gptq_info(const FerrumHipGptq* g, int* k, int* n, int* num_experts, int* symmetric) {
+    FH_REQUIRE(g, "gptq_info: null handle");
+    if (k) *k = g->dev.k;
+    if (n) *n = g->dev.n;
+    if (num_experts) *num_experts = g->dev.num_experts;
+    if (symmetric) *symmetric = g->symmetric ? 1 : 0;
+    return 0;
+}
+
+int ferrum_hip_gptq_linear_forward_f16(const FerrumHipGptq* handle, const void* in, void* out, int m,
+                                       FerrumHipWorkspace* ws, void* stream) {
+    FH_REQUIRE(handle && (m == 0 || (in && out)), "gptq_linear_forward: null argument");
+    FH_REQUIRE(handle->dev.num_experts == 1, "gptq_linear_forward: handle is an expert stack");
+    auto* g = const_cast<FerrumHipGptq*>(handle);
+    const __half* x = CH(in);
+    if (g->dev.perm) {
+        // act-order: gather input columns first (cuda/quant.rs:434).  The scratch grows outside
+        // of graph capture only (first call with a larger m).
+        if (g->gather_rows < m) {
+            if (g->gather_scratch) (void)hipFree(g->gather_scratch);
+            g->gather_scratch = nullptr;
+            FH_CHECK_HIP(hipMalloc((void**)&g->gather_scratch, (size_t)m * g->dev.k * 2));
+            g->gather_rows = m;
+        }
+        if (int rc = gather_columns_f16(x, g->dev.perm, g->gather_scratch, m, g->dev.k, ST(stream))) return rc;
+        x = g->gather_scratch;
+    }
+    if (int rc = w4_gemm_dense(g->dev, x, H(out), m, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream))) return rc;
+    if (g->dev.bias) return add_bias_f16(H(out), g->dev.bias, m, g->dev.n, ST(stream));
+    return 0;
+}
+
+int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input, const int32_t* sorted_token_ids,
+                                  const int32_t* expert_ids, const int32_t* num_tokens_past_padded, void* output,
+                                  int prob_m, int moe_block_size, int top_k, int max_blocks, int fused_silu_mul,
+                                  void* stream) {
+    FH_REQUIRE(stack && input && sorted_token_ids && expert_ids && num_tokens_past_padded && output,
+               "moe_gemm_phase: null argument");
+    if (moe_block_size != 16) { fh::set_error("moe_gemm_phase: moe_block_size=%d unsupported (16 only)", moe_block_size); return FERRUM_HIP_UNSUPPORTED; }
+    FH_REQUIRE(top_k >= 1, "moe_gemm_phase: top_k=%d", top_k);
+    FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase: fused epilogue needs a stack loaded with fuse_gate_up");
+    FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase: stack was loaded with fuse_gate_up; plain output is column-permuted");
+    return w4_gemm_moe(stack->dev, CH(input), H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
+                       max_blocks, top_k, fused_silu_mul, ST(stream));
+}
+
+// ── paged KV ────────────────────────────────────────────────────────────────
+size_t ferrum_hip_paged_pool_bytes(int num_blocks, int kv_heads, int head_dim) {
+    return (size_t)num_blocks * kv_heads * 16 * head_dim * 2;
+}
+
+int ferrum_hip_split_qkv_norm_rope_into_paged_cache_varlen_f16(
+    const void* qkv, const void* q_norm_w, const void* k_norm_w, const float* cos_tab, const float* sin_tab,
+    void* q_out, void* cache_k, void* cache_v, const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+    const int32_t* block_tables, int num_seqs, int m_total, int q_heads, int kv_heads, int head_dim, float eps,
+    int qk_mode, int block_size, int max_blocks_per_seq, void* stream) {
+    FH_REQUIRE(m_total == 0 || (qkv && q_out && cache_k && cache_v && cu_seqlens_q && pos_offsets && block_tables),
+               "split_qkv_norm_rope_into_paged_cache_varlen: null buffer");
+    FH_REQUIRE(qk_mode == 0 || (cos_tab && sin_tab), "split_qkv_norm_rope: rope tables missing");
+    FH_REQUIRE(qk_mode != 1 || (q_norm_w && k_norm_w), "split_qkv_norm_rope: norm weights missing for qk_mode 1");
+    return split_qkv_norm_rope_into_paged_cache_varlen_f16(CH(qkv), CH(q_norm_w), CH(k_norm_w), cos_tab, sin_tab,
+                                                           H(q_out), H(cache_k), H(cache_v), cu_seqlens_q, pos_offsets,
+                                                           block_tables, num_seqs, m_total, q_heads, kv_heads, head_dim,
+                                                           eps, qk_mode, block_size, max_blocks_per_seq, ST(stream));
+}
+
+int ferrum_hip_paged_varlen_attention_f16(const void* q, const void* k_pool, const void* v_pool, void* out,
+                                          const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+                                          const int32_t* block_tables, int num_seqs, int total_q_tokens, int max_kv_len,
+                                          int num_heads, int num_kv_heads, int head_dim, int sliding_window,
+                                          int block_size, int max_num_blocks_per_seq, int max_q_len,
+                                          FerrumHipWorkspace* ws, void* stream) {
+    FH_REQUIRE(total_q_tokens == 0 || (q && k_pool && v_pool && out && cu_seqlens_q && pos_offsets && block_tables),
+               "paged_varlen_attention: null buffer");
+    return paged_varlen_attention_f16(CH(q), CH(k_pool), CH(v_pool), H(out), cu_seqlens_q, pos_offsets, block_tables,
+                                      num_seqs, total_q_tokens, max_q_len, max_kv_len, num_heads, num_kv_heads, head_dim,
+                                      sliding_window, block_size, max_num_blocks_per_seq, ws ? ws->ptr : nullptr,
+                                      ws ? ws->bytes : 0, ST(stream));
+}
+
+int ferrum_hip_paged_batched_decode_attention_f16(const void* q, const void* k_pool, const void* v_pool, void* out,
+                                                  const int32_t* block_tables, const uint32_t* valid_kv_lens,
+                                                  int num_seqs, int max_kv_len, int num_heads, int num_kv_heads,
+                                                  int head_dim, int block_size, int max_num_blocks_per_seq,
+                                                  FerrumHipWorkspace* ws, void* stream) {
+    FH_REQUIRE(num_seqs == 0 || (q && k_pool && v_pool && out && block_tables && valid_kv_lens),
+               "paged_batched_decode_attention: null buffer");
+    return paged_batched_decode_attention_f16(CH(q), CH(k_pool), CH(v_pool), H(out), block_tables, valid_kv_lens,
+                                              num_seqs, max_kv_len, num_heads, num_kv_heads, head_dim, block_size,
+                                              max_num_blocks_per_seq, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0,
+                                              ST(stream));
+}
+
+int ferrum_hip_paged_kv_read_f16(const void* cache_k, const void* cache_v, const int32_t* block_table, int kv_len,
+                                 int kv_heads, int head_dim, int block_size, void* k_out, void* v_out, void* stream) {
+    return paged_kv_read_f16(CH(cache_k), CH(cache_v), block_table, kv_len, kv_heads, head_dim, block_size, H(k_out),
+                             H(v_out), ST(stream));
+}
+
+// ── MoE routing ─────────────────────────────────────────────────────────────
+int ferrum_hip_moe_route_topk_softmax_f16(const void* logits, int32_t* ids, float* w, int tokens, int num_experts,
+                                          int top_k, int norm, void* stream) {
+    return moe_route_topk_softmax_f16(CH(logits), ids, w, tokens, num_experts, top_k, norm, ST(stream));
+}
+int ferrum_hip_moe_route_topk_softmax_f32(const float* logits, int32_t* ids, float* w, int tokens, int num_experts,
+                                          int top_k, int norm, void* stream) {
+    return moe_route_topk_softmax_f32(logits, ids, w, tokens, num_experts, top_k, norm, ST(stream));
+}
+int ferrum_hip_moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
+                                    int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
+                                    int sorted_max, void* stream) {
+    FH_REQUIRE(expert_ids && sorted_token_ids && block_ids && total_post_pad, "moe_align_block_size: null buffer");
+    return moe_align_block_size(expert_ids, sorted_token_ids, block_ids, total_post_pad, batch_x_topk, num_experts,
+                                block_size, sorted_max, ST(stream));
+}
+int ferrum_hip_moe_combine_f16(const void* down, const float* weights, void* out, int tokens, int top_k, int hidden,
+                               int accumulate, void* stream) {
+    return moe_combine_f16(CH(down), weights, H(out), tokens, top_k, hidden, accumulate, ST(stream));
+}
+
+// ── sampling ────────────────────────────────────────────────────────────────
+int ferrum_hip_argmax_rows_f16(const void* logits, uint32_t* out, const uint8_t* mask, int mask_len, int m, int n, void* stream) {
+    return argmax_rows_f16(CH(logits), out, mask, mask_len, m, n, ST(stream));
+}
+int ferrum_hip_argmax_rows_f32(const float* logits, uint32_t* out, const uint8_t* mask, int mask_len, int m, int n, void* stream) {
+    return argmax_rows_f32(logits, out, mask, mask_len, m, n, ST(stream));
+}
+int ferrum_hip_apply_repetition_penalties_sparse_f16(void* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
+                                                     const float* penalties, int m, int n, void* stream) {
+    return apply_repetition_penalties_sparse_f16(H(logits), row_offsets, token_ids, penalties, m, n, ST(stream));
+}
+int ferrum_hip_apply_repetition_penalties_sparse_f32(float* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
+                                                     const float* penalties, int m, int n, void* stream) {
+    return apply_repetition_penalties_sparse_f32(logits, row_offsets, token_ids, penalties, m, n, ST(stream));
+}
+
+// ── BlockAllocator ──────────────────────────────────────────────────────────
+struct FerrumHipBlockAllocator { fh::BlockAllocator impl; explicit FerrumHipBlockAllocator(uint32_t n) : impl(n) {} };
+
+int ferrum_hip_block_allocator_create(FerrumHipBlockAllocator** a, uint32_t num_blocks) {
+    FH_REQUIRE(a, "block_allocator_create: null output");
+    *a = new FerrumHipBlockAllocator(num_blocks);
+    return 0;
+}
+int ferrum_hip_block_allocator_destroy(FerrumHipBlockAllocator* a) { delete a; return 0; }
+int ferrum_hip_block_allocator_allocate(FerrumHipBlockAllocator* a, uint32_t* block) {
+    FH_REQUIRE(a && block, "block_allocator_allocate: null argument");
+    if (!a->impl.allocate(block)) {
+        fh::set_error("paged KV pool exhausted (capacity=%u blocks, all in use)", a->impl.capacity());
+        return FERRUM_HIP_INVALID;
+    }
+    return 0;
+}
+int ferrum_hip_block_allocator_allocate_n(FerrumHipBlockAllocator* a, uint32_t n, uint32_t* blocks) {
+    FH_REQUIRE(a && (n == 0 || blocks), "block_allocator_allocate_n: null argument");
+    if (!a->impl.allocate_n(n, blocks)) {
+        fh::set_error("paged KV pool exhausted: need %u blocks but only %u free", n, a->impl.free_count());
+        return FERRUM_HIP_INVALID;
+    }
+    return 0;
+}
+int ferrum_hip_block_allocator_free(FerrumHipBlockAllocator* a, const uint32_t* blocks, uint32_t n) {
+    FH_REQUIRE(a && (n == 0 || blocks), "block_allocator_free: null argument");
+    a->impl.free(blocks, n);
+    return 0;
+}
+int ferrum_hip_block_allocator_acquire(FerrumHipBlockAllocator* a, uint32_t block) {
+    FH_REQUIRE(a, "block_allocator_acquire: null");
+    a->impl.acquire(block);
+    return 0;
+}
+int ferrum_hip_block_allocator_register_hash(FerrumHipBlockAllocator* a, uint32_t block, uint64_t hash) {
+    FH_REQUIRE(a, "block_allocator_register_hash: null");
+    a->impl.register_block_hash(block, hash);
+    return 0;
+}
+int ferrum_hip_block_allocator_try_acquire_by_hash(FerrumHipBlockAllocator* a, uint64_t hash, int64_t* block) {
+    FH_REQUIRE(a && block, "block_allocator_try_acquire_by_hash: null");
+    *block = a->impl.try_acquire_by_hash(hash);
+    return 0;
+}
+uint32_t ferrum_hip_block_allocator_free_count(const FerrumHipBlockAllocator* a) { return a->impl.free_count(); }
+uint32_t ferrum_hip_block_allocator_ref_count(const FerrumHipBlockAllocator* a, uint32_t b) { return a->impl.ref_count(b); }
+uint32_t ferrum_hip_block_allocator_peak_in_use(const FerrumHipBlockAllocator* a) { return a->impl.peak_in_use(); }
+uint32_t ferrum_hip_block_allocator_hash_table_size(const FerrumHipBlockAllocator* a) { return a->impl.hash_table_size(); }
+
+}  // extern "C"

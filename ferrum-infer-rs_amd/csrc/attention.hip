@@ -1,0 +1,320 @@
+// Paged-KV attention for gfx950: one kernel family for decode (q_len = 1), chunked prefill and
+// mixed batches.
+//
+// Reference ops: `paged_varlen_attention` / `paged_batched_decode_attention` /
+// `paged_decode_attention` (ferrum-kernels/src/backend/traits.rs:1813,1885,1719; CUDA launch sites
+// backend/cuda/paged.rs:942,1309,1160).  Maths = causal GQA softmax(QKᵀ/√hd)·V with optional sliding
+// window (CPU forms: backend/cpu.rs:2179-2259, ferrum-kv/src/attention.rs:30-114).
+//
+// Design (HBM-bound in decode):
+//  * a workgroup owns (sequence, kv_head, 16 query rows) where a "row" is a (token, q-head of the
+//    GQA group) pair — at decode the 16 rows are the nq/nkv heads of the single new token, so K/V
+//    of a kv head are read ONCE for the whole group (the reference's CUDA lane reads them once per
+//    q head, kernels/paged_decode_attention.cu:177-179);
+//  * K/V tiles are stored MFMA-fragment shaped (kv_layout.h): every wave load is 1 KiB contiguous,
+//    goes HBM → VGPR with no LDS staging, and is directly the A operand of v_mfma_f32_16x16x32_f16;
+//  * Sᵀ = K·Qᵀ puts one query row per lane column, so softmax statistics are lane-local plus two
+//    xor-shuffles; Oᵀ = Vᵀ·Pᵀ keeps the same column ↔ row map, so no cross-lane traffic for the
+//    rescale and P feeds the second MFMA straight from the accumulator registers;
+//  * the 4 waves of a workgroup split the KV range, and grid.z splits it further for long
+//    contexts (flash-decode); partial (m, l, O) are merged in fixed order (deterministic).
+#include "common.h"
+#include "kernels.h"
+#include "kv_layout.h"
+
+namespace fh {
+
+struct AttnArgs {
+    const __half* q;        // [total_q, nq, hd]
+    const __half* k_pool;   // [blocks, nkv, tile]
+    const __half* v_pool;
+    __half* out;            // [total_q, nq, hd]
+    const uint32_t* cu_seqlens_q;   // [num_seqs+1] or null (decode: token i ↔ seq i)
+    const uint32_t* pos_offsets;    // [num_seqs] kv position of each seq's first q token
+    const uint32_t* kv_lens;        // decode form: [num_seqs] kv length incl. the new token (pos = len-1)
+    const int32_t* block_tables;    // [num_seqs, max_blocks]
+    float* partial;         // [tiles][nsplit][16][hd+2] when nsplit > 1
+    int num_seqs, nq, nkv, tiles_per_seq, max_blocks, sliding_window, nsplit;
+    float scale;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
+    constexpr int DT = HD / 16;      // output d-tiles
+    constexpr int KS = HD / 32;      // QKᵀ k-steps (= 1-KiB loads per K tile = per V tile)
+    constexpr int OSTRIDE = HD + 4;  // padded LDS row (floats)
+    __shared__ __attribute__((aligned(16))) float lds_o[4 * 16 * OSTRIDE];
+    __shared__ float lds_m[4 * 16], lds_l[4 * 16];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int seq = blockIdx.x / p.tiles_per_seq, tile = blockIdx.x % p.tiles_per_seq;
+    const int kvh = blockIdx.y, z = blockIdx.z;
+    const int G = p.nq / p.nkv;
+
+    const int tok0 = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq] : seq;
+    const int q_len = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq + 1] - tok0 : 1;
+    const int rows_total = q_len * G;
+    if (tile * 16 >= rows_total) return;
+    const int pos0 = p.kv_lens ? (int)p.kv_lens[seq] - 1 : (int)p.pos_offsets[seq];
+
+    // this lane's query row (column b of every MFMA)
+    const int rho = tile * 16 + b;
+    const bool row_ok = rho < rows_total;
+    const int t_local = row_ok ? rho / G : 0;
+    const int g = row_ok ? rho % G : 0;
+    const int row_pos = pos0 + t_local;                 // attends keys [win_lo, row_pos]
+    const int win_lo = p.sliding_window > 0 ? max(0, row_pos + 1 - p.sliding_window) : 0;
+    const long q_off = ((long)(tok0 + t_local) * p.nq + kvh * G + g) * HD;
+
+    // tile-wide key range
+    const int t_first = (tile * 16) / G;
+    const int t_last = min(q_len - 1, (tile * 16 + 15) / G);
+    const int kv_end = pos0 + t_last + 1;
+    const int kv_begin = p.sliding_window > 0 ? max(0, pos0 + t_first + 1 - p.sliding_window) : 0;
+    const int pair_lo = (kv_begin / KV_BLOCK) / 2;
+    const int pair_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;       // exclusive
+    const int npairs = pair_hi - pair_lo;
+    const int per_split = (npairs + p.nsplit - 1) / p.nsplit;
+    const int my_lo = pair_lo + z * per_split;
+    const int my_hi = min(pair_hi, my_lo + per_split);
+    const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
+
+    half8 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) qf[s] = *reinterpret_cast<const half8*>(p.q + q_off + 32 * s + 8 * a);
+
+    float m_run = -INFINITY, l_run = 0.f;
+    float4v o_acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++) o_acc[dt] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
+    const long tile_elems = kv_tile_elems(HD);
+
+    for (int pr = my_lo + wave; pr < my_hi; pr += 4) {
+        const int blk0 = 2 * pr, blk1 = 2 * pr + 1;
+        const bool has1 = blk1 < nblocks;
+        const long phys0 = bt[blk0];
+        const long phys1 = has1 ? bt[blk1] : phys0;
+        const __half* k0 = p.k_pool + (phys0 * p.nkv + kvh) * tile_elems + lane * 8;
+        const __half* k1 = p.k_pool + (phys1 * p.nkv + kvh) * tile_elems + lane * 8;
+        const __half* v0 = p.v_pool + (phys0 * p.nkv + kvh) * tile_elems + lane * 8;
+        const __half* v1 = p.v_pool + (phys1 * p.nkv + kvh) * tile_elems + lane * 8;
+        half8 kf0[KS], kf1[KS], vf0[KS], vf1[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            kf0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(k0 + s * 512));
+            kf1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(k1 + s * 512));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            vf0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v0 + s * 512));
+            vf1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v1 + s * 512));
+        }
+        // Sᵀ[key][row] for the two blocks: lane (a,b) ← keys 4a+r of each block, query row b
+        float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0[s], qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1[s], qf[s], s1, 0, 0, 0);
+        }
+        float sc[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int kp0 = blk0 * KV_BLOCK + 4 * a + r, kp1 = blk1 * KV_BLOCK + 4 * a + r;
+            bool ok0 = row_ok && kp0 <= row_pos && kp0 >= win_lo;
+            bool ok1 = row_ok && has1 && kp1 <= row_pos && kp1 >= win_lo;
+            sc[r] = ok0 ? s0[r] * p.scale : -INFINITY;
+            sc[4 + r] = ok1 ? s1[r] * p.scale : -INFINITY;
+            mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __expf(m_run - m_safe);      // m_run = -inf → 0
+        float psum = 0.f;
+        half8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            float pv = __expf(sc[j] - m_safe);            // masked → 0
+            psum += pv;
+            pf[j] = (_Float16)pv;
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // Oᵀ[d][row] += Vᵀ[d][key]·Pᵀ[key][row]; contraction index (a,j): j<4 block0 key 4a+j, else block1
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) {
+            const int ld = dt >> 1, sub = (dt & 1) * 4;
+            half8 vfrag;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                vfrag[j] = vf0[ld][sub + j];
+                vfrag[4 + j] = has1 ? vf1[ld][sub + j] : (_Float16)0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) o_acc[dt][r] *= alpha;
+            o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf, o_acc[dt], 0, 0, 0);
+        }
+    }
+
+    // merge the 4 waves' partial states through LDS
+    if (a == 0) {
+        lds_m[wave * 16 + b] = m_run;
+        lds_l[wave * 16 + b] = l_run;
+    }
+#pragma unroll
+    for (int dt = 0; dt < DT; dt++)
+        *reinterpret_cast<float4v*>(&lds_o[(wave * 16 + b) * OSTRIDE + dt * 16 + 4 * a]) = o_acc[dt];
+    __syncthreads();
+
+    // 256 threads: thread → (row = tid/16, 8·HD/128 dims)
+    const int row = threadIdx.x >> 4, dl = threadIdx.x & 15;
+    float mw[4], M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { mw[w] = lds_m[w * 16 + row]; M = fmaxf(M, mw[w]); }
+    const float Ms = M == -INFINITY ? 0.f : M;
+    float fw[4], L = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { fw[w] = __expf(mw[w] - Ms); L += lds_l[w * 16 + row] * fw[w]; }
+
+    const int rho_o = tile * 16 + row;
+    const bool ok_o = rho_o < rows_total;
+    const int t_o = ok_o ? rho_o / G : 0, g_o = ok_o ? rho_o % G : 0;
+    constexpr int DPT = HD / 16;     // dims per thread
+    float ov[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; i++) {
+        int d = dl * DPT + i;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) acc += lds_o[(w * 16 + row) * OSTRIDE + d] * fw[w];
+        ov[i] = acc;
+    }
+    if (p.nsplit > 1) {
+        float* dst = p.partial + (((long)blockIdx.x * p.nkv + kvh) * p.nsplit + z) * 16 * (HD + 2) + row * (HD + 2);
+#pragma unroll
+        for (int i = 0; i < DPT; i++) dst[dl * DPT + i] = ov[i];
+        if (dl == 0) { dst[HD] = M; dst[HD + 1] = L; }
+        return;
+    }
+    if (!ok_o) return;
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    __half* o = p.out + ((long)(tok0 + t_o) * p.nq + kvh * G + g_o) * HD + dl * DPT;
+#pragma unroll
+    for (int i = 0; i < DPT; i++) o[i] = __float2half(ov[i] * inv);
+}
+
+// merge grid.z partials: one thread per (row, dim)
+template <int HD>
+__global__ void paged_attn_reduce_kernel(AttnArgs p) {
+    const int seq = blockIdx.x / p.tiles_per_seq, tile = blockIdx.x % p.tiles_per_seq;
+    const int kvh = blockIdx.y;
+    const int G = p.nq / p.nkv;
+    const int tok0 = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq] : seq;
+    const int q_len = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq + 1] - tok0 : 1;
+    const int rows_total = q_len * G;
+    const int row = threadIdx.x / (HD / 8), dl = threadIdx.x % (HD / 8);
+    const int rho = tile * 16 + row;
+    if (rho >= rows_total) return;
+    const float* base = p.partial + ((long)blockIdx.x * p.nkv + kvh) * p.nsplit * 16 * (HD + 2) + row * (HD + 2);
+    float M = -INFINITY;
+    for (int z = 0; z < p.nsplit; z++) M = fmaxf(M, base[(long)z * 16 * (HD + 2) + HD]);
+    const float Ms = M == -INFINITY ? 0.f : M;
+    float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.nsplit; z++) {
+        const float* src = base + (long)z * 16 * (HD + 2);
+        float f = __expf(src[HD] - Ms);
+        L += src[HD + 1] * f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] += src[dl * 8 + i] * f;
+    }
+    const float inv = L > 0.f ? 1.0f / L : 0.f;
+    const int t_o = rho / G, g_o = rho % G;
+    __half* o = p.out + ((long)(tok0 + t_o) * p.nq + kvh * G + g_o) * HD + dl * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = __float2half(acc[i] * inv);
+}
+
+static int choose_splits(int num_tiles_total, int nkv, int max_kv_len) {
+    // enough workgroups to cover the 256 CUs; at least 4 block pairs (128 keys) per wave per split
+    long wgs = (long)num_tiles_total * nkv;
+    int pairs = cdiv(cdiv(max_kv_len, KV_BLOCK), 2);
+    int s = 1;
+    while (wgs * s < 512 && pairs / (s * 2) >= 8 && s < 32) s *= 2;
+    return s;
+}
+
+size_t paged_attention_workspace_bytes(int total_q_tokens, int num_heads, int head_dim, int max_kv_len) {
+    // worst case: every (token, head) row in its own tile slot, 32 splits
+    long rows = (long)total_q_tokens * num_heads + 16L * 4096;
+    return (size_t)rows * 32 * (head_dim + 2) * sizeof(float);
+}
+
+static int paged_attention_launch(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
+                               const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets, const uint32_t* kv_lens,
+                               const int32_t* block_tables, int num_seqs, int total_q_tokens, int max_q_len,
+                               int max_kv_len, int num_heads, int num_kv_heads, int head_dim,
+                               int sliding_window, int block_size, int max_blocks_per_seq, float* workspace,
+                               size_t workspace_bytes, hipStream_t s) {
+    if (num_seqs <= 0 || total_q_tokens <= 0) return 0;
+    FH_REQUIRE(block_size == KV_BLOCK, "paged attention: block_size=%d unsupported (native layout uses 16)", block_size);
+    FH_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged attention: nq=%d not a multiple of nkv=%d",
+               num_heads, num_kv_heads);
+    FH_REQUIRE(head_dim == 128 || head_dim == 64 || head_dim == 256, "paged attention: head_dim=%d unsupported", head_dim);
+    const int G = num_heads / num_kv_heads;
+    if (max_q_len <= 0) max_q_len = total_q_tokens - (num_seqs - 1);
+    AttnArgs a{};
+    a.q = q; a.k_pool = k_pool; a.v_pool = v_pool; a.out = out;
+    a.cu_seqlens_q = cu_seqlens_q; a.pos_offsets = pos_offsets; a.kv_lens = kv_lens; a.block_tables = block_tables;
+    a.num_seqs = num_seqs; a.nq = num_heads; a.nkv = num_kv_heads;
+    a.tiles_per_seq = cdiv((long)max_q_len * G, 16);
+    a.max_blocks = max_blocks_per_seq; a.sliding_window = sliding_window;
+    a.scale = 1.0f / sqrtf((float)head_dim);
+    const int tiles = num_seqs * a.tiles_per_seq;
+    int nsplit = choose_splits(tiles, num_kv_heads, max_kv_len);
+    size_t need = (size_t)tiles * num_kv_heads * nsplit * 16 * (head_dim + 2) * sizeof(float);
+    if (nsplit > 1 && (workspace == nullptr || need > workspace_bytes)) nsplit = 1;
+    a.nsplit = nsplit;
+    a.partial = workspace;
+    dim3 grid(tiles, num_kv_heads, nsplit);
+#define FH_ATTN(HDV)                                                                              \
+    hipLaunchKernelGGL(paged_attn_kernel<HDV>, grid, dim3(256), 0, s, a);                         \
+    FH_CHECK_LAUNCH();                                                                            \
+    if (nsplit > 1) {                                                                             \
+        hipLaunchKernelGGL(paged_attn_reduce_kernel<HDV>, dim3(tiles, num_kv_heads), dim3(16 * HDV / 8), 0, s, a); \
+        FH_CHECK_LAUNCH();                                                                        \
+    }
+    if (head_dim == 128) { FH_ATTN(128) } else if (head_dim == 64) { FH_ATTN(64) } else { FH_ATTN(256) }
+#undef FH_ATTN
+    return 0;
+}
+
+int paged_varlen_attention_f16(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
+                               const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+                               const int32_t* block_tables, int num_seqs, int total_q_tokens, int max_q_len,
+                               int max_kv_len, int num_heads, int num_kv_heads, int head_dim,
+                               int sliding_window, int block_size, int max_blocks_per_seq, float* workspace,
+                               size_t workspace_bytes, hipStream_t s) {
+    return paged_attention_launch(q, k_pool, v_pool, out, cu_seqlens_q, pos_offsets, nullptr, block_tables, num_seqs,
+                                  total_q_tokens, max_q_len, max_kv_len, num_heads, num_kv_heads, head_dim,
+                                  sliding_window, block_size, max_blocks_per_seq, workspace, workspace_bytes, s);
+}
+
+// paged_batched_decode_attention (traits.rs:1885): q_len = 1 per sequence, kv length given directly.
+int paged_batched_decode_attention_f16(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
+                                       const int32_t* block_tables, const uint32_t* valid_kv_lens, int num_seqs,
+                                       int max_kv_len, int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                       int max_blocks_per_seq, float* workspace, size_t workspace_bytes,
+                                       hipStream_t s) {
+    return paged_attention_launch(q, k_pool, v_pool, out, nullptr, nullptr, valid_kv_lens, block_tables, num_seqs,
+                                  num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, 0, block_size,
+                                  max_blocks_per_seq, workspace, workspace_bytes, s);
+}
+
+}  // namespace fh

@@ -1,0 +1,65 @@
+// Shared helpers for the gfx950 kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+
+namespace fh {
+
+// Thread-local error text returned by ferrum_hip_last_error().
+void set_error(const char* fmt, ...);
+const char* last_error();
+
+#define FH_CHECK_HIP(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            fh::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                   \
+        }                                                                               \
+    } while (0)
+
+#define FH_REQUIRE(cond, ...)                 \
+    do {                                      \
+        if (!(cond)) {                        \
+            fh::set_error(__VA_ARGS__);       \
+            return 2;                         \
+        }                                     \
+    } while (0)
+
+#define FH_CHECK_LAUNCH()                                                            \
+    do {                                                                             \
+        hipError_t _e = hipGetLastError();                                           \
+        if (_e != hipSuccess) {                                                      \
+            fh::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 1;                                                                \
+        }                                                                            \
+    } while (0)
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+__host__ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace fh

@@ -1,0 +1,102 @@
+// Internal C++ interface between the kernel translation units and the C-ABI / runner.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace fh {
+
+// ── GPTQ-INT4 (w4_gemm.hip) ──────────────────────────────────────────────────
+struct W4HostPacked {
+    int k = 0, n = 0, n64 = 0, G = 0;
+    bool symmetric = true;
+    std::vector<uint32_t> qw;
+    std::vector<uint16_t> sc, zp;
+    std::vector<int32_t> perm;   // act-order input gather (empty = identity)
+};
+
+struct W4Device {
+    int k = 0, n = 0, n64 = 0, G = 0;
+    int num_experts = 1;         // stacked experts share one allocation
+    uint32_t* qw = nullptr;
+    __half* sc = nullptr;
+    __half* zp = nullptr;        // null when symmetric
+    int32_t* perm = nullptr;     // device act-order permutation or null
+    __half* bias = nullptr;      // optional [n]
+    bool fused_gate_up = false;  // columns permuted for the fused silu·mul epilogue
+};
+
+int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* qzeros,
+                   const int32_t* g_idx, const int32_t* col_perm, int group_size, int k, int n,
+                   W4HostPacked* out);
+int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
+                  size_t workspace_bytes, hipStream_t stream);
+int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
+                const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs,
+                int max_blocks, int top_k, int fused_silu, hipStream_t stream);
+int f16_gemm(const __half* x, const __half* w, __half* out, int m, int n, int k, float* workspace,
+             size_t workspace_bytes, hipStream_t stream);
+int f16_gemm_f32out(const __half* x, const __half* w, float* out, int m, int n, int k, float* workspace,
+                    size_t workspace_bytes, hipStream_t stream);
+
+// ── norms / elementwise (norm.hip) ───────────────────────────────────────────
+int rms_norm_f16(const __half* x, const __half* w, float eps, __half* out, int tokens, int dim, hipStream_t s);
+int fused_add_rms_norm_f16(__half* residual, const __half* x, const __half* w, float eps, __half* out,
+                           int tokens, int dim, hipStream_t s);
+int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, int n_ids, int dim, hipStream_t s);
+int fused_silu_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s);
+int fused_gelu_tanh_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s);
+int add_inplace_f16(__half* residual, const __half* x, long len, hipStream_t s);
+int scale_inplace_f16(__half* buf, float scale, long len, hipStream_t s);
+int add_bias_f16(__half* data, const __half* bias, int rows, int cols, hipStream_t s);
+int gather_columns_f16(const __half* in, const int32_t* perm, __half* out, int rows, int cols, hipStream_t s);
+int gather_rows_f16(const __half* in, const int32_t* row_idx, __half* out, int n_rows, int dim, hipStream_t s);
+
+// ── paged KV (rope_kv.hip, attention.hip) ────────────────────────────────────
+// Native pool layout, per (block, kv_head) 4 KiB tiles for head_dim 128 / block 16:
+//   K : [hd/8 chunks][16 keys][8 dims]                — MFMA A-fragment shaped
+//   V : [hd/32][4 key-quads][16 d][2 d-sub][4 keys]    — MFMA B-fragment shaped
+// pool = [num_blocks][kv_heads][tile].
+int split_qkv_norm_rope_into_paged_cache_varlen_f16(
+    const __half* qkv, const __half* q_norm_w, const __half* k_norm_w, const float* cos_t, const float* sin_t,
+    __half* q_out, __half* cache_k, __half* cache_v, const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+    const int32_t* block_tables, int num_seqs, int m_total, int q_heads, int kv_heads, int head_dim, float eps,
+    int qk_mode, int block_size, int max_blocks_per_seq, hipStream_t s);
+int paged_kv_read_f16(const __half* cache_k, const __half* cache_v, const int32_t* block_table, int kv_len,
+                      int kv_heads, int head_dim, int block_size, __half* k_out, __half* v_out, hipStream_t s);
+int paged_varlen_attention_f16(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
+                               const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+                               const int32_t* block_tables, int num_seqs, int total_q_tokens, int max_q_len,
+                               int max_kv_len, int num_heads, int num_kv_heads, int head_dim,
+                               int sliding_window, int block_size, int max_blocks_per_seq, float* workspace,
+                               size_t workspace_bytes, hipStream_t s);
+int paged_batched_decode_attention_f16(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
+                                       const int32_t* block_tables, const uint32_t* valid_kv_lens, int num_seqs,
+                                       int max_kv_len, int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                       int max_blocks_per_seq, float* workspace, size_t workspace_bytes,
+                                       hipStream_t s);
+size_t paged_attention_workspace_bytes(int total_q_tokens, int num_heads, int head_dim, int max_kv_len);
+
+// ── MoE routing (moe.hip) ────────────────────────────────────────────────────
+int moe_route_topk_softmax_f16(const __half* logits, int32_t* expert_ids, float* expert_weights, int tokens,
+                               int num_experts, int top_k, int norm_topk_prob, hipStream_t s);
+int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* expert_weights, int tokens,
+                               int num_experts, int top_k, int norm_topk_prob, hipStream_t s);
+int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
+                         int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
+                         int sorted_max, hipStream_t s);
+int moe_combine_f16(const __half* down, const float* weights, __half* out, int tokens, int top_k, int hidden,
+                    int accumulate_into_residual, hipStream_t s);
+
+// ── sampling (sampling.hip) ──────────────────────────────────────────────────
+int argmax_rows_f16(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                    hipStream_t s);
+int argmax_rows_f32(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                    hipStream_t s);
+int apply_repetition_penalties_sparse_f32(float* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
+                                          const float* penalties, int m, int n, hipStream_t s);
+int apply_repetition_penalties_sparse_f16(__half* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
+                                          const float* penalties, int m, int n, hipStream_t s);
+
+}  // namespace fh

@@ -1,0 +1,203 @@
+// MoE routing on device: router top-k softmax, align-block-size, weighted combine.
+//
+// Reference: `BackendMoeFused::route_topk_softmax` (ferrum-kernels/src/backend/capabilities.rs:334;
+// CUDA kernels/moe_router.cu:32; CPU ferrum-models/src/moe/router.rs:113-195),
+// `moe_align_block_size_pair_ids` (capabilities.rs:449; kernels/moe_align_block_size_pair_ids.cu:13),
+// `moe_combine` / `weighted_sum_batched` (capabilities.rs:684,560; kernels/moe_combine.cu:29,62).
+// Integer outputs are bit-exact with the host plan (dispatch.rs:1408-1461): slots inside an expert
+// are in ascending pair id (the CUDA lane's atomicAdd order is unspecified; ours is not).
+#include "common.h"
+#include "kernels.h"
+
+namespace fh {
+
+// One wave per token.  E ≤ 512.  f32 softmax, k argmax-mask passes, ties → lowest index.
+template <typename T>
+__global__ __launch_bounds__(64) void moe_route_kernel(const T* __restrict__ logits, int32_t* __restrict__ ids,
+                                                       float* __restrict__ weights, int num_experts, int top_k,
+                                                       int norm_topk_prob) {
+    constexpr int PER = 8;   // experts per lane (E ≤ 512)
+    const int tok = blockIdx.x, lane = threadIdx.x;
+    const T* row = logits + (long)tok * num_experts;
+    float v[PER];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        int e = lane + i * 64;
+        v[i] = e < num_experts ? (float)row[e] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_reduce_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        int e = lane + i * 64;
+        v[i] = e < num_experts ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+    sum = wave_reduce_sum(sum);
+    const float inv_sum = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        int e = lane + i * 64;
+        v[i] = e < num_experts ? v[i] * inv_sum : -INFINITY;
+    }
+    float sel_sum = 0.f;
+    float my_w = 0.f;   // lane k keeps the k-th selected weight
+    int my_id = 0;
+    for (int k = 0; k < top_k; k++) {
+        float best = -INFINITY;
+        int best_idx = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            int e = lane + i * 64;
+            if (v[i] > best) { best = v[i]; best_idx = e; }   // ascending e within a lane → first max
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            float ob = __shfl_xor(best, off, 64);
+            int oi = __shfl_xor(best_idx, off, 64);
+            if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+        }
+        if (best_idx == 0x7fffffff) best_idx = 0;   // all -inf (router.rs keeps best_idx = 0)
+        sel_sum += best;
+        if (lane == (k & 63)) { my_w = best; my_id = best_idx; }
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (lane + i * 64 == best_idx) v[i] = -INFINITY;
+        if (top_k > 64 && (k & 63) == 63) {}  // top_k ≤ 64 enforced on host
+    }
+    if (lane < top_k) {
+        float w = my_w;
+        if (norm_topk_prob) w = sel_sum > 0.f ? w * (1.0f / sel_sum) : 1.0f / (float)top_k;
+        ids[(long)tok * top_k + lane] = my_id;
+        weights[(long)tok * top_k + lane] = w;
+    }
+}
+
+int moe_route_topk_softmax_f16(const __half* logits, int32_t* expert_ids, float* expert_weights, int tokens,
+                               int num_experts, int top_k, int norm_topk_prob, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(num_experts > 0 && num_experts <= 512, "moe route: num_experts=%d must be in [1,512]", num_experts);
+    FH_REQUIRE(top_k > 0 && top_k <= num_experts && top_k <= 64, "moe route: top_k=%d invalid for %d experts", top_k, num_experts);
+    hipLaunchKernelGGL(moe_route_kernel<__half>, dim3(tokens), dim3(64), 0, s, logits, expert_ids, expert_weights,
+                       num_experts, top_k, norm_topk_prob);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* expert_weights, int tokens,
+                               int num_experts, int top_k, int norm_topk_prob, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(num_experts > 0 && num_experts <= 512, "moe route: num_experts=%d must be in [1,512]", num_experts);
+    FH_REQUIRE(top_k > 0 && top_k <= num_experts && top_k <= 64, "moe route: top_k=%d invalid for %d experts", top_k, num_experts);
+    hipLaunchKernelGGL(moe_route_kernel<float>, dim3(tokens), dim3(64), 0, s, logits, expert_ids, expert_weights,
+                       num_experts, top_k, norm_topk_prob);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// One workgroup per expert: histogram of every pair (LDS atomics, order-free) → padded prefix →
+// ordered compaction of this expert's pair ids (ballot prefix keeps ascending pair id).
+constexpr int MAX_EXPERTS = 512;
+__global__ __launch_bounds__(256) void moe_align_kernel(const int32_t* __restrict__ expert_ids,
+                                                        int32_t* __restrict__ sorted_token_ids,
+                                                        int32_t* __restrict__ block_ids,
+                                                        int32_t* __restrict__ total_post_pad, int n_pairs,
+                                                        int num_experts, int block_size, int sorted_max) {
+    __shared__ int counts[MAX_EXPERTS];
+    __shared__ int wave_cnt[4];
+    __shared__ int s_offset, s_total;
+    const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < num_experts; i += 256) counts[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < n_pairs; p += 256) {
+        int x = expert_ids[p];
+        if (x >= 0 && x < num_experts) atomicAdd(&counts[x], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0, mine = 0;
+        for (int i = 0; i < num_experts; i++) {
+            if (i == e) mine = acc;
+            acc += ((counts[i] + block_size - 1) / block_size) * block_size;
+        }
+        s_offset = mine;
+        s_total = acc;
+        if (e == 0) total_post_pad[0] = acc;
+    }
+    __syncthreads();
+    const int offset = s_offset, total = s_total;
+    const int cnt = counts[e];
+    const int padded = ((cnt + block_size - 1) / block_size) * block_size;
+    // sentinel for the padding tail of this expert and (striped) the unused end of the array
+    for (int i = cnt + tid; i < padded; i += 256) sorted_token_ids[offset + i] = n_pairs;
+    for (int i = total + e * 256 + tid; i < sorted_max; i += 256 * gridDim.x) sorted_token_ids[i] = n_pairs;
+    for (int b = tid; b < padded / block_size; b += 256) block_ids[offset / block_size + b] = e;
+    // ordered compaction
+    int base = 0;
+    for (int p0 = 0; p0 < n_pairs; p0 += 256) {
+        int p = p0 + tid;
+        bool mine = p < n_pairs && expert_ids[p] == e;
+        unsigned long long bal = __ballot(mine);
+        int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += wave_cnt[w];
+        int chunk_total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        if (mine) sorted_token_ids[offset + base + before + in_wave] = p;
+        base += chunk_total;
+        __syncthreads();
+    }
+}
+
+int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
+                         int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
+                         int sorted_max, hipStream_t s) {
+    FH_REQUIRE(num_experts > 0 && num_experts <= MAX_EXPERTS, "moe align: num_experts=%d must be in [1,%d]", num_experts, MAX_EXPERTS);
+    FH_REQUIRE(block_size > 0, "moe align: block_size=%d", block_size);
+    FH_REQUIRE(sorted_max >= batch_x_topk, "moe align: sorted_max=%d < pairs=%d", sorted_max, batch_x_topk);
+    hipLaunchKernelGGL(moe_align_kernel, dim3(num_experts), dim3(256), 0, s, expert_ids, sorted_token_ids, block_ids,
+                       total_post_pad, batch_x_topk, num_experts, block_size, sorted_max);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// out[b] (+)= Σ_k w[b,k]·down[b·top_k + k]   (k ascending, fp32 accumulate; moe_forward_cpu order,
+// ferrum-models/src/moe/dispatch.rs:2277-2283).  accumulate=1 folds the residual add
+// (qwen3_moe_forward_unified_layer.rs:451) into the same pass.
+__global__ void moe_combine_kernel(const __half* __restrict__ down, const float* __restrict__ weights,
+                                   __half* __restrict__ out, int top_k, int hidden, int accumulate) {
+    const long b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (hidden >> 3)) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < top_k; k++) {
+        float w = weights[b * top_k + k];
+        half8 d = *reinterpret_cast<const half8*>(down + (b * top_k + k) * hidden + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] += w * (float)d[j];
+    }
+    half8 o;
+    if (accumulate) {
+        half8 r = *reinterpret_cast<const half8*>(out + b * hidden + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)r[j] + acc[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (_Float16)acc[j];
+    }
+    *reinterpret_cast<half8*>(out + b * hidden + i * 8) = o;
+}
+
+int moe_combine_f16(const __half* down, const float* weights, __half* out, int tokens, int top_k, int hidden,
+                    int accumulate_into_residual, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(hidden % 8 == 0, "moe combine: hidden=%d must be a multiple of 8", hidden);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(cdiv(hidden / 8, 256), tokens), dim3(256), 0, s, down, weights, out,
+                       top_k, hidden, accumulate_into_residual);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace fh

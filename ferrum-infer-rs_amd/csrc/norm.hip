@@ -1,0 +1,216 @@
+// RMSNorm family, embedding gather and the elementwise ops of the decode layer (gfx950).
+//
+// Reference contracts (ferrum-kernels/src/backend/traits.rs; CPU forms in backend/cpu.rs):
+//   rms_norm            traits.rs:202  / cpu.rs:495-513   y = x·rsqrt(mean(x²)+eps)·w
+//   fused_add_rms_norm  traits.rs:212  / cpu.rs:515-538   res += x; y = rms(res)·w
+//   embedding_lookup    traits.rs:809  / cpu.rs:1632
+//   fused_silu_mul_split / fused_gelu_tanh_mul_split  traits.rs:863,875 / cpu.rs:1666-1698
+//   add_inplace, scale_inplace, add_bias              traits.rs:1308,889,1359
+//   gather_columns (act-order)                        kernels/gather_columns.cu:15
+// All are HBM/latency-bound: 16-byte vector accesses (8 × fp16 per lane), fp32 math, one pass
+// over the row with the row held in registers between the reduction and the scale.
+#include "common.h"
+#include "kernels.h"
+
+namespace fh {
+
+__device__ __forceinline__ float block_reduce_sum_256(float v, float* smem) {
+    v = wave_reduce_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    float t = smem[0] + smem[1] + smem[2] + smem[3];
+    __syncthreads();
+    return t;
+}
+
+// One 256-thread workgroup per row; each thread keeps up to CHUNKS 16-byte chunks in registers.
+template <bool FUSED_ADD, int CHUNKS>
+__global__ __launch_bounds__(256) void rms_norm_kernel(const __half* __restrict__ x, __half* __restrict__ residual,
+                                                       const __half* __restrict__ w, float eps,
+                                                       __half* __restrict__ out, int dim) {
+    __shared__ float smem[4];
+    const long row = blockIdx.x;
+    const int nvec = dim >> 3;
+    half8 v[CHUNKS];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            half8 xv = *reinterpret_cast<const half8*>(x + row * dim + i * 8);
+            if (FUSED_ADD) {
+                half8 rv = *reinterpret_cast<const half8*>(residual + row * dim + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + (float)xv[j]);
+                // the updated residual is stored as fp16 and the variance is taken from the
+                // rounded values (same rounding point as the reference's fp16 lane,
+                // kernels/fused_add_rms_norm.cu:88-101)
+                *reinterpret_cast<half8*>(residual + row * dim + i * 8) = rv;
+                xv = rv;
+            }
+            v[c] = xv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)xv[j] * (float)xv[j];
+        }
+    }
+    float total = block_reduce_sum_256(ss, smem);
+    float inv = 1.0f / sqrtf(total / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            half8 wv = *reinterpret_cast<const half8*>(w + i * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
+            *reinterpret_cast<half8*>(out + row * dim + i * 8) = o;
+        }
+    }
+}
+
+template <bool FUSED>
+static int launch_rms(const __half* x, __half* residual, const __half* w, float eps, __half* out, int tokens,
+                      int dim, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0 && dim <= 8 * 256 * 8, "rms_norm: dim=%d must be a multiple of 8 and <= 16384", dim);
+    int chunks = cdiv(dim / 8, 256);
+    dim3 grid(tokens), block(256);
+    if (chunks <= 1) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 1>), grid, block, 0, s, x, residual, w, eps, out, dim);
+    else if (chunks <= 2) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 2>), grid, block, 0, s, x, residual, w, eps, out, dim);
+    else if (chunks <= 4) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 4>), grid, block, 0, s, x, residual, w, eps, out, dim);
+    else hipLaunchKernelGGL((rms_norm_kernel<FUSED, 8>), grid, block, 0, s, x, residual, w, eps, out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+int rms_norm_f16(const __half* x, const __half* w, float eps, __half* out, int tokens, int dim, hipStream_t s) {
+    return launch_rms<false>(x, nullptr, w, eps, out, tokens, dim, s);
+}
+int fused_add_rms_norm_f16(__half* residual, const __half* x, const __half* w, float eps, __half* out, int tokens,
+                           int dim, hipStream_t s) {
+    return launch_rms<true>(x, residual, w, eps, out, tokens, dim, s);
+}
+
+// ── row gathers ──────────────────────────────────────────────────────────────
+template <typename IdxT>
+__global__ void gather_rows_kernel(const __half* __restrict__ table, const IdxT* __restrict__ ids,
+                                   __half* __restrict__ out, int dim) {
+    const long row = blockIdx.y;
+    const long src = (long)ids[row];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (dim >> 3))
+        *reinterpret_cast<half8*>(out + row * dim + i * 8) = *reinterpret_cast<const half8*>(table + src * dim + i * 8);
+}
+
+int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, int n_ids, int dim, hipStream_t s) {
+    if (n_ids <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0, "embedding_lookup: dim=%d must be a multiple of 8", dim);
+    hipLaunchKernelGGL(gather_rows_kernel<uint32_t>, dim3(cdiv(dim / 8, 256), n_ids), dim3(256), 0, s, table, ids, out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+int gather_rows_f16(const __half* in, const int32_t* row_idx, __half* out, int n_rows, int dim, hipStream_t s) {
+    if (n_rows <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0, "gather_rows: dim=%d must be a multiple of 8", dim);
+    hipLaunchKernelGGL(gather_rows_kernel<int32_t>, dim3(cdiv(dim / 8, 256), n_rows), dim3(256), 0, s, in, row_idx, out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// ── gated activations: [T, 2I] (gate columns, then up columns) → [T, I] ──────
+template <bool GELU>
+__global__ void gated_act_kernel(const __half* __restrict__ gate_up, __half* __restrict__ out, int im) {
+    const long t = blockIdx.y;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (im >> 3)) return;
+    half8 g = *reinterpret_cast<const half8*>(gate_up + t * 2 * im + i * 8);
+    half8 u = *reinterpret_cast<const half8*>(gate_up + t * 2 * im + im + i * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float gf = (float)g[j], uf = (float)u[j], a;
+        if (GELU) {
+            float inner = 0.79788456f * (gf + 0.044715f * gf * gf * gf);
+            a = 0.5f * gf * (1.0f + tanhf(inner));
+        } else {
+            a = gf / (1.0f + __expf(-gf));
+        }
+        o[j] = (_Float16)(a * uf);
+    }
+    *reinterpret_cast<half8*>(out + t * im + i * 8) = o;
+}
+
+int fused_silu_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(im % 8 == 0, "fused_silu_mul_split: intermediate=%d must be a multiple of 8", im);
+    hipLaunchKernelGGL(gated_act_kernel<false>, dim3(cdiv(im / 8, 256), tokens), dim3(256), 0, s, gate_up, out, im);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+int fused_gelu_tanh_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(im % 8 == 0, "fused_gelu_tanh_mul_split: intermediate=%d must be a multiple of 8", im);
+    hipLaunchKernelGGL(gated_act_kernel<true>, dim3(cdiv(im / 8, 256), tokens), dim3(256), 0, s, gate_up, out, im);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// ── flat elementwise ─────────────────────────────────────────────────────────
+__global__ void add_inplace_kernel(__half* __restrict__ r, const __half* __restrict__ x, long len) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= len) {
+        half8 a = *reinterpret_cast<half8*>(r + i), b = *reinterpret_cast<const half8*>(x + i);
+#pragma unroll
+        for (int j = 0; j < 8; j++) a[j] = (_Float16)((float)a[j] + (float)b[j]);
+        *reinterpret_cast<half8*>(r + i) = a;
+    } else {
+        for (long j = i; j < len; j++) r[j] = __float2half(__half2float(r[j]) + __half2float(x[j]));
+    }
+}
+int add_inplace_f16(__half* residual, const __half* x, long len, hipStream_t s) {
+    if (len <= 0) return 0;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(cdiv(cdiv(len, 8), 256)), dim3(256), 0, s, residual, x, len);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void scale_inplace_kernel(__half* __restrict__ buf, float scale, long len) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) buf[i] = __float2half(__half2float(buf[i]) * scale);
+}
+int scale_inplace_f16(__half* buf, float scale, long len, hipStream_t s) {
+    if (len <= 0) return 0;
+    hipLaunchKernelGGL(scale_inplace_kernel, dim3(cdiv(len, 256)), dim3(256), 0, s, buf, scale, len);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void add_bias_kernel(__half* __restrict__ data, const __half* __restrict__ bias, int cols) {
+    long r = blockIdx.y;
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cols) data[r * cols + c] = __float2half(__half2float(data[r * cols + c]) + __half2float(bias[c]));
+}
+int add_bias_f16(__half* data, const __half* bias, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(add_bias_kernel, dim3(cdiv(cols, 256), rows), dim3(256), 0, s, data, bias, cols);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// act-order input gather A'[m, j] = A[m, perm[j]] (kernels/gather_columns.cu:15).
+__global__ void gather_columns_kernel(const __half* __restrict__ in, const int32_t* __restrict__ perm,
+                                      __half* __restrict__ out, int cols) {
+    long r = blockIdx.y;
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cols) out[r * cols + c] = in[r * cols + perm[c]];
+}
+int gather_columns_f16(const __half* in, const int32_t* perm, __half* out, int rows, int cols, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3(cdiv(cols, 256), rows), dim3(256), 0, s, in, perm, out, cols);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace fh

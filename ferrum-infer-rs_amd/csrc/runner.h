@@ -1,0 +1,88 @@
+// Decoder runner: the C++ host side above the C-ABI kernels.  Mirrors the reference's
+// `DecoderOnlyLLM` / `LlamaFamilyModel` / `Qwen3MoeModel` unified forward and the executor-level
+// KV admission contract (see include/ferrum_hip.h for file:line citations).
+#pragma once
+#include <memory>
+#include <unordered_map>
+
+#include "../../include/ferrum_hip.h"
+#include "block_allocator.h"
+#include "kernels.h"
+#include "kv_layout.h"
+
+namespace fh {
+
+struct LayerWeights {
+    __half* input_ln = nullptr;
+    __half* post_ln = nullptr;
+    __half* q_norm = nullptr;
+    __half* k_norm = nullptr;
+    __half* router = nullptr;      // [E, H] fp16
+    W4Device qkv, o, gate_up, down;
+    W4Device exp_gate_up, exp_down;   // stacked experts
+    std::vector<uint8_t> exp_loaded;   // per expert: bit0 gate_up, bit1 down
+    __half* k_pool = nullptr;
+    __half* v_pool = nullptr;
+};
+
+struct SeqState {
+    std::vector<uint32_t> blocks;
+    int len = 0;
+};
+
+// Layout of the per-forward index block (host pinned mirror → device).
+struct IndexLayout {
+    size_t tokens, cu_seqlens, pos_offsets, kv_lens, sampled_idx, block_tables, total;
+};
+
+}  // namespace fh
+
+struct FerrumHipModel {
+    FerrumHipModelConfig cfg{};
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    int max_blocks_per_seq = 0;
+
+    // weights
+    __half* embed = nullptr;
+    __half* lm_head = nullptr;     // null → tied
+    __half* final_norm = nullptr;
+    float* cos_t = nullptr;
+    float* sin_t = nullptr;
+    std::vector<fh::LayerWeights> layers;
+
+    // KV
+    std::unique_ptr<fh::BlockAllocator> alloc;
+    std::unordered_map<uint64_t, fh::SeqState> seqs;
+
+    // scratch
+    __half *residual = nullptr, *norm_out = nullptr, *qkv_out = nullptr, *q_out = nullptr, *attn_out = nullptr,
+           *o_out = nullptr, *gate_up_out = nullptr, *act_out = nullptr, *mlp_out = nullptr, *sampled_hidden = nullptr,
+           *moe_act = nullptr, *moe_down = nullptr;
+    float* router_logits = nullptr;
+    int32_t *expert_ids = nullptr, *sorted_ids = nullptr, *block_ids = nullptr, *total_post_pad = nullptr;
+    float* expert_w = nullptr;
+    float* logits = nullptr;       // [max_seqs, V] fp32
+    uint32_t* out_tokens = nullptr;   // [max_seqs]
+    float* workspace = nullptr;
+    size_t workspace_bytes = 0;
+    float* taps = nullptr;         // [L, max_tokens, H] fp32 when enabled
+    bool taps_enabled = false;
+    int taps_tokens = 0;
+
+    // index block
+    fh::IndexLayout il{};
+    uint8_t* idx_host = nullptr;   // pinned
+    uint8_t* idx_dev = nullptr;
+
+    // decode-steps state
+    uint32_t* history = nullptr;   // [max_steps, max_seqs] device
+    int history_cap = 0;
+    int32_t* step_counter = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_n = 0, graph_max_kv = 0;
+
+    // tensor parallel (RCCL, resolved lazily by dlopen)
+    void* nccl_comm = nullptr;
+};

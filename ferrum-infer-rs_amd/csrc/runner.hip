@@ -1,0 +1,867 @@
+// Decoder runner (C-ABI `ferrum_hip_model_*`): weights, paged-KV admission, the unified
+// prefill+decode forward and the steady-state decode loop with hipGraph replay.
+//
+// Op order per layer follows the reference's unified forward
+//   LlamaFamilyModel::unified_forward_layer (ferrum-models/src/models/llama_family_forward_batched.rs:2625-3090)
+//   Qwen3MoeModel::unified_forward_layer    (models/qwen3_moe_forward_unified_layer.rs:46-455)
+//   moe_forward_bucketed                    (moe/dispatch.rs:1558-2192)
+// and the drivers unified_forward_internal (models/qwen3_moe_forward_unified.rs:174-445):
+//   embed → L × { rms_norm → qkv → split/qk-norm/rope/paged-write → paged attention → o_proj →
+//   fused_add_rms_norm → [gate_up → act·mul → down | router → top-k → align → grouped gate_up(+silu·mul)
+//   → grouped down → combine] → residual add } → final rms_norm (sampled rows) → lm_head → argmax.
+#include <dlfcn.h>
+#include <math.h>
+
+#include "runner.h"
+
+using namespace fh;
+
+namespace {
+
+int upload_f32_as_f16(const float* src, size_t n, __half** dst) {
+    std::vector<uint16_t> tmp(n);
+    for (size_t i = 0; i < n; i++) {
+        _Float16 h = (_Float16)src[i];
+        memcpy(&tmp[i], &h, 2);
+    }
+    if (!*dst) FH_CHECK_HIP(hipMalloc((void**)dst, n * 2));
+    FH_CHECK_HIP(hipMemcpy(*dst, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T>
+int dev_alloc(T** p, size_t count) {
+    *p = nullptr;
+    if (!count) return 0;
+    FH_CHECK_HIP(hipMalloc((void**)p, count * sizeof(T)));
+    FH_CHECK_HIP(hipMemset(*p, 0, count * sizeof(T)));
+    return 0;
+}
+
+void free_w4(W4Device& w) {
+    if (w.qw) (void)hipFree(w.qw);
+    if (w.sc) (void)hipFree(w.sc);
+    if (w.zp) (void)hipFree(w.zp);
+    if (w.perm) (void)hipFree(w.perm);
+    if (w.bias) (void)hipFree(w.bias);
+    w = W4Device();
+}
+
+int upload_w4(const W4HostPacked& hp, W4Device* w) {
+    free_w4(*w);
+    w->k = hp.k; w->n = hp.n; w->n64 = hp.n64; w->G = hp.G; w->num_experts = 1;
+    FH_CHECK_HIP(hipMalloc((void**)&w->qw, hp.qw.size() * 4));
+    FH_CHECK_HIP(hipMemcpy(w->qw, hp.qw.data(), hp.qw.size() * 4, hipMemcpyHostToDevice));
+    FH_CHECK_HIP(hipMalloc((void**)&w->sc, hp.sc.size() * 2));
+    FH_CHECK_HIP(hipMemcpy(w->sc, hp.sc.data(), hp.sc.size() * 2, hipMemcpyHostToDevice));
+    if (!hp.symmetric) {
+        FH_CHECK_HIP(hipMalloc((void**)&w->zp, hp.zp.size() * 2));
+        FH_CHECK_HIP(hipMemcpy(w->zp, hp.zp.data(), hp.zp.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (!hp.perm.empty()) {
+        FH_CHECK_HIP(hipMalloc((void**)&w->perm, hp.perm.size() * 4));
+        FH_CHECK_HIP(hipMemcpy(w->perm, hp.perm.data(), hp.perm.size() * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+// fused gate_up column order: supertile st = [gate 32st.. | up I+32st..]
+std::vector<int32_t> gate_up_col_perm(int n) {
+    std::vector<int32_t> p(n);
+    const int I = n / 2;
+    for (int st = 0; st < n / 64; st++)
+        for (int c = 0; c < 64; c++) p[st * 64 + c] = c < 32 ? st * 32 + c : I + st * 32 + (c - 32);
+    return p;
+}
+
+// RoPE table (llama_family.rs:5220-5282): angle in f64, stored f32.
+double rope_freq(const FerrumHipModelConfig& c, int i) {
+    double base = 1.0 / pow(c.rope_theta, (double)(2 * i) / (double)c.head_dim);
+    if (c.rope_scaling_kind == 1) return base / c.rope_p0;
+    if (c.rope_scaling_kind == 2) {
+        double wavelen = 2.0 * M_PI / base;
+        double low_wl = c.rope_p3 / c.rope_p1, high_wl = c.rope_p3 / c.rope_p2;
+        if (wavelen < high_wl) return base;
+        if (wavelen > low_wl) return base / c.rope_p0;
+        double smooth = (c.rope_p3 / wavelen - c.rope_p1) / (c.rope_p2 - c.rope_p1);
+        return (1.0 - smooth) * base / c.rope_p0 + smooth * base;
+    }
+    return base;
+}
+
+// ── tiny device helpers of the decode loop ──────────────────────────────────
+// After a decode step: record the sampled tokens, feed them back as the next inputs, advance the
+// per-sequence positions.  Everything the next step needs lives in device buffers, so one captured
+// step can be replayed (the reference keeps per-iter state in buffers for the same reason,
+// kernels/split_qkv_norm_rope_into_paged_cache.cu:9-16).
+__global__ void decode_advance_kernel(const uint32_t* __restrict__ sampled, uint32_t* __restrict__ tokens,
+                                      uint32_t* __restrict__ pos_offsets, uint32_t* __restrict__ kv_lens,
+                                      uint32_t* __restrict__ history, int32_t* __restrict__ step_counter, int n) {
+    int i = threadIdx.x + blockIdx.x * blockDim.x;
+    int step = *step_counter;
+    if (i < n) {
+        uint32_t t = sampled[i];
+        tokens[i] = t;
+        pos_offsets[i] += 1;
+        kv_lens[i] += 1;
+        history[(long)step * n + i] = t;
+    }
+    __syncthreads();
+    if (i == 0) *step_counter = step + 1;
+}
+
+__global__ void f16_to_f32_kernel(const __half* __restrict__ src, float* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = __half2float(src[i]);
+}
+
+// synthetic weights: counter-based hash RNG (splitmix64), reproducible for a given seed
+__device__ __forceinline__ uint64_t splitmix(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void synth_u32_kernel(uint32_t* p, long n, uint64_t seed) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)(splitmix(seed + (uint64_t)i) >> 16);
+}
+__global__ void synth_f16_uniform_kernel(__half* p, long n, uint64_t seed, float lo, float hi) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float u = (float)(splitmix(seed + (uint64_t)i) >> 40) / 16777216.0f;
+        p[i] = __float2half(lo + u * (hi - lo));
+    }
+}
+__global__ void synth_f16_normal_kernel(__half* p, long n, uint64_t seed, float std) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        uint64_t r = splitmix(seed + (uint64_t)i);
+        float u1 = ((float)(r >> 40) + 0.5f) / 16777216.0f, u2 = (float)((r >> 16) & 0xFFFFFF) / 16777216.0f;
+        p[i] = __float2half(std * sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2));
+    }
+}
+__global__ void fill_f16_kernel(__half* p, long n, float v) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = __float2half(v);
+}
+
+int check_shape(const char* what, int k, int n, int ek, int en) {
+    FH_REQUIRE(k == ek && n == en, "model_set_gptq(%s): got K=%d N=%d, config expects K=%d N=%d", what, k, n, ek, en);
+    return 0;
+}
+
+}  // namespace
+
+// RCCL entry points resolved at tp_init
+namespace {
+struct UidBlob { char b[128]; };   // ncclUniqueId is passed by value (128 bytes)
+typedef int (*nccl_get_uid_t)(void*);
+typedef int (*nccl_comm_init_rank_t)(void**, int, UidBlob, int);
+typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+void* g_rccl = nullptr;
+nccl_all_reduce_t g_all_reduce = nullptr;
+int load_rccl() {
+    if (g_rccl) return 0;
+    g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!g_rccl) g_rccl = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    FH_REQUIRE(g_rccl, "tensor parallel: cannot dlopen librccl.so: %s", dlerror());
+    g_all_reduce = (nccl_all_reduce_t)dlsym(g_rccl, "ncclAllReduce");
+    FH_REQUIRE(g_all_reduce, "tensor parallel: ncclAllReduce not found");
+    return 0;
+}
+int tp_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
+    if (m->cfg.tp_world <= 1) return 0;
+    FH_REQUIRE(m->nccl_comm && g_all_reduce, "tensor parallel: communicator not initialised (ferrum_hip_model_tp_init)");
+    // ncclFloat16 = 6, ncclSum = 0 (rccl.h); in-place fp16 sum like nccl_comm.rs all_reduce_in_place
+    int rc = g_all_reduce(buf, buf, count, 6, 0, m->nccl_comm, m->stream);
+    FH_REQUIRE(rc == 0, "ncclAllReduce failed: %d", rc);
+    return 0;
+}
+}  // namespace
+
+static int q_dim(const FerrumHipModelConfig& c) { return c.num_heads * c.head_dim; }
+static int kv_dim(const FerrumHipModelConfig& c) { return c.num_kv_heads * c.head_dim; }
+static int qkv_dim(const FerrumHipModelConfig& c) { return q_dim(c) + 2 * kv_dim(c); }
+
+extern "C" {
+
+int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* cfg) {
+    FH_REQUIRE(model && cfg, "model_create: null argument");
+    FH_REQUIRE(cfg->num_layers > 0 && cfg->hidden > 0 && cfg->hidden % 128 == 0, "model_create: hidden=%d must be a multiple of 128", cfg->hidden);
+    FH_REQUIRE(cfg->num_kv_heads > 0 && cfg->num_heads % cfg->num_kv_heads == 0, "model_create: heads %d/%d", cfg->num_heads, cfg->num_kv_heads);
+    FH_REQUIRE(cfg->num_heads / cfg->num_kv_heads <= 16, "model_create: GQA group %d > 16 unsupported", cfg->num_heads / cfg->num_kv_heads);
+    FH_REQUIRE(cfg->head_dim == 64 || cfg->head_dim == 128 || cfg->head_dim == 256, "model_create: head_dim=%d unsupported", cfg->head_dim);
+    FH_REQUIRE(cfg->max_seqs > 0 && cfg->max_tokens >= cfg->max_seqs && cfg->kv_num_blocks > 0 && cfg->max_seq_len > 0,
+               "model_create: max_seqs/max_tokens/kv_num_blocks/max_seq_len must be positive");
+    FH_REQUIRE(cfg->group_size > 0 && cfg->group_size % 128 == 0, "model_create: group_size=%d must be a multiple of 128", cfg->group_size);
+    if (cfg->num_experts > 0) {
+        FH_REQUIRE(cfg->top_k > 0 && cfg->top_k <= cfg->num_experts && cfg->num_experts <= 512, "model_create: experts=%d top_k=%d", cfg->num_experts, cfg->top_k);
+        FH_REQUIRE(cfg->expert_inter % 128 == 0, "model_create: expert_inter=%d must be a multiple of 128", cfg->expert_inter);
+    } else {
+        FH_REQUIRE(cfg->intermediate > 0 && cfg->intermediate % 128 == 0, "model_create: intermediate=%d must be a multiple of 128", cfg->intermediate);
+    }
+    auto* m = new FerrumHipModel();
+    m->cfg = *cfg;
+    if (m->cfg.tp_world < 1) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
+    m->layers.resize(cfg->num_layers);
+    m->max_blocks_per_seq = cdiv(cfg->max_seq_len, KV_BLOCK);
+    hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete m; fh::set_error("model_create: hipStreamCreate: %s", hipGetErrorString(e)); return 1; }
+    // RoPE tables
+    const int half = cfg->head_dim / 2;
+    std::vector<float> cs((size_t)cfg->max_seq_len * half), sn((size_t)cfg->max_seq_len * half);
+    std::vector<double> freq(half);
+    for (int i = 0; i < half; i++) freq[i] = rope_freq(*cfg, i);
+    for (int pos = 0; pos < cfg->max_seq_len; pos++)
+        for (int i = 0; i < half; i++) {
+            double ang = (double)pos * freq[i];
+            cs[(size_t)pos * half + i] = (float)cos(ang);
+            sn[(size_t)pos * half + i] = (float)sin(ang);
+        }
+    if (hipMalloc((void**)&m->cos_t, cs.size() * 4) != hipSuccess || hipMalloc((void**)&m->sin_t, sn.size() * 4) != hipSuccess) {
+        fh::set_error("model_create: rope table allocation failed");
+        ferrum_hip_model_destroy(m);
+        return 1;
+    }
+    (void)hipMemcpy(m->cos_t, cs.data(), cs.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(m->sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice);
+    m->alloc.reset(new BlockAllocator((uint32_t)cfg->kv_num_blocks));
+    *model = m;
+    return 0;
+}
+
+int ferrum_hip_model_destroy(FerrumHipModel* m) {
+    if (!m) return 0;
+    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+    if (m->graph) (void)hipGraphDestroy(m->graph);
+    for (auto& L : m->layers) {
+        for (__half* p : {L.input_ln, L.post_ln, L.q_norm, L.k_norm, L.router, L.k_pool, L.v_pool})
+            if (p) (void)hipFree(p);
+        free_w4(L.qkv); free_w4(L.o); free_w4(L.gate_up); free_w4(L.down); free_w4(L.exp_gate_up); free_w4(L.exp_down);
+    }
+    for (void* p : {(void*)m->embed, (void*)m->lm_head, (void*)m->final_norm, (void*)m->cos_t, (void*)m->sin_t,
+                    (void*)m->residual, (void*)m->norm_out, (void*)m->qkv_out, (void*)m->q_out, (void*)m->attn_out,
+                    (void*)m->o_out, (void*)m->gate_up_out, (void*)m->act_out, (void*)m->mlp_out,
+                    (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->router_logits,
+                    (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
+                    (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
+                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter})
+        if (p) (void)hipFree(p);
+    if (m->idx_host) (void)hipHostFree(m->idx_host);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return 0;
+}
+
+int ferrum_hip_model_set_global_f32(FerrumHipModel* m, int which, const float* data) {
+    FH_REQUIRE(m && data, "model_set_global: null argument");
+    const size_t vh = (size_t)m->cfg.vocab * m->cfg.hidden;
+    switch (which) {
+    case 0: return upload_f32_as_f16(data, vh, &m->embed);
+    case 1: return upload_f32_as_f16(data, vh, &m->lm_head);
+    case 2: return upload_f32_as_f16(data, m->cfg.hidden, &m->final_norm);
+    }
+    fh::set_error("model_set_global: which=%d", which);
+    return FERRUM_HIP_INVALID;
+}
+
+int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* m, int layer, int which, const float* data) {
+    FH_REQUIRE(m && data && layer >= 0 && layer < m->cfg.num_layers, "model_set_layer_dense: bad argument");
+    LayerWeights& L = m->layers[layer];
+    switch (which) {
+    case 0: return upload_f32_as_f16(data, m->cfg.hidden, &L.input_ln);
+    case 1: return upload_f32_as_f16(data, m->cfg.hidden, &L.post_ln);
+    case 2: return upload_f32_as_f16(data, m->cfg.head_dim, &L.q_norm);
+    case 3: return upload_f32_as_f16(data, m->cfg.head_dim, &L.k_norm);
+    case 4:
+        FH_REQUIRE(m->cfg.num_experts > 0, "model_set_layer_dense: router on a dense model");
+        return upload_f32_as_f16(data, (size_t)m->cfg.num_experts * m->cfg.hidden, &L.router);
+    }
+    fh::set_error("model_set_layer_dense: which=%d", which);
+    return FERRUM_HIP_INVALID;
+}
+
+static int ensure_expert_stack(W4Device* w, int k, int n, int E, bool fused) {
+    if (w->qw) return 0;
+    w->k = k; w->n = n; w->n64 = (n + 63) / 64; w->G = k / 128; w->num_experts = E; w->fused_gate_up = fused;
+    size_t qw = (size_t)w->n64 * w->G * 4 * 64 * 4, sc = (size_t)w->n64 * w->G * 16 * 4;
+    FH_CHECK_HIP(hipMalloc((void**)&w->qw, qw * 4 * E));
+    FH_CHECK_HIP(hipMalloc((void**)&w->sc, sc * 2 * E));
+    return 0;
+}
+
+int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int expert, const int32_t* qweight,
+                              const float* scales, const int32_t* qzeros, const int32_t* g_idx, int k, int n) {
+    FH_REQUIRE(m && qweight && scales && qzeros && layer >= 0 && layer < m->cfg.num_layers, "model_set_gptq: bad argument");
+    const FerrumHipModelConfig& c = m->cfg;
+    LayerWeights& L = m->layers[layer];
+    W4HostPacked hp;
+    const int H = c.hidden;
+    if (which <= 3) {
+        int rc = 0;
+        W4Device* dst = nullptr;
+        switch (which) {
+        case 0: rc = check_shape("qkv", k, n, H, qkv_dim(c)); dst = &L.qkv; break;
+        case 1: rc = check_shape("o", k, n, q_dim(c), H); dst = &L.o; break;
+        case 2: rc = check_shape("gate_up", k, n, H, 2 * c.intermediate); dst = &L.gate_up; break;
+        case 3: rc = check_shape("down", k, n, c.intermediate, H); dst = &L.down; break;
+        }
+        if (rc) return rc;
+        if (int r = w4_repack_host(qweight, scales, qzeros, g_idx, nullptr, c.group_size, k, n, &hp)) return r;
+        return upload_w4(hp, dst);
+    }
+    FH_REQUIRE(which == 4 || which == 5, "model_set_gptq: which=%d", which);
+    FH_REQUIRE(c.num_experts > 0 && expert >= 0 && expert < c.num_experts, "model_set_gptq: expert=%d of %d", expert, c.num_experts);
+    FH_REQUIRE(!g_idx, "model_set_gptq: act-order experts unsupported");
+    const bool gu = which == 4;
+    if (int rc = gu ? check_shape("expert gate_up", k, n, H, 2 * c.expert_inter) : check_shape("expert down", k, n, c.expert_inter, H)) return rc;
+    std::vector<int32_t> perm;
+    if (gu) perm = gate_up_col_perm(n);
+    if (int r = w4_repack_host(qweight, scales, qzeros, nullptr, gu ? perm.data() : nullptr, c.group_size, k, n, &hp)) return r;
+    FH_REQUIRE(hp.symmetric, "model_set_gptq: asymmetric expert zero points are not supported by the runner (use the op API)");
+    W4Device* w = gu ? &L.exp_gate_up : &L.exp_down;
+    if (int rc = ensure_expert_stack(w, k, n, c.num_experts, gu)) return rc;
+    FH_CHECK_HIP(hipMemcpy(w->qw + (size_t)expert * hp.qw.size(), hp.qw.data(), hp.qw.size() * 4, hipMemcpyHostToDevice));
+    FH_CHECK_HIP(hipMemcpy(w->sc + (size_t)expert * hp.sc.size(), hp.sc.data(), hp.sc.size() * 2, hipMemcpyHostToDevice));
+    if (L.exp_loaded.empty()) L.exp_loaded.assign(c.num_experts, 0);
+    L.exp_loaded[expert] |= gu ? 1 : 2;
+    return 0;
+}
+
+static void launch1d(void (*k)(__half*, long, uint64_t, float, float), __half* p, long n, uint64_t seed, float a, float b, hipStream_t s) {
+    hipLaunchKernelGGL(k, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n, seed, a, b);
+}
+
+// Synthetic weights generated on the device (bench only: no checkpoints are available offline).
+// qweight nibbles uniform, scales uniform [0.01,0.1)·f with f = 1/(0.28·sqrt(K)) so that
+// dequantised W has std ≈ 1/sqrt(K) and activations stay O(1) through all layers,
+// zero point 8 (sym), norm weights 1, embeddings / lm_head / router N(0, 0.02).
+static int synth_w4(W4Device* w, int k, int n, int E, bool fused, uint64_t seed, hipStream_t s) {
+    free_w4(*w);
+    w->k = k; w->n = n; w->n64 = (n + 63) / 64; w->G = k / 128; w->num_experts = E; w->fused_gate_up = fused;
+    long qw = (long)w->n64 * w->G * 4 * 64 * 4 * E, sc = (long)w->n64 * w->G * 16 * 4 * E;
+    FH_CHECK_HIP(hipMalloc((void**)&w->qw, qw * 4));
+    FH_CHECK_HIP(hipMalloc((void**)&w->sc, sc * 2));
+    hipLaunchKernelGGL(synth_u32_kernel, dim3(cdiv(qw, 256)), dim3(256), 0, s, w->qw, qw, seed);
+    float f = 1.0f / (0.28f * sqrtf((float)k));
+    launch1d(synth_f16_uniform_kernel, w->sc, sc, seed ^ 0x5ca1e5ull, 0.01f * f, 0.1f * f, s);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
+    FH_REQUIRE(m && !m->finalized, "model_init_synthetic: bad state");
+    const FerrumHipModelConfig& c = m->cfg;
+    hipStream_t s = m->stream;
+    auto alloc_fill = [&](__half** p, long n, float v) -> int {
+        if (!*p) FH_CHECK_HIP(hipMalloc((void**)p, n * 2));
+        hipLaunchKernelGGL(fill_f16_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, *p, n, v);
+        return 0;
+    };
+    auto alloc_normal = [&](__half** p, long n, uint64_t sd, float std) -> int {
+        if (!*p) FH_CHECK_HIP(hipMalloc((void**)p, n * 2));
+        hipLaunchKernelGGL(synth_f16_normal_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, *p, n, sd, std);
+        return 0;
+    };
+    const long vh = (long)c.vocab * c.hidden;
+    if (int rc = alloc_normal(&m->embed, vh, seed ^ 0xe0bedull, 0.02f)) return rc;
+    if (int rc = alloc_normal(&m->lm_head, vh, seed ^ 0x1a4eadull, 0.02f)) return rc;
+    if (int rc = alloc_fill(&m->final_norm, c.hidden, 1.0f)) return rc;
+    for (int li = 0; li < c.num_layers; li++) {
+        LayerWeights& L = m->layers[li];
+        uint64_t ls = seed + 0x1000003ull * (uint64_t)(li + 1);
+        if (int rc = alloc_fill(&L.input_ln, c.hidden, 1.0f)) return rc;
+        if (int rc = alloc_fill(&L.post_ln, c.hidden, 1.0f)) return rc;
+        if (c.has_qk_norm) {
+            if (int rc = alloc_fill(&L.q_norm, c.head_dim, 1.0f)) return rc;
+            if (int rc = alloc_fill(&L.k_norm, c.head_dim, 1.0f)) return rc;
+        }
+        if (int rc = synth_w4(&L.qkv, c.hidden, qkv_dim(c), 1, false, ls ^ 0x11, s)) return rc;
+        if (int rc = synth_w4(&L.o, q_dim(c), c.hidden, 1, false, ls ^ 0x22, s)) return rc;
+        if (c.num_experts > 0) {
+            if (int rc = alloc_normal(&L.router, (long)c.num_experts * c.hidden, ls ^ 0x33, 0.02f)) return rc;
+            if (int rc = synth_w4(&L.exp_gate_up, c.hidden, 2 * c.expert_inter, c.num_experts, true, ls ^ 0x44, s)) return rc;
+            if (int rc = synth_w4(&L.exp_down, c.expert_inter, c.hidden, c.num_experts, false, ls ^ 0x55, s)) return rc;
+            L.exp_loaded.assign(c.num_experts, 3);
+        } else {
+            if (int rc = synth_w4(&L.gate_up, c.hidden, 2 * c.intermediate, 1, false, ls ^ 0x44, s)) return rc;
+            if (int rc = synth_w4(&L.down, c.intermediate, c.hidden, 1, false, ls ^ 0x55, s)) return rc;
+        }
+    }
+    FH_CHECK_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int ferrum_hip_model_finalize(FerrumHipModel* m) {
+    FH_REQUIRE(m, "model_finalize: null");
+    if (m->finalized) return 0;
+    const FerrumHipModelConfig& c = m->cfg;
+    FH_REQUIRE(m->embed && m->final_norm, "model_finalize: embed / final_norm missing");
+    for (int li = 0; li < c.num_layers; li++) {
+        const LayerWeights& L = m->layers[li];
+        FH_REQUIRE(L.input_ln && L.post_ln && L.qkv.qw && L.o.qw, "model_finalize: layer %d attention weights missing", li);
+        FH_REQUIRE(!c.has_qk_norm || (L.q_norm && L.k_norm), "model_finalize: layer %d q/k norm missing", li);
+        if (c.num_experts > 0) {
+            FH_REQUIRE(L.router && L.exp_gate_up.qw && L.exp_down.qw, "model_finalize: layer %d MoE weights missing", li);
+            for (int e = 0; e < c.num_experts; e++)
+                FH_REQUIRE(L.exp_loaded[e] == 3, "model_finalize: layer %d expert %d incomplete", li, e);
+        } else {
+            FH_REQUIRE(L.gate_up.qw && L.down.qw, "model_finalize: layer %d MLP weights missing", li);
+        }
+    }
+    const size_t T = c.max_tokens, S = c.max_seqs, H = c.hidden;
+    // KV pools, zero-initialised
+    for (auto& L : m->layers) {
+        size_t elems = (size_t)c.kv_num_blocks * c.num_kv_heads * kv_tile_elems(c.head_dim);
+        if (int rc = dev_alloc(&L.k_pool, elems)) return rc;
+        if (int rc = dev_alloc(&L.v_pool, elems)) return rc;
+    }
+    int rc = 0;
+    rc |= dev_alloc(&m->residual, T * H);
+    rc |= dev_alloc(&m->norm_out, T * H);
+    rc |= dev_alloc(&m->qkv_out, T * qkv_dim(c));
+    rc |= dev_alloc(&m->q_out, T * q_dim(c));
+    rc |= dev_alloc(&m->attn_out, T * q_dim(c));
+    rc |= dev_alloc(&m->o_out, T * H);
+    rc |= dev_alloc(&m->mlp_out, T * H);
+    rc |= dev_alloc(&m->sampled_hidden, S * H);
+    rc |= dev_alloc(&m->logits, S * (size_t)c.vocab);
+    rc |= dev_alloc(&m->out_tokens, S);
+    if (c.num_experts > 0) {
+        const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 16;
+        rc |= dev_alloc(&m->router_logits, T * c.num_experts);
+        rc |= dev_alloc(&m->expert_ids, P);
+        rc |= dev_alloc(&m->expert_w, P);
+        rc |= dev_alloc(&m->sorted_ids, sorted_max);
+        rc |= dev_alloc(&m->block_ids, sorted_max / 16 + 1);
+        rc |= dev_alloc(&m->total_post_pad, (size_t)4);
+        rc |= dev_alloc(&m->moe_act, P * c.expert_inter);
+        rc |= dev_alloc(&m->moe_down, P * H);
+    } else {
+        rc |= dev_alloc(&m->gate_up_out, T * 2 * c.intermediate);
+        rc |= dev_alloc(&m->act_out, T * (size_t)c.intermediate);
+    }
+    if (rc) return rc;
+    // workspace: split-K slabs (≤ 64 rows) and split-KV attention partials
+    size_t widest = std::max<size_t>({(size_t)qkv_dim(c), (size_t)H, (size_t)2 * std::max(c.intermediate, 1), (size_t)c.vocab});
+    size_t gemm_ws = (size_t)64 * 64 * ((widest + 63) / 64 * 64) * sizeof(float);
+    size_t attn_ws = (size_t)32 * S * c.num_kv_heads * 16 * (c.head_dim + 2) * sizeof(float) * 2;
+    m->workspace_bytes = std::max(gemm_ws, attn_ws);
+    FH_CHECK_HIP(hipMalloc((void**)&m->workspace, m->workspace_bytes));
+    // index block
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    m->il.tokens = take(T * 4);
+    m->il.cu_seqlens = take((S + 1) * 4);
+    m->il.pos_offsets = take(S * 4);
+    m->il.kv_lens = take(S * 4);
+    m->il.sampled_idx = take(S * 4);
+    m->il.block_tables = take(S * m->max_blocks_per_seq * 4);
+    m->il.total = off;
+    FH_CHECK_HIP(hipHostMalloc((void**)&m->idx_host, off, hipHostMallocDefault));
+    FH_CHECK_HIP(hipMalloc((void**)&m->idx_dev, off));
+    FH_CHECK_HIP(hipMemset(m->idx_dev, 0, off));
+    if (int r = dev_alloc(&m->step_counter, (size_t)4)) return r;
+    m->finalized = true;
+    return 0;
+}
+
+int ferrum_hip_model_kv_capacity_snapshot(const FerrumHipModel* m, FerrumHipKvSlotReservation* out) {
+    FH_REQUIRE(m && out, "kv_capacity_snapshot: null");
+    out->block_size = KV_BLOCK;
+    out->total_blocks = (int)m->alloc->capacity();
+    out->free_blocks_before = out->free_blocks_after = (int)m->alloc->free_count();
+    return 0;
+}
+
+// reserve_paged_kv_slots (llama_family.rs:2255) + PagedSeqState::ensure_capacity (paged_pool.rs:416-442)
+static int reserve(FerrumHipModel* m, const FerrumHipKvSlotRequest* reqs, int n, FerrumHipKvSlotReservation* out) {
+    const int before = (int)m->alloc->free_count();
+    long need = 0;
+    for (int i = 0; i < n; i++) {
+        int blocks = cdiv(reqs[i].target_len, KV_BLOCK);
+        if (blocks > m->max_blocks_per_seq) {
+            fh::set_error("paged KV: target_len=%d would need %d blocks, exceeds max_blocks_per_seq=%d", reqs[i].target_len, blocks, m->max_blocks_per_seq);
+            return FERRUM_HIP_INVALID;
+        }
+        auto it = m->seqs.find(reqs[i].seq_id);
+        int have = it == m->seqs.end() ? 0 : (int)it->second.blocks.size();
+        if (blocks > have) need += blocks - have;
+    }
+    if (need > before) {
+        fh::set_error("paged KV pool exhausted: need %ld blocks but only %d free", need, before);
+        return FERRUM_HIP_INVALID;
+    }
+    for (int i = 0; i < n; i++) {
+        SeqState& st = m->seqs[reqs[i].seq_id];
+        int blocks = cdiv(reqs[i].target_len, KV_BLOCK);
+        while ((int)st.blocks.size() < blocks) {
+            uint32_t b;
+            m->alloc->allocate(&b);
+            st.blocks.push_back(b);
+        }
+    }
+    if (out) {
+        out->block_size = KV_BLOCK;
+        out->total_blocks = (int)m->alloc->capacity();
+        out->free_blocks_before = before;
+        out->free_blocks_after = (int)m->alloc->free_count();
+    }
+    return 0;
+}
+
+int ferrum_hip_model_reserve_kv_slots(FerrumHipModel* m, const FerrumHipKvSlotRequest* reqs, int n,
+                                      FerrumHipKvSlotReservation* out) {
+    FH_REQUIRE(m && (n == 0 || reqs), "reserve_kv_slots: null");
+    return reserve(m, reqs, n, out);
+}
+
+int ferrum_hip_model_release(FerrumHipModel* m, uint64_t seq_id) {
+    FH_REQUIRE(m, "model_release: null");
+    auto it = m->seqs.find(seq_id);
+    if (it == m->seqs.end()) return 0;
+    m->alloc->free(it->second.blocks.data(), (uint32_t)it->second.blocks.size());
+    m->seqs.erase(it);
+    return 0;
+}
+
+int ferrum_hip_model_block_table(const FerrumHipModel* m, uint64_t seq_id, uint32_t* blocks, int capacity,
+                                 int* num_blocks, int* kv_len) {
+    FH_REQUIRE(m, "model_block_table: null");
+    auto it = m->seqs.find(seq_id);
+    FH_REQUIRE(it != m->seqs.end(), "model_block_table: unknown sequence %llu", (unsigned long long)seq_id);
+    int nb = (int)it->second.blocks.size();
+    if (num_blocks) *num_blocks = nb;
+    if (kv_len) *kv_len = it->second.len;
+    for (int i = 0; i < nb && i < capacity; i++) blocks[i] = it->second.blocks[i];
+    return 0;
+}
+
+int ferrum_hip_model_read_kv_f32(FerrumHipModel* m, uint64_t seq_id, int layer, int is_v, float* out_host) {
+    FH_REQUIRE(m && m->finalized && out_host && layer >= 0 && layer < m->cfg.num_layers, "model_read_kv: bad argument");
+    auto it = m->seqs.find(seq_id);
+    FH_REQUIRE(it != m->seqs.end(), "model_read_kv: unknown sequence");
+    const SeqState& st = it->second;
+    if (st.len == 0) return 0;
+    const FerrumHipModelConfig& c = m->cfg;
+    size_t n = (size_t)st.len * c.num_kv_heads * c.head_dim;
+    __half *kd = nullptr, *vd = nullptr;
+    float* fd = nullptr;
+    int32_t* bt = nullptr;
+    FH_CHECK_HIP(hipMalloc((void**)&kd, n * 2));
+    FH_CHECK_HIP(hipMalloc((void**)&vd, n * 2));
+    FH_CHECK_HIP(hipMalloc((void**)&fd, n * 4));
+    FH_CHECK_HIP(hipMalloc((void**)&bt, st.blocks.size() * 4));
+    FH_CHECK_HIP(hipMemcpy(bt, st.blocks.data(), st.blocks.size() * 4, hipMemcpyHostToDevice));
+    int rc = paged_kv_read_f16(m->layers[layer].k_pool, m->layers[layer].v_pool, bt, st.len, c.num_kv_heads, c.head_dim,
+                               KV_BLOCK, kd, vd, m->stream);
+    if (!rc) {
+        hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, m->stream, is_v ? vd : kd, fd, (long)n);
+        (void)hipMemcpyAsync(out_host, fd, n * 4, hipMemcpyDeviceToHost, m->stream);
+        (void)hipStreamSynchronize(m->stream);
+    }
+    (void)hipFree(kd); (void)hipFree(vd); (void)hipFree(fd); (void)hipFree(bt);
+    return rc;
+}
+
+int ferrum_hip_model_enable_taps(FerrumHipModel* m, int enable) {
+    FH_REQUIRE(m && m->finalized, "model_enable_taps: bad state");
+    m->taps_enabled = enable != 0;
+    if (m->taps_enabled && !m->taps)
+        return dev_alloc(&m->taps, (size_t)m->cfg.num_layers * m->cfg.max_tokens * m->cfg.hidden);
+    return 0;
+}
+int ferrum_hip_model_read_taps(FerrumHipModel* m, float* out_host, int max_tokens) {
+    FH_REQUIRE(m && m->taps && out_host, "model_read_taps: taps not enabled");
+    const int T = std::min(max_tokens, m->taps_tokens);
+    for (int li = 0; li < m->cfg.num_layers; li++)
+        FH_CHECK_HIP(hipMemcpy(out_host + (size_t)li * max_tokens * m->cfg.hidden,
+                               m->taps + (size_t)li * m->cfg.max_tokens * m->cfg.hidden,
+                               (size_t)T * m->cfg.hidden * 4, hipMemcpyDeviceToHost));
+    return 0;
+}
+int ferrum_hip_model_stream(FerrumHipModel* m, void** stream) {
+    FH_REQUIRE(m && stream, "model_stream: null");
+    *stream = m->stream;
+    return 0;
+}
+
+}  // extern "C"
+
+// ── the forward itself ──────────────────────────────────────────────────────
+namespace {
+
+struct StepShape {
+    int m_total, num_seqs, max_q_len, max_kv_len, num_sampled;
+    bool pure_decode;
+};
+
+template <typename T>
+T* idx(FerrumHipModel* m, size_t off) { return reinterpret_cast<T*>(m->idx_dev + off); }
+
+// Enqueue every kernel of one forward on m->stream.  Index tensors are already on the device.
+int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
+    const FerrumHipModelConfig& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int T = sh.m_total, H = c.hidden, nq = c.num_heads, nkv = c.num_kv_heads, hd = c.head_dim;
+    const int qk_mode = c.has_qk_norm ? 1 : 2;
+    const uint32_t* tokens = idx<uint32_t>(m, m->il.tokens);
+    const uint32_t* cu = idx<uint32_t>(m, m->il.cu_seqlens);
+    const uint32_t* pos = idx<uint32_t>(m, m->il.pos_offsets);
+    const uint32_t* kvl = idx<uint32_t>(m, m->il.kv_lens);
+    const int32_t* sampled_idx = idx<int32_t>(m, m->il.sampled_idx);
+    const int32_t* bt = idx<int32_t>(m, m->il.block_tables);
+    int rc;
+#define RUN(x) if ((rc = (x))) return rc
+    RUN(embedding_lookup_f16(m->embed, tokens, m->residual, T, H, s));
+    for (int li = 0; li < c.num_layers; li++) {
+        LayerWeights& L = m->layers[li];
+        const __half* dummy = L.input_ln;
+        RUN(rms_norm_f16(m->residual, L.input_ln, c.rms_eps, m->norm_out, T, H, s));
+        RUN(w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s));
+        RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
+                                                            m->cos_t, m->sin_t, m->q_out, L.k_pool, L.v_pool, cu, pos, bt,
+                                                            sh.num_seqs, T, nq, nkv, hd, c.rms_eps, qk_mode, KV_BLOCK,
+                                                            m->max_blocks_per_seq, s));
+        if (sh.pure_decode) {
+            RUN(paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, bt, kvl, sh.num_seqs,
+                                                   sh.max_kv_len, nq, nkv, hd, KV_BLOCK, m->max_blocks_per_seq,
+                                                   m->workspace, m->workspace_bytes, s));
+        } else {
+            RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu, pos, bt, sh.num_seqs, T,
+                                           sh.max_q_len, sh.max_kv_len, nq, nkv, hd, c.sliding_window, KV_BLOCK,
+                                           m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
+        }
+        RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+        RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+        RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+        if (c.num_experts > 0) {
+            const int E = c.num_experts, K = c.top_k, P = T * K, sorted_max = P + E * 16;
+            RUN(f16_gemm_f32out(m->norm_out, L.router, m->router_logits, T, E, H, m->workspace, m->workspace_bytes, s));
+            RUN(moe_route_topk_softmax_f32(m->router_logits, m->expert_ids, m->expert_w, T, E, K, c.norm_topk_prob, s));
+            RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
+            // Σ_e ceil(cnt_e/16) ≤ P/16 + min(P, E): the grid covers every block that can exist
+            const int max_blocks = std::min(sorted_max / 16, P / 16 + std::min(P, E));
+            RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                            max_blocks, K, 1, s));
+            RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                            max_blocks, 1, 0, s));
+            // combine + residual add in one pass (tp: experts are not sharded — SURVEY.md §8e)
+            RUN(moe_combine_f16(m->moe_down, m->expert_w, m->residual, T, K, H, 1, s));
+        } else {
+            const int I = c.intermediate;
+            RUN(w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s));
+            if (c.activation == 1) {
+                RUN(fused_gelu_tanh_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
+            } else {
+                RUN(fused_silu_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
+            }
+            RUN(w4_gemm_dense(L.down, m->act_out, m->mlp_out, T, m->workspace, m->workspace_bytes, s));
+            RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
+            RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
+        }
+        if (m->taps_enabled && m->taps) {
+            hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)T * H, 256)), dim3(256), 0, s, m->residual,
+                               m->taps + (size_t)li * c.max_tokens * H, (long)T * H);
+        }
+    }
+    m->taps_tokens = T;
+    if (sh.num_sampled > 0) {
+        // final norm + lm_head on the sampled rows only (same rows the reference packs,
+        // qwen3_moe_forward_unified.rs:365-392)
+        RUN(gather_rows_f16(m->residual, sampled_idx, m->sampled_hidden, sh.num_sampled, H, s));
+        RUN(rms_norm_f16(m->sampled_hidden, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
+        RUN(f16_gemm_f32out(m->sampled_hidden, m->lm_head ? m->lm_head : m->embed, m->logits, sh.num_sampled, c.vocab, H,
+                            m->workspace, m->workspace_bytes, s));
+        if (greedy) RUN(argmax_rows_f32(m->logits, m->out_tokens, nullptr, 0, sh.num_sampled, c.vocab, s));
+    }
+#undef RUN
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ferrum_hip_model_unified_forward(FerrumHipModel* m, const FerrumHipBatchItem* items, int num_items, int greedy,
+                                     uint32_t* out_tokens, float* logits_out) {
+    FH_REQUIRE(m && m->finalized, "unified_forward: model not finalized");
+    if (num_items <= 0) return 0;
+    FH_REQUIRE(items, "unified_forward: null items");
+    const FerrumHipModelConfig& c = m->cfg;
+    FH_REQUIRE(num_items <= c.max_seqs, "unified_forward: %d items > max_seqs %d", num_items, c.max_seqs);
+    // shape + admission
+    StepShape sh{};
+    sh.num_seqs = num_items;
+    sh.pure_decode = true;
+    std::vector<FerrumHipKvSlotRequest> reqs(num_items);
+    for (int i = 0; i < num_items; i++) {
+        const FerrumHipBatchItem& it = items[i];
+        FH_REQUIRE(it.num_q_tokens > 0 && it.q_tokens, "unified_forward: item %d has no tokens", i);
+        auto f = m->seqs.find(it.seq_id);
+        int have = f == m->seqs.end() ? 0 : f->second.len;
+        FH_REQUIRE(it.pos_offset == have, "unified_forward: item %d pos_offset=%d but cache holds %d tokens", i, it.pos_offset, have);
+        FH_REQUIRE(it.pos_offset + it.num_q_tokens <= c.max_seq_len, "unified_forward: item %d exceeds max_seq_len %d", i, c.max_seq_len);
+        for (int t = 0; t < it.num_q_tokens; t++)
+            FH_REQUIRE(it.q_tokens[t] < (uint32_t)c.vocab, "unified_forward: item %d token %u out of vocab", i, it.q_tokens[t]);
+        sh.m_total += it.num_q_tokens;
+        sh.max_q_len = std::max(sh.max_q_len, it.num_q_tokens);
+        sh.max_kv_len = std::max(sh.max_kv_len, it.pos_offset + it.num_q_tokens);
+        if (it.num_q_tokens != 1) sh.pure_decode = false;
+        if (it.is_final_chunk) sh.num_sampled++;
+        reqs[i] = {it.seq_id, it.pos_offset + it.num_q_tokens, 0};
+    }
+    FH_REQUIRE(sh.m_total <= c.max_tokens, "unified_forward: %d tokens > max_tokens %d", sh.m_total, c.max_tokens);
+    if (c.sliding_window > 0) sh.pure_decode = false;
+    if (int rc = reserve(m, reqs.data(), num_items, nullptr)) return rc;
+
+    // index block
+    uint32_t* h_tok = reinterpret_cast<uint32_t*>(m->idx_host + m->il.tokens);
+    uint32_t* h_cu = reinterpret_cast<uint32_t*>(m->idx_host + m->il.cu_seqlens);
+    uint32_t* h_pos = reinterpret_cast<uint32_t*>(m->idx_host + m->il.pos_offsets);
+    uint32_t* h_kvl = reinterpret_cast<uint32_t*>(m->idx_host + m->il.kv_lens);
+    int32_t* h_samp = reinterpret_cast<int32_t*>(m->idx_host + m->il.sampled_idx);
+    int32_t* h_bt = reinterpret_cast<int32_t*>(m->idx_host + m->il.block_tables);
+    int t = 0, j = 0;
+    for (int i = 0; i < num_items; i++) {
+        const FerrumHipBatchItem& it = items[i];
+        h_cu[i] = (uint32_t)t;
+        memcpy(h_tok + t, it.q_tokens, (size_t)it.num_q_tokens * 4);
+        t += it.num_q_tokens;
+        h_pos[i] = (uint32_t)it.pos_offset;
+        h_kvl[i] = (uint32_t)(it.pos_offset + it.num_q_tokens);
+        if (it.is_final_chunk) h_samp[j++] = t - 1;
+        const SeqState& st = m->seqs[it.seq_id];
+        int32_t* row = h_bt + (size_t)i * m->max_blocks_per_seq;
+        for (int b = 0; b < m->max_blocks_per_seq; b++) row[b] = b < (int)st.blocks.size() ? (int32_t)st.blocks[b] : 0;   // padded with 0 (paged_pool.rs:438-440)
+    }
+    h_cu[num_items] = (uint32_t)t;
+    // only the used prefix of the block-table region needs to travel
+    size_t used = m->il.block_tables + (size_t)num_items * m->max_blocks_per_seq * 4;
+    FH_CHECK_HIP(hipMemcpyAsync(m->idx_dev, m->idx_host, used, hipMemcpyHostToDevice, m->stream));
+    if (int rc = enqueue_forward(m, sh, greedy != 0)) return rc;
+    if (sh.num_sampled > 0) {
+        if (greedy && out_tokens)
+            FH_CHECK_HIP(hipMemcpyAsync(out_tokens, m->out_tokens, (size_t)sh.num_sampled * 4, hipMemcpyDeviceToHost, m->stream));
+        if (logits_out)
+            FH_CHECK_HIP(hipMemcpyAsync(logits_out, m->logits, (size_t)sh.num_sampled * c.vocab * 4, hipMemcpyDeviceToHost, m->stream));
+    }
+    FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < num_items; i++) m->seqs[items[i].seq_id].len += items[i].num_q_tokens;
+    return 0;
+}
+
+int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, const uint32_t* first_tokens, int n,
+                                  int steps, uint32_t* out_tokens) {
+    FH_REQUIRE(m && m->finalized && seq_ids && first_tokens, "decode_steps: bad argument");
+    if (n <= 0 || steps <= 0) return 0;
+    const FerrumHipModelConfig& c = m->cfg;
+    FH_REQUIRE(n <= c.max_seqs && n <= 1024, "decode_steps: %d sequences > max_seqs %d (or 1024)", n, c.max_seqs);
+    FH_REQUIRE(c.sliding_window == 0, "decode_steps: sliding-window models use unified_forward");
+    // admission for the whole run up front: block tables are then constant across the steps
+    std::vector<FerrumHipKvSlotRequest> reqs(n);
+    StepShape sh{};
+    sh.m_total = sh.num_seqs = sh.num_sampled = n;
+    sh.max_q_len = 1;
+    sh.pure_decode = true;
+    for (int i = 0; i < n; i++) {
+        auto f = m->seqs.find(seq_ids[i]);
+        FH_REQUIRE(f != m->seqs.end() && f->second.len > 0, "decode_steps: sequence %llu has no prefilled context", (unsigned long long)seq_ids[i]);
+        FH_REQUIRE(f->second.len + steps <= c.max_seq_len, "decode_steps: sequence %llu would exceed max_seq_len", (unsigned long long)seq_ids[i]);
+        FH_REQUIRE(first_tokens[i] < (uint32_t)c.vocab, "decode_steps: token out of vocab");
+        reqs[i] = {seq_ids[i], f->second.len + steps, 0};
+        sh.max_kv_len = std::max(sh.max_kv_len, f->second.len + steps);
+    }
+    if (int rc = reserve(m, reqs.data(), n, nullptr)) return rc;
+    if (m->history_cap < steps * n) {
+        if (m->history) (void)hipFree(m->history);
+        m->history = nullptr;
+        FH_CHECK_HIP(hipMalloc((void**)&m->history, (size_t)steps * n * 4));
+        m->history_cap = steps * n;
+    }
+    uint32_t* h_tok = reinterpret_cast<uint32_t*>(m->idx_host + m->il.tokens);
+    uint32_t* h_cu = reinterpret_cast<uint32_t*>(m->idx_host + m->il.cu_seqlens);
+    uint32_t* h_pos = reinterpret_cast<uint32_t*>(m->idx_host + m->il.pos_offsets);
+    uint32_t* h_kvl = reinterpret_cast<uint32_t*>(m->idx_host + m->il.kv_lens);
+    int32_t* h_samp = reinterpret_cast<int32_t*>(m->idx_host + m->il.sampled_idx);
+    int32_t* h_bt = reinterpret_cast<int32_t*>(m->idx_host + m->il.block_tables);
+    for (int i = 0; i < n; i++) {
+        const SeqState& st = m->seqs[seq_ids[i]];
+        h_tok[i] = first_tokens[i];
+        h_cu[i] = (uint32_t)i;
+        h_pos[i] = (uint32_t)st.len;
+        h_kvl[i] = (uint32_t)st.len + 1;
+        h_samp[i] = i;
+        int32_t* row = h_bt + (size_t)i * m->max_blocks_per_seq;
+        for (int b = 0; b < m->max_blocks_per_seq; b++) row[b] = b < (int)st.blocks.size() ? (int32_t)st.blocks[b] : 0;
+    }
+    h_cu[n] = (uint32_t)n;
+    size_t used = m->il.block_tables + (size_t)n * m->max_blocks_per_seq * 4;
+    FH_CHECK_HIP(hipMemcpyAsync(m->idx_dev, m->idx_host, used, hipMemcpyHostToDevice, m->stream));
+    FH_CHECK_HIP(hipMemsetAsync(m->step_counter, 0, 4, m->stream));
+
+    auto enqueue_step = [&]() -> int {
+        if (int rc = enqueue_forward(m, sh, true)) return rc;
+        hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1024), 0, m->stream, m->out_tokens,
+                           idx<uint32_t>(m, m->il.tokens), idx<uint32_t>(m, m->il.pos_offsets),
+                           idx<uint32_t>(m, m->il.kv_lens), m->history, m->step_counter, n);
+        FH_CHECK_LAUNCH();
+        return 0;
+    };
+
+    // One decode step is captured into a hipGraph (BackendGraph, capabilities.rs:35-70) and
+    // replayed: every per-step quantity lives in device buffers.  A graph is reusable while
+    // (n, grid-shaping max_kv_len bucket) stay the same.  TP uses eager launches (RCCL).
+    const bool use_graph = c.tp_world == 1 && !m->taps_enabled && getenv("FERRUM_HIP_NO_GRAPH") == nullptr;
+    int kv_bucket = cdiv(sh.max_kv_len, 256) * 256;
+    sh.max_kv_len = kv_bucket;
+    if (use_graph) {
+        if (!m->graph_exec || m->graph_n != n || m->graph_max_kv != kv_bucket) {
+            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+            FH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_step();
+            hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+            if (rc) return rc;
+            FH_CHECK_HIP(e);
+            FH_CHECK_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            m->graph_n = n;
+            m->graph_max_kv = kv_bucket;
+        }
+        for (int st = 0; st < steps; st++) FH_CHECK_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+    } else {
+        for (int st = 0; st < steps; st++)
+            if (int rc = enqueue_step()) return rc;
+    }
+    if (out_tokens)
+        FH_CHECK_HIP(hipMemcpyAsync(out_tokens, m->history, (size_t)steps * n * 4, hipMemcpyDeviceToHost, m->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    for (int i = 0; i < n; i++) m->seqs[seq_ids[i]].len += steps;
+    return 0;
+}
+
+int ferrum_hip_tp_unique_id(uint8_t id[128]) {
+    if (int rc = load_rccl()) return rc;
+    auto f = (nccl_get_uid_t)dlsym(g_rccl, "ncclGetUniqueId");
+    FH_REQUIRE(f, "tensor parallel: ncclGetUniqueId not found");
+    int rc = f(id);
+    FH_REQUIRE(rc == 0, "ncclGetUniqueId failed: %d", rc);
+    return 0;
+}
+
+int ferrum_hip_model_tp_init(FerrumHipModel* m, const uint8_t id[128]) {
+    FH_REQUIRE(m && id, "tp_init: null");
+    if (m->cfg.tp_world <= 1) return 0;
+    if (int rc = load_rccl()) return rc;
+    auto f = (nccl_comm_init_rank_t)dlsym(g_rccl, "ncclCommInitRank");
+    FH_REQUIRE(f, "tensor parallel: ncclCommInitRank not found");
+    UidBlob blob;
+    memcpy(blob.b, id, 128);
+    int rc = f(&m->nccl_comm, m->cfg.tp_world, blob, m->cfg.tp_rank);
+    FH_REQUIRE(rc == 0, "ncclCommInitRank failed: %d", rc);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,544 @@
+// GPTQ-INT4 dequant-GEMM for gfx950 (skinny-M / decode regime) and the MoE grouped form.
+//
+// Replaces, on the reference side: `GptqLinear::forward` → `B::load_gptq` + Marlin
+// (ferrum-quantization/src/gptq.rs:42-112, ferrum-kernels/src/backend/cuda/marlin.rs:488-633)
+// and `MarlinExpertStack::gemm_phase_vllm` (ferrum-kernels/src/marlin_expert_stack.rs:86).
+// Arithmetic contract (cpu.rs:2283-2315): W[n,k] = (q − (z+1))·s[k/g, n].
+//
+// Design (HBM-bound at T ≤ 64):
+//  * load-time repack GPTQ [K/8,N] → "w4t" tiles: one wave-instruction (64 lanes × 16 B = 1 KiB,
+//    fully coalesced) fetches a 16-column × 128-row (= one quant group) tile whose per-lane dwords
+//    ARE the B-operand fragments of four v_mfma_f32_16x16x32_f16 k-steps.
+//  * weights go HBM → VGPR directly (no LDS round trip: each weight byte is used once);
+//    nibbles are expanded to exact fp16 integers (q − zero) with the 0x6400 magic-number trick
+//    (9 VALU per 8 weights) and the group scale is applied to the fp32 MFMA partial sum, so the
+//    only rounding is fp32 accumulation.
+//  * activations are the A operand (rows = tokens, padded to 16); a wave owns a 64-column
+//    "supertile" so every A fragment feeds four MFMAs.
+//  * split-K writes fp32 slabs that a small epilogue kernel sums in fixed order (deterministic).
+#include "common.h"
+#include "kernels.h"
+
+namespace fh {
+
+// ───────────────────────────── repacked layout ─────────────────────────────
+// qw : u32  [n64][G][4 nt][64 lanes][4 ksteps]          (G = K/128, n64 = ceil(N/64))
+//      lane l=(a=l>>4, b=l&15); dword s holds k = g·128 + 32s + 8a + {0..7} for column
+//      n = st·64 + nt·16 + b, nibble order [k0,k2,k4,k6,k1,k3,k5,k7] (cheap pair extraction).
+// sc : f16  [n64][G][16 b][4 nt]                         group scale of column st·64+nt·16+b
+// zp : f16  [n64][G][16 b][4 nt]  (only when asymmetric)  value (z+1) as fp16
+
+static inline uint32_t permute_nibbles(const uint8_t q[8]) {
+    // output nibble i ← k index order [0,2,4,6,1,3,5,7]
+    static const int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+    uint32_t w = 0;
+    for (int i = 0; i < 8; i++) w |= (uint32_t)(q[order[i]] & 0xF) << (4 * i);
+    return w;
+}
+
+static inline uint16_t f32_to_f16_bits(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* qzeros,
+                   const int32_t* g_idx, const int32_t* col_perm, int group_size, int k, int n,
+                   W4HostPacked* out) {
+    FH_REQUIRE(k % 128 == 0, "w4 repack: K=%d must be a multiple of 128", k);
+    FH_REQUIRE(n % 8 == 0, "w4 repack: N=%d must be a multiple of 8", n);
+    FH_REQUIRE(group_size > 0 && group_size % 128 == 0 && k % group_size == 0,
+               "w4 repack: group_size=%d must be a multiple of 128 dividing K=%d", group_size, k);
+    const int G = k / 128, n64 = (n + 63) / 64;
+    const int num_groups = k / group_size;
+
+    // act-order: rows sorted by g_idx so that quant groups become contiguous
+    // (same transform the reference applies before Marlin: cuda/quant.rs:434 + gather_columns).
+    std::vector<int32_t> perm;
+    bool use_perm = false;
+    if (g_idx) {
+        bool sequential = true;
+        for (int i = 0; i < k; i++)
+            if (g_idx[i] != i / group_size) { sequential = false; break; }
+        if (!sequential) {
+            use_perm = true;
+            perm.resize(k);
+            for (int i = 0; i < k; i++) perm[i] = i;
+            std::stable_sort(perm.begin(), perm.end(), [&](int x, int y) { return g_idx[x] < g_idx[y]; });
+            std::vector<int> counts(num_groups, 0);
+            for (int i = 0; i < k; i++) {
+                FH_REQUIRE(g_idx[i] >= 0 && g_idx[i] < num_groups, "w4 repack: g_idx[%d]=%d out of range", i, g_idx[i]);
+                counts[g_idx[i]]++;
+            }
+            for (int g = 0; g < num_groups; g++)
+                FH_REQUIRE(counts[g] == group_size, "w4 repack: act-order groups must be balanced (group %d has %d rows)", g, counts[g]);
+        }
+    }
+    // symmetric ⇔ every zero nibble is 7 (zero point 8), the `sym=true` canonical form
+    // (ferrum-quantization/src/native_safetensors.rs:1242).
+    bool symmetric = true;
+    for (long i = 0; i < (long)num_groups * (n / 8); i++)
+        if ((uint32_t)qzeros[i] != 0x77777777u) { symmetric = false; break; }
+
+    out->k = k; out->n = n; out->n64 = n64; out->G = G; out->symmetric = symmetric;
+    out->qw.assign((size_t)n64 * G * 4 * 64 * 4, 0);
+    out->sc.assign((size_t)n64 * G * 16 * 4, 0);
+    if (!symmetric) out->zp.assign((size_t)n64 * G * 16 * 4, f32_to_f16_bits(8.0f));
+    else out->zp.clear();
+    out->perm = perm;
+
+    auto src_k = [&](int kk) { return use_perm ? perm[kk] : kk; };
+    for (int st = 0; st < n64; st++)
+        for (int g = 0; g < G; g++) {
+            for (int nt = 0; nt < 4; nt++)
+                for (int lane = 0; lane < 64; lane++) {
+                    int a = lane >> 4, b = lane & 15;
+                    int np = st * 64 + nt * 16 + b;          // packed column
+                    int col = np < n ? (col_perm ? col_perm[np] : np) : -1;
+                    for (int s = 0; s < 4; s++) {
+                        uint8_t q[8];
+                        for (int j = 0; j < 8; j++) {
+                            int kk = src_k(g * 128 + 32 * s + 8 * a + j);
+                            // padded columns decode to q − zero = 0 (zero point 8 when symmetric)
+                            q[j] = col < 0 ? 8
+                                           : (uint8_t)(((uint32_t)qweight[(long)(kk / 8) * n + col] >> (4 * (kk % 8))) & 0xF);
+                        }
+                        out->qw[((((size_t)st * G + g) * 4 + nt) * 64 + lane) * 4 + s] = permute_nibbles(q);
+                    }
+                }
+            for (int b = 0; b < 16; b++)
+                for (int nt = 0; nt < 4; nt++) {
+                    int np = st * 64 + nt * 16 + b;
+                    int col = np < n ? (col_perm ? col_perm[np] : np) : -1;
+                    size_t idx = (((size_t)st * G + g) * 16 + b) * 4 + nt;
+                    if (col < 0) { out->sc[idx] = 0; continue; }
+                    int kk0 = src_k(g * 128);
+                    int grp = g_idx ? g_idx[kk0] : kk0 / group_size;
+                    out->sc[idx] = f32_to_f16_bits(scales[(long)grp * n + col]);
+                    if (!symmetric) {
+                        uint32_t zw = (uint32_t)qzeros[(long)grp * (n / 8) + col / 8];
+                        int zero = (int)((zw >> (4 * (col % 8))) & 0xF) + 1;
+                        out->zp[idx] = f32_to_f16_bits((float)zero);
+                    }
+                }
+        }
+    return 0;
+}
+
+// ─────────────────────────────── device code ───────────────────────────────
+
+__device__ __forceinline__ half2v u32_as_half2(uint32_t u) {
+    union { uint32_t u; half2v h; } c;
+    c.u = u;
+    return c.h;
+}
+
+// Expand one packed dword (8 nibbles) to 8 exact fp16 integers (q − zero).
+// c_lo = −(1024+zero), c_hi = −(64+zero), both broadcast to the two fp16 lanes.
+__device__ __forceinline__ half8 dequant8(uint32_t w, half2v c_lo, half2v c_hi) {
+    const half2v sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+    uint32_t w8 = w >> 8;
+    half2v p0 = u32_as_half2((w & 0x000F000Fu) | 0x64006400u) + c_lo;                                      // k0,k1
+    half2v p1 = __builtin_elementwise_fma(u32_as_half2((w & 0x00F000F0u) | 0x64006400u), sixteenth, c_hi);  // k2,k3
+    half2v p2 = u32_as_half2((w8 & 0x000F000Fu) | 0x64006400u) + c_lo;                                     // k4,k5
+    half2v p3 = __builtin_elementwise_fma(u32_as_half2((w8 & 0x00F000F0u) | 0x64006400u), sixteenth, c_hi); // k6,k7
+    half8 r;
+    r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
+    r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
+    return r;
+}
+
+struct W4Args {
+    const uint32_t* qw;   // repacked weights (expert 0)
+    const __half* sc;
+    const __half* zp;     // null when symmetric
+    long expert_stride_qw;   // dwords between experts (MoE), 0 for dense
+    long expert_stride_sc;   // halves between experts
+    const __half* x;      // activations [rows, K]
+    __half* out;          // fp16 output [rows, ldo] (non-split, or fused-act)
+    float* partial;       // fp32 slabs [S][rows_pad][n_pad] when split-K
+    int M;                // rows (dense) / number of valid pair ids (MoE: T·k)
+    int K, N, G, n64;
+    int ldo;              // output row stride (elements)
+    int S;                // K splits
+    // MoE routing (null for dense)
+    const int32_t* sorted_token_ids;
+    const int32_t* block_ids;
+    const int32_t* total_post_pad;
+    int top_k;            // input row = id / top_k
+    int rows_pad;         // slab row count
+    int n_pad;            // slab column count (= n64·64)
+};
+
+// MODE: 0 dense, 1 MoE (plain output), 2 MoE gate_up with fused silu·mul epilogue
+template <int MT, bool HAS_ZP, int MODE>
+__global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int st = blockIdx.x * 4 + wave;          // 64-column supertile owned by this wave
+    if (st >= p.n64) return;
+    const int rb = blockIdx.y;                     // row block (16·MT rows)
+    const int z = blockIdx.z;                      // K split
+
+    const uint32_t* qw = p.qw;
+    const __half* sc = p.sc;
+    const __half* zp = p.zp;
+    int row_in[MT], row_out[MT];
+    bool row_ok[MT];
+    if (MODE == 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            int r = rb * 16 * MT + mt * 16 + b;
+            row_ok[mt] = r < p.M;
+            row_in[mt] = row_ok[mt] ? r : p.M - 1;
+            row_out[mt] = r;
+        }
+    } else {
+        // MoE: one 16-row block of sorted pair ids, all of one expert.
+        const int total = *p.total_post_pad;
+        if (rb * 16 >= total) return;
+        const int e = p.block_ids[rb];
+        qw += (long)e * p.expert_stride_qw;
+        sc += (long)e * p.expert_stride_sc;
+        if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
+        int id = p.sorted_token_ids[rb * 16 + b];
+        row_ok[0] = id < p.M;
+        row_out[0] = id;
+        row_in[0] = row_ok[0] ? id / p.top_k : 0;
+    }
+
+    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+    // per-lane bases
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(qw) + ((long)st * p.G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(zp) + ((long)st * p.G) * 16 + b : nullptr;
+    const __half* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) xrow[mt] = p.x + (long)row_in[mt] * p.K + 8 * a;
+
+    float4v acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    // register double buffer: group g+1 is in flight while group g is consumed
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 wq[2][4];
+    uint2 scv[2], zpv[2];
+    half8 af[2][MT][4];
+    auto issue = [&](int buf, int g) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[buf][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[buf] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[buf] = zp_lane[(long)g * 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                af[buf][mt][s] = *reinterpret_cast<const half8*>(xrow[mt] + g * 128 + 32 * s);
+    };
+    auto consume = [&](int buf) {
+        union { uint2 u; _Float16 h[4]; } su, zu;
+        su.u = scv[buf];
+        if (HAS_ZP) zu.u = zpv[buf];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            _Float16 zero = HAS_ZP ? zu.h[nt] : (_Float16)8.0f;
+            _Float16 clo = (_Float16)(-1024.0f) - zero, chi = (_Float16)(-64.0f) - zero;
+            half2v c_lo = {clo, clo}, c_hi = {chi, chi};
+            uint32_t words[4] = {wq[buf][nt][0], wq[buf][nt][1], wq[buf][nt][2], wq[buf][nt][3]};
+            float4v tmp[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) tmp[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                half8 bf = dequant8(words[s], c_lo, c_hi);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[buf][mt][s], bf, tmp[mt], 0, 0, 0);
+            }
+            float s_f = (float)su.h[nt];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[mt][nt][r] += s_f * tmp[mt][r];
+        }
+    };
+
+    if (g0 < g1) {
+        issue(0, g0);
+        int g = g0;
+        for (; g + 2 <= g1 - 1; g += 2) {   // two groups per trip keeps buffer indices static
+            issue(1, g + 1);
+            consume(0);
+            issue(0, g + 2);
+            consume(1);
+        }
+        if (g + 1 < g1) {
+            issue(1, g + 1);
+            consume(0);
+            consume(1);
+        } else {
+            consume(0);
+        }
+    }
+
+    // accumulator map (v_mfma_f32_16x16x32): column = lane&15 → n, row = 4·(lane>>4)+r → token.
+    // Lanes exchange nothing: every lane owns token rows 4a..4a+3 of column b.  The A operand
+    // was loaded with lane b ↔ token b, so token t = 4a'+r lives in lanes with (lane>>4)==a'.
+    // (D row index is the A row index, i.e. the token slot 0..15 of this block.)
+    int out_rows[MT][4];
+    bool out_ok[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // the token slot 4a+r's routing lives in lane (·, b=4a+r): fetch it by shuffle
+            int src_lane = 4 * a + r;
+            out_rows[mt][r] = __shfl(row_out[mt], src_lane, 64);
+            out_ok[mt][r] = __shfl((int)row_ok[mt], src_lane, 64) != 0;
+        }
+
+    if (MODE == 2) {
+        // supertile = [16 gate | 16 gate | 16 up | 16 up] (column-permuted at repack):
+        // act[row][st·32 + j·16 + b] = silu(gate)·up   (cpu.rs:1666-1680)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (!out_ok[0][r]) continue;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float gt = acc[0][j][r], up = acc[0][2 + j][r];
+                float v = (gt / (1.0f + __expf(-gt))) * up;
+                int col = st * 32 + j * 16 + b;
+                if (col < p.ldo) p.out[(long)out_rows[0][r] * p.ldo + col] = __float2half(v);
+            }
+        }
+        return;
+    }
+    if (p.S > 1) {
+        float* slab = p.partial + (long)z * p.rows_pad * p.n_pad;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = MODE == 0 ? rb * 16 * MT + mt * 16 + 4 * a + r : rb * 16 + 4 * a + r;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++)
+                    slab[(long)row * p.n_pad + st * 64 + nt * 16 + b] = acc[mt][nt][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (!out_ok[mt][r]) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                int col = st * 64 + nt * 16 + b;
+                if (col < p.N) p.out[(long)out_rows[mt][r] * p.ldo + col] = __float2half(acc[mt][nt][r]);
+            }
+        }
+}
+
+// Sum S fp32 slabs in fixed order → fp16 [M, N] (optionally gathering padded MoE rows).
+template <typename OutT>
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, OutT* __restrict__ out, int S,
+                                     int M, int N, int rows_pad, int n_pad, int ldo) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    int row = blockIdx.y;
+    if (col >= N || row >= M) return;
+    float s = 0.f;
+    for (int z = 0; z < S; z++) s += partial[((long)z * rows_pad + row) * n_pad + col];
+    out[(long)row * ldo + col] = (OutT)s;
+}
+
+// ─────────────────────────────── host launchers ────────────────────────────
+
+template <int MODE>
+static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_t stream) {
+#define FH_W4_CASE(MTV, ZPV)                                                       \
+    hipLaunchKernelGGL((w4_gemm_kernel<MTV, ZPV, MODE>), grid, dim3(256), 0, stream, a)
+    if constexpr (MODE != 0) {
+        if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false);
+    } else {
+        if (mt == 1) { if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false); }
+        else if (mt == 2) { if (has_zp) FH_W4_CASE(2, true); else FH_W4_CASE(2, false); }
+        else { if (has_zp) FH_W4_CASE(4, true); else FH_W4_CASE(4, false); }
+    }
+#undef FH_W4_CASE
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// Dense y[M,N] = x[M,K]·Wᵀ.  `workspace` holds split-K slabs (w4_workspace_bytes()).
+int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
+                  size_t workspace_bytes, hipStream_t stream) {
+    if (m <= 0) return 0;
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.x = x; a.out = out; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n;
+    int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    int row_blocks = cdiv(m, 16 * mt);
+    int wg_x = cdiv(w.n64, 4);
+    // split K until there are enough wave-tasks to cover the chip (≈8 waves/CU), keeping ≥2
+    // groups per slice; only when the slabs fit the workspace.
+    long tasks = (long)w.n64 * row_blocks;
+    int S = 1;
+    while (tasks * S < 2048 && S * 2 <= w.G / 2) S *= 2;
+    a.rows_pad = row_blocks * 16 * mt;
+    a.n_pad = w.n64 * 64;
+    if (S > 1 && (size_t)S * a.rows_pad * a.n_pad * sizeof(float) > workspace_bytes) S = 1;
+    a.S = S;
+    a.partial = workspace;
+    int rc = launch_w4<0>(a, mt, w.zp != nullptr, dim3(wg_x, row_blocks, S), stream);
+    if (rc) return rc;
+    if (S > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel<__half>, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, S,
+                           m, w.n, a.rows_pad, a.n_pad, w.n);
+        FH_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+// MoE grouped GEMM over align-block routing arrays (block size 16).
+// out row = pair id, in row = pair id / top_k (vLLM marlin_moe convention, ops.cu:942).
+int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
+                const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs, int max_blocks,
+                int top_k, int fused_silu, hipStream_t stream) {
+    if (num_valid_pairs <= 0 || max_blocks <= 0) return 0;
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
+    a.expert_stride_sc = (long)w.n64 * w.G * 16 * 4;
+    a.x = x; a.out = out; a.M = num_valid_pairs; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64;
+    a.ldo = fused_silu ? w.n / 2 : w.n;
+    a.S = 1;
+    a.sorted_token_ids = sorted_token_ids; a.block_ids = block_ids; a.total_post_pad = total_post_pad;
+    a.top_k = top_k;
+    dim3 grid(cdiv(w.n64, 4), max_blocks, 1);
+    if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
+    return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
+}
+
+// ───────────────────────── fp16 skinny GEMM (router, lm_head) ───────────────
+// out[M,N] = x[M,K]·Wᵀ with W [N,K] fp16 row-major (B::gemm, traits.rs:190; cuBLAS hgemm on the
+// reference's CUDA lane).  Same operand roles as the INT4 kernel: W rows are B-operand columns.
+template <int MT, typename OutT>
+__global__ __launch_bounds__(256) void f16_gemm_kernel(const __half* __restrict__ x, const __half* __restrict__ w,
+                                                       OutT* __restrict__ out, float* __restrict__ partial,
+                                                       int M, int N, int K, int S, int rows_pad, int n_pad) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int ntile2 = blockIdx.x * 4 + wave;       // pair of 16-column tiles
+    const int n0 = ntile2 * 32;
+    if (n0 >= N) return;
+    const int rb = blockIdx.y, z = blockIdx.z;
+    const int ksteps = K / 32;
+    const int s0 = (int)((long)ksteps * z / S), s1 = (int)((long)ksteps * (z + 1) / S);
+    const __half* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int r = rb * 16 * MT + mt * 16 + b;
+        xrow[mt] = x + (long)(r < M ? r : M - 1) * K + 8 * a;
+    }
+    const __half* wrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int n = n0 + j * 16 + b;
+        wrow[j] = w + (long)(n < N ? n : N - 1) * K + 8 * a;
+    }
+    float4v acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[mt][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int U = 4;   // k-steps in flight per trip
+    int s = s0;
+    for (; s + U <= s1; s += U) {
+        half8 bw[U][2], ax[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                bw[u][j] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(wrow[j] + (s + u) * 32));
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) ax[u][mt] = *reinterpret_cast<const half8*>(xrow[mt] + (s + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[u][mt], bw[u][j], acc[mt][j], 0, 0, 0);
+    }
+    for (; s < s1; s++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            half8 bwv = *reinterpret_cast<const half8*>(wrow[j] + s * 32);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                half8 axv = *reinterpret_cast<const half8*>(xrow[mt] + s * 32);
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axv, bwv, acc[mt][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                int col = n0 + j * 16 + b;
+                if (S > 1) {
+                    partial[((long)z * rows_pad + row) * n_pad + col] = acc[mt][j][r];
+                } else if (row < M && col < N) {
+                    out[(long)row * N + col] = (OutT)acc[mt][j][r];
+                }
+            }
+        }
+}
+
+template <typename OutT>
+static int f16_gemm_impl(const __half* x, const __half* w, OutT* out, int m, int n, int k, float* workspace,
+                         size_t workspace_bytes, hipStream_t stream) {
+    if (m <= 0) return 0;
+    FH_REQUIRE(k % 32 == 0, "f16_gemm: K=%d must be a multiple of 32", k);
+    int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    int row_blocks = cdiv(m, 16 * mt);
+    int ntile2 = cdiv(n, 32);
+    int ksteps = k / 32;
+    long tasks = (long)ntile2 * row_blocks;
+    int S = 1;
+    while (tasks * S < 2048 && S * 2 <= ksteps / 8) S *= 2;
+    int rows_pad = row_blocks * 16 * mt, n_pad = ntile2 * 32;
+    if (S > 1 && (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes) S = 1;
+    dim3 grid(cdiv(ntile2, 4), row_blocks, S);
+    if (mt == 1) hipLaunchKernelGGL((f16_gemm_kernel<1, OutT>), grid, dim3(256), 0, stream, x, w, out, workspace, m, n, k, S, rows_pad, n_pad);
+    else if (mt == 2) hipLaunchKernelGGL((f16_gemm_kernel<2, OutT>), grid, dim3(256), 0, stream, x, w, out, workspace, m, n, k, S, rows_pad, n_pad);
+    else hipLaunchKernelGGL((f16_gemm_kernel<4, OutT>), grid, dim3(256), 0, stream, x, w, out, workspace, m, n, k, S, rows_pad, n_pad);
+    FH_CHECK_LAUNCH();
+    if (S > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel<OutT>, dim3(cdiv(n, 256), m), dim3(256), 0, stream, workspace, out, S, m, n,
+                           rows_pad, n_pad, n);
+        FH_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+int f16_gemm(const __half* x, const __half* w, __half* out, int m, int n, int k, float* workspace,
+             size_t workspace_bytes, hipStream_t stream) {
+    return f16_gemm_impl<__half>(x, w, out, m, n, k, workspace, workspace_bytes, stream);
+}
+int f16_gemm_f32out(const __half* x, const __half* w, float* out, int m, int n, int k, float* workspace,
+                    size_t workspace_bytes, hipStream_t stream) {
+    return f16_gemm_impl<float>(x, w, out, m, n, k, workspace, workspace_bytes, stream);
+}
+
+}  // namespace fh

@@ -1,0 +1,169 @@
+"""Host mirror of the reference's `ModelExecutor` unified-decode contract over the C++ runner.
+
+`HipModel` wraps `ferrum_hip_model_*` (include/ferrum_hip.h): weight hand-over as host slices
+(`WeightLoader` → `B::load_gptq`, ferrum-quantization/src/loader.rs:21), `reserve_kv_slots` /
+`unified_decode` / `release` (ferrum-interfaces/src/model_executor.rs:456-651) and the
+steady-state decode loop.  All compute happens in libferrum_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .backend import _check, load_library
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_layers", "hidden", "num_heads", "num_kv_heads", "head_dim", "intermediate", "vocab", "max_seq_len",
+        "has_qk_norm", "activation", "num_experts", "top_k", "expert_inter", "norm_topk_prob", "rope_scaling_kind",
+        "sliding_window", "group_size", "kv_num_blocks", "max_seqs", "max_tokens")] + [
+        ("rms_eps", C.c_float), ("_pad", C.c_float), ("rope_theta", C.c_double), ("rope_p0", C.c_double),
+        ("rope_p1", C.c_double), ("rope_p2", C.c_double), ("rope_p3", C.c_double), ("tp_rank", C.c_int32),
+        ("tp_world", C.c_int32)]
+
+
+class BatchItem(C.Structure):
+    """UnifiedBatchItem (model_executor.rs:354-386)."""
+    _fields_ = [("seq_id", C.c_uint64), ("q_tokens", C.POINTER(C.c_uint32)), ("num_q_tokens", C.c_int32),
+                ("pos_offset", C.c_int32), ("is_final_chunk", C.c_int32), ("_pad", C.c_int32)]
+
+
+class KvSlotRequest(C.Structure):
+    _fields_ = [("seq_id", C.c_uint64), ("target_len", C.c_int32), ("_pad", C.c_int32)]
+
+
+class KvSlotReservation(C.Structure):
+    _fields_ = [("block_size", C.c_int32), ("total_blocks", C.c_int32), ("free_blocks_before", C.c_int32),
+                ("free_blocks_after", C.c_int32)]
+
+
+_DEFAULTS = dict(max_seq_len=512, has_qk_norm=0, activation=0, num_experts=0, top_k=0, expert_inter=0,
+                 norm_topk_prob=1, rope_scaling_kind=0, sliding_window=0, group_size=128, kv_num_blocks=256,
+                 max_seqs=32, max_tokens=512, rms_eps=1e-6, rope_theta=1e6, intermediate=0, tp_rank=0, tp_world=1)
+
+GLOBAL = {"embed": 0, "lm_head": 1, "final_norm": 2}
+LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4}
+GPTQ = {"qkv": 0, "o": 1, "gate_up": 2, "down": 3, "expert_gate_up": 4, "expert_down": 5}
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class HipModel:
+    def __init__(self, **kw):
+        self.lib = load_library()
+        self.cfg = ModelConfig()
+        d = dict(_DEFAULTS)
+        d.update(kw)
+        for k, v in d.items():
+            setattr(self.cfg, k, v)
+        self.h = C.c_void_p()
+        _check(self.lib.ferrum_hip_model_create(C.byref(self.h), C.byref(self.cfg)), "model_create")
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ferrum_hip_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ── weights ──────────────────────────────────────────────────────────────
+    def set_global(self, name, data):
+        d = _f32(data)
+        _check(self.lib.ferrum_hip_model_set_global_f32(self.h, GLOBAL[name], d.ctypes.data_as(C.POINTER(C.c_float))),
+               f"set_global({name})")
+
+    def set_layer_dense(self, layer, name, data):
+        d = _f32(data)
+        _check(self.lib.ferrum_hip_model_set_layer_dense_f32(self.h, layer, LAYER_DENSE[name],
+                                                             d.ctypes.data_as(C.POINTER(C.c_float))), f"set_layer_dense({name})")
+
+    def set_gptq(self, layer, name, qweight, scales, qzeros, k, n, expert=0, g_idx=None):
+        qw, sc, qz = _i32(qweight), _f32(scales), _i32(qzeros)
+        gi = None if g_idx is None else _i32(g_idx)
+        p = C.POINTER(C.c_int32)
+        _check(self.lib.ferrum_hip_model_set_gptq(self.h, layer, GPTQ[name], expert, qw.ctypes.data_as(p),
+                                                  sc.ctypes.data_as(C.POINTER(C.c_float)), qz.ctypes.data_as(p),
+                                                  None if gi is None else gi.ctypes.data_as(p), k, n), f"set_gptq({name})")
+
+    def init_synthetic(self, seed):
+        _check(self.lib.ferrum_hip_model_init_synthetic(self.h, C.c_uint64(seed)), "init_synthetic")
+
+    def finalize(self):
+        _check(self.lib.ferrum_hip_model_finalize(self.h), "finalize")
+
+    # ── KV admission ─────────────────────────────────────────────────────────
+    def reserve_kv_slots(self, requests):
+        """requests: [(seq_id, target_len)] → KvSlotReservation dict; raises when the pool is exhausted."""
+        arr = (KvSlotRequest * max(len(requests), 1))(*[KvSlotRequest(s, t, 0) for s, t in requests])
+        out = KvSlotReservation()
+        _check(self.lib.ferrum_hip_model_reserve_kv_slots(self.h, arr, len(requests), C.byref(out)), "reserve_kv_slots")
+        return {f: getattr(out, f) for f, _ in KvSlotReservation._fields_}
+
+    def kv_slot_capacity_snapshot(self):
+        out = KvSlotReservation()
+        _check(self.lib.ferrum_hip_model_kv_capacity_snapshot(self.h, C.byref(out)), "kv_capacity_snapshot")
+        return {"block_size": out.block_size, "total_blocks": out.total_blocks, "free_blocks": out.free_blocks_after}
+
+    def release(self, seq_id):
+        _check(self.lib.ferrum_hip_model_release(self.h, C.c_uint64(seq_id)), "release")
+
+    def block_table(self, seq_id):
+        cap = (self.cfg.max_seq_len + 15) // 16
+        arr = (C.c_uint32 * cap)()
+        nb, kl = C.c_int(), C.c_int()
+        _check(self.lib.ferrum_hip_model_block_table(self.h, C.c_uint64(seq_id), arr, cap, C.byref(nb), C.byref(kl)), "block_table")
+        return list(arr[:nb.value]), kl.value
+
+    def read_kv(self, seq_id, layer, is_v):
+        _, kv_len = self.block_table(seq_id)
+        out = np.zeros((kv_len, self.cfg.num_kv_heads, self.cfg.head_dim), np.float32)
+        _check(self.lib.ferrum_hip_model_read_kv_f32(self.h, C.c_uint64(seq_id), layer, int(is_v),
+                                                     out.ctypes.data_as(C.POINTER(C.c_float))), "read_kv")
+        return out
+
+    # ── forward ──────────────────────────────────────────────────────────────
+    def unified_forward(self, items, greedy=True, want_logits=False):
+        """items: [(seq_id, tokens, pos_offset, is_final_chunk)].  Returns (tokens|None, logits|None) for the
+        final-chunk items in order."""
+        keep = [np.ascontiguousarray(t, dtype=np.uint32) for _, t, _, _ in items]
+        arr = (BatchItem * len(items))()
+        n_final = 0
+        for i, (sid, _, pos, fin) in enumerate(items):
+            arr[i] = BatchItem(sid, keep[i].ctypes.data_as(C.POINTER(C.c_uint32)), len(keep[i]), pos, int(fin), 0)
+            n_final += int(bool(fin))
+        toks = np.zeros(max(n_final, 1), np.uint32)
+        logits = np.zeros((max(n_final, 1), self.cfg.vocab), np.float32) if want_logits else None
+        _check(self.lib.ferrum_hip_model_unified_forward(
+            self.h, arr, len(items), int(greedy), toks.ctypes.data_as(C.POINTER(C.c_uint32)),
+            None if logits is None else logits.ctypes.data_as(C.POINTER(C.c_float))), "unified_forward")
+        return (toks[:n_final] if greedy else None), (logits[:n_final] if logits is not None else None)
+
+    def decode_steps(self, seq_ids, first_tokens, steps):
+        n = len(seq_ids)
+        sid = np.ascontiguousarray(seq_ids, dtype=np.uint64)
+        ft = np.ascontiguousarray(first_tokens, dtype=np.uint32)
+        out = np.zeros((steps, n), np.uint32)
+        _check(self.lib.ferrum_hip_model_decode_steps(self.h, sid.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      ft.ctypes.data_as(C.POINTER(C.c_uint32)), n, steps,
+                                                      out.ctypes.data_as(C.POINTER(C.c_uint32))), "decode_steps")
+        return out
+
+    def enable_taps(self, on=True):
+        _check(self.lib.ferrum_hip_model_enable_taps(self.h, int(on)), "enable_taps")
+
+    def read_taps(self, tokens):
+        out = np.zeros((self.cfg.num_layers, tokens, self.cfg.hidden), np.float32)
+        _check(self.lib.ferrum_hip_model_read_taps(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), tokens), "read_taps")
+        return out
+
+    def stream(self):
+        s = C.c_void_p()
+        _check(self.lib.ferrum_hip_model_stream(self.h, C.byref(s)), "model_stream")
+        return s

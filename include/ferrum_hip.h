@@ -1,0 +1,304 @@
+/*
+ * ferrum_hip.h — C ABI of the MI355X (gfx950) decode hot path for ferrum-infer-rs.
+ *
+ * This is the drop-in boundary: the entry points a Rust FFI crate (`ferrum-hip`) binds to implement
+ * the reference's backend traits
+ *     Backend + BackendGraph + BackendPagedKv + BackendQuantMarlin + BackendMoeFused (+ BackendCollective)
+ *     = MoeLlmBackend          (crates/ferrum-kernels/src/backend/traits.rs:2196-2208)
+ * in place of the CUDA lane of `ferrum-kernels`.  INTEGRATION.md shows the binding.
+ *
+ * Conventions (same as the reference's own C entry points: FA2 shim
+ * crates/ferrum-kernels/src/backend/cuda/fa2_ffi.rs:16-37, Marlin cuda/marlin.rs:293-387):
+ *   - every function returns 0 on success, non-zero on failure; the message is available from
+ *     ferrum_hip_last_error() (thread-local) — capability ops that the reference returns
+ *     `FerrumError::unsupported` for return FERRUM_HIP_UNSUPPORTED (3);
+ *   - buffers are raw DEVICE pointers owned by the caller (never freed here); dims are plain ints;
+ *     `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - activations are fp16, accumulation fp32; index tensors are i32/u32 exactly as in the traits;
+ *   - no call allocates device memory after ferrum_hip_*_create / *_load, so every compute entry
+ *     point may be captured into a hipGraph (capabilities.rs:205-214 contract).
+ * All paths in comments are relative to the reference's `crates/` directory.
+ */
+#ifndef FERRUM_HIP_H
+#define FERRUM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built with -fvisibility=hidden */
+#endif
+
+#define FERRUM_HIP_OK 0
+#define FERRUM_HIP_ERROR 1
+#define FERRUM_HIP_INVALID 2
+#define FERRUM_HIP_UNSUPPORTED 3
+
+/* ── native-operator artifact contract ─────────────────────────────────────────────────────────
+ * ferrum-native-ops/src/abi.rs:3-13: required exports of a native operator artifact and the
+ * #[repr(C)] descriptor; the resolver checks them with `nm -g` (resolver.rs:136-318). */
+typedef struct {
+    uint32_t abi_version;             /* FERRUM_NATIVE_ABI_VERSION = 1 */
+    const char* operator_name;        /* "ferrum_hip_decode" */
+    const char* operator_abi_version; /* "1" */
+} FerrumNativeOperatorDescriptor;
+int ferrum_native_op_init(void);
+const FerrumNativeOperatorDescriptor* ferrum_native_op_descriptor(void);
+
+/* ── context / memory: Backend::{new_context, sync, alloc, from_slice, to_vec, zero_buffer,
+ *    copy_slice} (ferrum-kernels/src/backend/traits.rs:69,90,159,170-182,798,1388-1390) ──────── */
+const char* ferrum_hip_last_error(void);
+int ferrum_hip_device_count(int* count);
+int ferrum_hip_set_device(int ordinal);
+int ferrum_hip_stream_create(void** stream);
+int ferrum_hip_stream_destroy(void* stream);
+int ferrum_hip_stream_synchronize(void* stream);
+int ferrum_hip_alloc(void** dev_ptr, size_t bytes);           /* zero-filled, like B::alloc */
+int ferrum_hip_free(void* dev_ptr);
+int ferrum_hip_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int ferrum_hip_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int ferrum_hip_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int ferrum_hip_memset_zero(void* dev_ptr, size_t bytes, void* stream);
+
+/* Scratch the split-K GEMMs and the split-KV attention use.  One per stream; sized once. */
+typedef struct FerrumHipWorkspace FerrumHipWorkspace;
+int ferrum_hip_workspace_create(FerrumHipWorkspace** ws, size_t bytes);
+int ferrum_hip_workspace_destroy(FerrumHipWorkspace* ws);
+
+/* ── norms, embedding, elementwise ─────────────────────────────────────────────────────────────
+ * Backend::rms_norm (traits.rs:202), fused_add_rms_norm (:212), embedding_lookup (:809),
+ * fused_silu_mul_split (:863), fused_gelu_tanh_mul_split (:875), scale_inplace (:889),
+ * add_inplace (:1308), add_bias (:1359).  CPU forms: backend/cpu.rs:495-538,1632-1704,2042. */
+int ferrum_hip_rms_norm_f16(const void* x, const void* w, float eps, void* out, int tokens, int dim, void* stream);
+int ferrum_hip_fused_add_rms_norm_f16(void* residual, const void* x, const void* w, float eps, void* out,
+                                      int tokens, int dim, void* stream);
+int ferrum_hip_embedding_lookup_f16(const void* table, const uint32_t* ids_dev, void* out, int n_ids, int dim,
+                                    void* stream);
+int ferrum_hip_fused_silu_mul_split_f16(const void* gate_up, void* out, int tokens, int intermediate, void* stream);
+int ferrum_hip_fused_gelu_tanh_mul_split_f16(const void* gate_up, void* out, int tokens, int intermediate,
+                                             void* stream);
+int ferrum_hip_scale_inplace_f16(void* buf, float scale, size_t len, void* stream);
+int ferrum_hip_add_inplace_f16(void* residual, const void* x, size_t len, void* stream);
+int ferrum_hip_add_bias_f16(void* data, const void* bias, int rows, int cols, void* stream);
+
+/* ── dense fp16 GEMM: Backend::gemm (traits.rs:190; cpu.rs:438-493): out[m,n] = a[m,k]·b[n,k]ᵀ.
+ *    Used for the MoE router and the unquantised lm_head.  `_f32out` keeps fp32 logits. ─────────── */
+int ferrum_hip_gemm_f16(const void* a, const void* b, void* out, int m, int n, int k, FerrumHipWorkspace* ws,
+                        void* stream);
+int ferrum_hip_gemm_f16_f32out(const void* a, const void* b, float* out, int m, int n, int k,
+                               FerrumHipWorkspace* ws, void* stream);
+
+/* ── GPTQ-INT4 linear: BackendQuantMarlin::load_gptq / load_gptq_stacked (capabilities.rs:136-193;
+ *    CPU cpu.rs:2283-2379) and Linear<B>::forward (linear.rs:109-129), MarlinExpertStack::
+ *    gemm_phase_vllm (marlin_expert_stack.rs:86).  Weights are handed over ONCE as HOST slices
+ *    (qweight [K/8,N] i32, scales [K/g,N] f32, qzeros [K/g,N/8] i32, optional g_idx [K], optional
+ *    bias [N] f32); the handle owns the repacked device copy thereafter.  bits must be 4,
+ *    K % 128 == 0, group_size % 128 == 0 (else FERRUM_HIP_UNSUPPORTED, like Marlin's K,N % 128). */
+typedef struct FerrumHipGptq FerrumHipGptq;
+int ferrum_hip_gptq_load(FerrumHipGptq** handle, const int32_t* qweight, const float* scales,
+                         const int32_t* qzeros, const int32_t* g_idx, const float* bias, int bits,
+                         int group_size, int k, int n);
+/* Stacked experts, contiguous per expert.  fuse_gate_up != 0 declares the N axis as [gate(I)|up(I)]
+ * and enables the fused silu·mul epilogue of ferrum_hip_moe_gemm_phase (output width N/2). */
+int ferrum_hip_gptq_load_stacked(FerrumHipGptq** handle, const int32_t* const* qweights,
+                                 const float* const* scales, const int32_t* const* qzeros,
+                                 const int32_t* g_idx, int bits, int group_size, int k, int n_per_expert,
+                                 int num_experts, int fuse_gate_up);
+int ferrum_hip_gptq_free(FerrumHipGptq* handle);
+int ferrum_hip_gptq_info(const FerrumHipGptq* handle, int* k, int* n, int* num_experts, int* symmetric);
+/* out[m,N] = in[m,K]·Wᵀ (+bias) */
+int ferrum_hip_gptq_linear_forward_f16(const FerrumHipGptq* handle, const void* in, void* out, int m,
+                                       FerrumHipWorkspace* ws, void* stream);
+/* One launch over the align-block routing arrays (block 16): for every valid sorted id p,
+ * out[p] = in[p / top_k]·W[block expert]ᵀ; with fused_silu_mul the stack must have been loaded with
+ * fuse_gate_up and out[p] = silu(gate)·up ([T·k, N/2]).  prob_m = number of valid pair ids. */
+int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input, const int32_t* sorted_token_ids,
+                                  const int32_t* expert_ids, const int32_t* num_tokens_past_padded, void* output,
+                                  int prob_m, int moe_block_size, int top_k, int max_blocks, int fused_silu_mul,
+                                  void* stream);
+
+/* ── paged KV: BackendPagedKv (traits.rs:1622-1904).  Block tables and block ids are the
+ *    reference's (ferrum-models/src/common/paged_pool.rs); the bytes inside a block use the native
+ *    MFMA-shaped tile layout (csrc/kv_layout.h).  Pools: [num_blocks][kv_heads][16·head_dim] fp16,
+ *    must be zero-initialised (ferrum_hip_alloc does).  block_size must be 16. ──────────────────── */
+size_t ferrum_hip_paged_pool_bytes(int num_blocks, int kv_heads, int head_dim);
+/* split_qkv_norm_rope_into_paged_cache_varlen (traits.rs:1764): qk_mode 0 copy, 1 QK-norm + half-split
+ * RoPE, 2 half-split RoPE, 3 interleaved RoPE.  cos/sin are f32 [max_seq, head_dim/2]
+ * (llama_family.rs:5220-5237 values). */
+int ferrum_hip_split_qkv_norm_rope_into_paged_cache_varlen_f16(
+    const void* qkv, const void* q_norm_w, const void* k_norm_w, const float* cos_tab, const float* sin_tab,
+    void* q_out, void* cache_k, void* cache_v, const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+    const int32_t* block_tables, int num_seqs, int m_total, int q_heads, int kv_heads, int head_dim, float eps,
+    int qk_mode, int block_size, int max_blocks_per_seq, void* stream);
+/* paged_varlen_attention (traits.rs:1813): causal GQA over the pool, mixed q_len, optional sliding
+ * window.  max_q_len is an extra hint (0 = derive from total_q_tokens). */
+int ferrum_hip_paged_varlen_attention_f16(const void* q, const void* k_pool, const void* v_pool, void* out,
+                                          const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets,
+                                          const int32_t* block_tables, int num_seqs, int total_q_tokens,
+                                          int max_kv_len, int num_heads, int num_kv_heads, int head_dim,
+                                          int sliding_window, int block_size, int max_num_blocks_per_seq,
+                                          int max_q_len, FerrumHipWorkspace* ws, void* stream);
+/* paged_batched_decode_attention (traits.rs:1885): one token per sequence; valid_kv_lens[s] is the
+ * sequence's kv length INCLUDING the token being decoded. */
+int ferrum_hip_paged_batched_decode_attention_f16(const void* q, const void* k_pool, const void* v_pool, void* out,
+                                                  const int32_t* block_tables, const uint32_t* valid_kv_lens,
+                                                  int num_seqs, int max_kv_len, int num_heads, int num_kv_heads,
+                                                  int head_dim, int block_size, int max_num_blocks_per_seq,
+                                                  FerrumHipWorkspace* ws, void* stream);
+/* Gather one sequence's K/V to token-major [kv_len, kv_heads, head_dim] (ferrum-kv read_kv order,
+ * ferrum-kv/src/managers/paged.rs:528-561).  Off the hot path (tests, prefix export). */
+int ferrum_hip_paged_kv_read_f16(const void* cache_k, const void* cache_v, const int32_t* block_table, int kv_len,
+                                 int kv_heads, int head_dim, int block_size, void* k_out, void* v_out,
+                                 void* stream);
+
+/* ── MoE routing: BackendMoeFused (capabilities.rs:305-724) ─────────────────────────────────────
+ * route_topk_softmax (:334; CPU ferrum-models/src/moe/router.rs:113-195), moe_align_block_size_pair_ids
+ * (:449), moe_combine / weighted_sum_batched (:684,:560). */
+int ferrum_hip_moe_route_topk_softmax_f16(const void* logits, int32_t* expert_ids, float* expert_weights,
+                                          int tokens, int num_experts, int top_k, int norm_topk_prob, void* stream);
+int ferrum_hip_moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* expert_weights,
+                                          int tokens, int num_experts, int top_k, int norm_topk_prob, void* stream);
+/* sorted_max = batch_x_topk + num_experts·block_size (ferrum-models/src/moe/dispatch.rs:1865);
+ * block_ids holds sorted_max/block_size entries. */
+int ferrum_hip_moe_align_block_size(const int32_t* expert_ids_per_pair, int32_t* sorted_token_ids,
+                                    int32_t* block_ids, int32_t* total_tokens_post_pad, int batch_x_topk,
+                                    int num_experts, int block_size, int sorted_max, void* stream);
+/* out[b] = Σ_k weights[b,k]·down[b·top_k+k]; accumulate != 0 adds into out (fused residual add). */
+int ferrum_hip_moe_combine_f16(const void* down, const float* weights, void* out, int tokens, int top_k,
+                               int hidden, int accumulate, void* stream);
+
+/* ── device sampling: Backend::argmax_rows_f16[_masked|_sparse_repetition_penalty]
+ *    (traits.rs:1534-1591).  First maximum wins.  valid_token_mask may be NULL. ───────────────── */
+int ferrum_hip_argmax_rows_f16(const void* logits, uint32_t* out_ids_dev, const uint8_t* valid_token_mask,
+                               int mask_len, int m, int n, void* stream);
+int ferrum_hip_argmax_rows_f32(const float* logits, uint32_t* out_ids_dev, const uint8_t* valid_token_mask,
+                               int mask_len, int m, int n, void* stream);
+int ferrum_hip_apply_repetition_penalties_sparse_f16(void* logits, const uint32_t* row_offsets,
+                                                     const uint32_t* token_ids, const float* penalties, int m,
+                                                     int n, void* stream);
+int ferrum_hip_apply_repetition_penalties_sparse_f32(float* logits, const uint32_t* row_offsets,
+                                                     const uint32_t* token_ids, const float* penalties, int m,
+                                                     int n, void* stream);
+
+/* ── host-side KV block bookkeeping: BlockAllocator (ferrum-models/src/common/paged_pool.rs:106-365).
+ *    Pure host code; reproduces block ids bit-exactly (ids from 0, LIFO, prefer-unhashed). ─────── */
+typedef struct FerrumHipBlockAllocator FerrumHipBlockAllocator;
+int ferrum_hip_block_allocator_create(FerrumHipBlockAllocator** a, uint32_t num_blocks);
+int ferrum_hip_block_allocator_destroy(FerrumHipBlockAllocator* a);
+int ferrum_hip_block_allocator_allocate(FerrumHipBlockAllocator* a, uint32_t* block);       /* INVALID when exhausted */
+int ferrum_hip_block_allocator_allocate_n(FerrumHipBlockAllocator* a, uint32_t n, uint32_t* blocks); /* atomic */
+int ferrum_hip_block_allocator_free(FerrumHipBlockAllocator* a, const uint32_t* blocks, uint32_t n);
+int ferrum_hip_block_allocator_acquire(FerrumHipBlockAllocator* a, uint32_t block);
+int ferrum_hip_block_allocator_register_hash(FerrumHipBlockAllocator* a, uint32_t block, uint64_t hash);
+int ferrum_hip_block_allocator_try_acquire_by_hash(FerrumHipBlockAllocator* a, uint64_t hash, int64_t* block); /* -1 miss */
+uint32_t ferrum_hip_block_allocator_free_count(const FerrumHipBlockAllocator* a);
+uint32_t ferrum_hip_block_allocator_ref_count(const FerrumHipBlockAllocator* a, uint32_t block);
+uint32_t ferrum_hip_block_allocator_peak_in_use(const FerrumHipBlockAllocator* a);
+uint32_t ferrum_hip_block_allocator_hash_table_size(const FerrumHipBlockAllocator* a);
+
+/* ── decoder runner: the C++ mirror of DecoderOnlyLLM / LlamaFamilyModel / Qwen3MoeModel
+ *    unified forward (ferrum-models/src/common/llm.rs:45-293,
+ *    models/llama_family_forward_batched.rs:1676-2420, models/qwen3_moe_forward_unified.rs:174-445)
+ *    behind ModelExecutor::{reserve_kv_slots, unified_decode, release}
+ *    (ferrum-interfaces/src/model_executor.rs:456-651). ────────────────────────────────────────── */
+typedef struct FerrumHipModel FerrumHipModel;
+
+typedef struct {
+    int32_t num_layers, hidden, num_heads, num_kv_heads, head_dim, intermediate, vocab;
+    int32_t max_seq_len;          /* RoPE table length / per-sequence KV capacity */
+    int32_t has_qk_norm;          /* qk_mode 1 else 2 (llama_family.rs llama_qk_mode) */
+    int32_t activation;           /* 0 silu, 1 gelu_tanh */
+    int32_t num_experts;          /* 0 = dense MLP */
+    int32_t top_k, expert_inter, norm_topk_prob;
+    int32_t rope_scaling_kind;    /* 0 none, 1 linear, 2 llama3 */
+    int32_t sliding_window;       /* 0 = full attention */
+    int32_t group_size;           /* GPTQ group size (128) */
+    int32_t kv_num_blocks;        /* physical KV blocks in the pool (block size 16) */
+    int32_t max_seqs;             /* max sequences per unified batch */
+    int32_t max_tokens;           /* max query tokens per unified batch */
+    float rms_eps;
+    float _pad;
+    double rope_theta;
+    double rope_p0, rope_p1, rope_p2, rope_p3;
+    int32_t tp_rank, tp_world;    /* tensor-parallel shard of this process (world 1 = none) */
+} FerrumHipModelConfig;
+
+/* One item of a UnifiedBatch (model_executor.rs:354-386). */
+typedef struct {
+    uint64_t seq_id;              /* cache id */
+    const uint32_t* q_tokens;     /* host pointer */
+    int32_t num_q_tokens;
+    int32_t pos_offset;           /* kv position of the first q token */
+    int32_t is_final_chunk;       /* produce logits / a token for the last q token */
+    int32_t _pad;
+} FerrumHipBatchItem;
+
+/* KvSlotRequest / KvSlotReservation (model_executor.rs:24-64). */
+typedef struct {
+    uint64_t seq_id;
+    int32_t target_len;
+    int32_t _pad;
+} FerrumHipKvSlotRequest;
+typedef struct {
+    int32_t block_size, total_blocks, free_blocks_before, free_blocks_after;
+} FerrumHipKvSlotReservation;
+
+int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* cfg);
+int ferrum_hip_model_destroy(FerrumHipModel* model);
+/* Weight hand-over (host slices, copied/repacked to device).  which:
+ *   global dense: 0 embed [V,H], 1 lm_head [V,H] (omit → tied to embed), 2 final_norm [H]
+ *   layer dense : 0 input_ln [H], 1 post_ln [H], 2 q_norm [hd], 3 k_norm [hd], 4 router [E,H]
+ *   gptq        : 0 qkv, 1 o, 2 gate_up, 3 down, 4 expert gate_up, 5 expert down               */
+int ferrum_hip_model_set_global_f32(FerrumHipModel* model, int which, const float* data);
+int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* model, int layer, int which, const float* data);
+int ferrum_hip_model_set_gptq(FerrumHipModel* model, int layer, int which, int expert, const int32_t* qweight,
+                              const float* scales, const int32_t* qzeros, const int32_t* g_idx, int k, int n);
+/* Deterministic synthetic weights generated on the device (bench: no checkpoints offline). */
+int ferrum_hip_model_init_synthetic(FerrumHipModel* model, uint64_t seed);
+int ferrum_hip_model_finalize(FerrumHipModel* model);
+
+/* ModelExecutor::reserve_kv_slots (model_executor.rs:484): allocate physical blocks so every
+ * requested sequence can hold target_len tokens; atomic — on exhaustion nothing is taken and
+ * FERRUM_HIP_INVALID is returned. */
+int ferrum_hip_model_reserve_kv_slots(FerrumHipModel* model, const FerrumHipKvSlotRequest* reqs, int n,
+                                      FerrumHipKvSlotReservation* out);
+int ferrum_hip_model_kv_capacity_snapshot(const FerrumHipModel* model, FerrumHipKvSlotReservation* out);
+int ferrum_hip_model_release(FerrumHipModel* model, uint64_t seq_id);
+/* Block table of a sequence (u32 physical ids), for "bit-exact KV-block indexing" checks. */
+int ferrum_hip_model_block_table(const FerrumHipModel* model, uint64_t seq_id, uint32_t* blocks, int capacity,
+                                 int* num_blocks, int* kv_len);
+/* Read a sequence's K or V of one layer back as fp32 [kv_len, kv_heads, head_dim]. */
+int ferrum_hip_model_read_kv_f32(FerrumHipModel* model, uint64_t seq_id, int layer, int is_v, float* out_host);
+
+/* ModelExecutor::unified_decode (model_executor.rs; llm.rs:260): mixed prefill+decode forward.
+ * For every item with is_final_chunk, in item order:
+ *   - greedy != 0 : out_tokens[j] = device argmax (LogitsReturnPolicy::GreedyArgmax, model_executor.rs:109)
+ *   - logits_out != NULL : logits_out[j·vocab ..] = fp32 logits (LogitsReturnPolicy::FullLogits)
+ * Blocks are reserved on demand (as unified_forward_internal does via ensure_paged_kv_capacity);
+ * returns FERRUM_HIP_INVALID if the pool is exhausted. */
+int ferrum_hip_model_unified_forward(FerrumHipModel* model, const FerrumHipBatchItem* items, int num_items,
+                                     int greedy, uint32_t* out_tokens, float* logits_out);
+/* Steady-state decode: every listed sequence advances by one token (its last sampled token),
+ * `steps` times, with device-side greedy sampling and hipGraph replay when available.
+ * out_tokens [steps, n] (may be NULL). */
+int ferrum_hip_model_decode_steps(FerrumHipModel* model, const uint64_t* seq_ids, const uint32_t* first_tokens,
+                                  int n, int steps, uint32_t* out_tokens);
+/* Tap for parity tests: hidden state after each layer of the LAST forward, fp32 [layers, T, H]. */
+int ferrum_hip_model_enable_taps(FerrumHipModel* model, int enable);
+int ferrum_hip_model_read_taps(FerrumHipModel* model, float* out_host, int max_tokens);
+/* Per-kernel-class device time of the last decode_steps call (hipEvent based), microseconds. */
+int ferrum_hip_model_stream(FerrumHipModel* model, void** stream);
+/* Tensor parallel: 128-byte RCCL unique id created on rank 0 and broadcast by the host. */
+int ferrum_hip_tp_unique_id(uint8_t id[128]);
+int ferrum_hip_model_tp_init(FerrumHipModel* model, const uint8_t id[128]);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* FERRUM_HIP_H */

@@ -1,0 +1,514 @@
+"""GPU parity tests: every hot-path op through the C ABI (libferrum_hip.so) vs the CPU oracle on the
+same seeded inputs.  Tolerances are the reference's own op_diff buckets
+(ferrum-testkit/src/op_diff/mod.rs:46-49: NMSE fp16 1e-6, attention 5e-3, fp16 round-trip 3e-3)
+unless a tighter one is written in the test; integer outputs are bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NMSE_FP16_TOL = 1e-6
+NMSE_ATTN_TOL = 5e-3
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import __graft_entry__ as ge
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    pkg = ge.load_package()
+    pkg.load_library()          # raises if the HIP extension is missing — no fallback
+    from oracle import oracle as O
+    O.build()
+    ctx = pkg.HipBackend.new_context()
+    return pkg, pkg.HipBackend, ctx, O, torch
+
+
+def f16r(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def nmse(ref, got):
+    ref, got = np.asarray(ref, np.float64).ravel(), np.asarray(got, np.float64).ravel()
+    return float(((ref - got) ** 2).mean() / max((ref ** 2).mean(), 1e-30))
+
+
+def dev16(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to("cuda").half().contiguous()
+
+
+def host(t):
+    return t.float().cpu().numpy()
+
+
+# ── norms / elementwise ──────────────────────────────────────────────────────
+@pytest.mark.parametrize("tokens,dim", [(1, 1024), (5, 2048), (32, 4096), (3, 5376), (2, 8192), (7, 128)])
+def test_rms_norm_and_fused_add(env, tokens, dim):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(dim + tokens)
+    x = f16r(rng.standard_normal((tokens, dim)) * 2)
+    r = f16r(rng.standard_normal((tokens, dim)) * 3)
+    w = f16r(1 + 0.2 * rng.standard_normal(dim))
+    out = torch.empty(tokens, dim, dtype=torch.float16, device="cuda")
+    B.rms_norm(ctx, dev16(torch, x), dev16(torch, w), 1e-6, out, tokens, dim)
+    assert nmse(O.rms_norm(x, w, 1e-6), host(out)) < NMSE_FP16_TOL
+    rd = dev16(torch, r)
+    B.fused_add_rms_norm(ctx, rd, dev16(torch, x), dev16(torch, w), 1e-6, out, tokens, dim)
+    r_ref, o_ref = O.fused_add_rms_norm(r, x, w, 1e-6)
+    assert nmse(r_ref, host(rd)) < NMSE_FP16_TOL          # residual stored as fp16
+    # the fp16 lane norms the ROUNDED residual (fused_add_rms_norm.cu:88-101): compare both ways
+    assert nmse(o_ref, host(out)) < 3e-6
+    assert nmse(O.rms_norm(host(rd), w, 1e-6), host(out)) < NMSE_FP16_TOL
+
+
+def test_rms_norm_empty_is_noop(env):
+    pkg, B, ctx, O, torch = env
+    out = torch.empty(0, 128, dtype=torch.float16, device="cuda")
+    B.rms_norm(ctx, out, dev16(torch, np.ones(128)), 1e-6, out, 0, 128)
+
+
+def test_embedding_silu_gelu_add_scale(env):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(1)
+    table = f16r(rng.standard_normal((300, 256)))
+    ids = np.array([0, 299, 17, 17, 4], np.uint32)
+    out = torch.empty(5, 256, dtype=torch.float16, device="cuda")
+    B.embedding_lookup(ctx, dev16(torch, table), torch.from_numpy(ids.astype(np.int32)).cuda(), out, 256)
+    assert np.array_equal(host(out), O.embedding_lookup(table, ids))        # a copy: exact
+    gu = f16r(rng.standard_normal((6, 2 * 768)) * 3)
+    act = torch.empty(6, 768, dtype=torch.float16, device="cuda")
+    B.fused_silu_mul_split(ctx, dev16(torch, gu), act, 6, 768)
+    assert nmse(O.fused_silu_mul_split(gu, 768), host(act)) < NMSE_FP16_TOL
+    B.fused_gelu_tanh_mul_split(ctx, dev16(torch, gu), act, 6, 768)
+    assert nmse(O.fused_gelu_tanh_mul_split(gu, 768), host(act)) < NMSE_FP16_TOL
+    a, b = f16r(rng.standard_normal(1000)), f16r(rng.standard_normal(1000))
+    ad = dev16(torch, a)
+    B.add_inplace(ctx, ad, dev16(torch, b), 1000)
+    assert np.array_equal(host(ad), f16r(O.add_inplace(a, b)))              # one rounding, exact after fp16
+    sd = dev16(torch, np.array([1.0, -2.0, 0.5]))
+    B.scale_inplace(ctx, sd, 33.9375, 3)                                    # llama_family.rs:6076-6086 KAT
+    assert list(host(sd)) == [33.9375, -67.875, 16.96875]
+
+
+# ── GPTQ INT4 linear ─────────────────────────────────────────────────────────
+def _gptq_case(env, k, n, m, seed, symmetric, g_idx=False, x_fn=None):
+    pkg, B, ctx, O, torch = env
+    qw, sc, qz = O.make_synthetic_gptq(k, n, 128, seed, symmetric=symmetric)
+    sc = f16r(sc)                                          # scales travel as fp16 on the device
+    gi = O.make_desc_act_g_idx(k, 128) if g_idx else None
+    lin = pkg.GptqLinear.from_raw(qw, sc, qz, gi, None, 4, 128, k, n)
+    if x_fn is None:
+        x = f16r(np.random.default_rng(seed).standard_normal((m, k)))
+    else:
+        x = f16r(x_fn(np.arange(m * k, dtype=np.float32)).reshape(m, k))
+    out = torch.empty(m, n, dtype=torch.float16, device="cuda")
+    lin.forward(ctx, dev16(torch, x), out, m)
+    w = O.dequant_gptq(qw, sc, qz, 128, k, n, g_idx=gi)
+    ref = O.gemm(x, w, m, n, k)
+    return ref, host(out)
+
+
+def test_gptq_reference_shapes(env):
+    # gptq_parity_test.rs:108-145 (K=256,N=128,m=2, sin(0.001 i)) and :329-405 (K=512,N=256,m=2, symmetric,
+    # cos(0.003 i) rounded to f16, rel err < 5 %): we hold the fp16 NMSE bucket instead
+    ref, got = _gptq_case(env, 256, 128, 2, 0xDEADBEEF, False, x_fn=lambda i: np.sin(i * np.float32(0.001)))
+    assert nmse(ref, got) < NMSE_FP16_TOL
+    ref, got = _gptq_case(env, 512, 256, 2, 0xC0FFEE, True, x_fn=lambda i: np.cos(i * np.float32(0.003)))
+    assert nmse(ref, got) < NMSE_FP16_TOL
+    assert np.max(np.abs(ref - got)) / np.max(np.abs(ref)) < 2e-3
+
+
+@pytest.mark.parametrize("k,n,m", [(2048, 5120, 1), (2048, 5120, 32), (4096, 2048, 4), (4096, 2048, 16),
+                                   (1024, 1536, 33), (768, 2048, 64), (512, 264, 100), (256, 72, 7)])
+def test_gptq_model_shapes(env, k, n, m):
+    ref, got = _gptq_case(env, k, n, m, 0x1234 + k + n + m, True)
+    assert nmse(ref, got) < NMSE_FP16_TOL
+
+
+@pytest.mark.parametrize("k,n,m", [(512, 256, 3), (2048, 640, 17)])
+def test_gptq_asymmetric_and_act_order(env, k, n, m):
+    ref, got = _gptq_case(env, k, n, m, 0x51A7E5, False)                 # explicit zero points
+    assert nmse(ref, got) < NMSE_FP16_TOL
+    ref, got = _gptq_case(env, k, n, m, 0x5A170A7, False, g_idx=True)    # desc_act (gptq_parity_test.rs:271)
+    assert nmse(ref, got) < NMSE_FP16_TOL
+
+
+def test_gptq_linearity(env):
+    # size-independent property at a BASELINE shape (Llama-8B o_proj 4096→4096): f(a·x+y) = a·f(x)+f(y)
+    pkg, B, ctx, O, torch = env
+    k, n, m = 4096, 4096, 8
+    qw, sc, qz = O.make_synthetic_gptq(k, n, 128, 99, symmetric=True)
+    lin = pkg.GptqLinear.from_raw(qw, f16r(sc), qz, None, None, 4, 128, k, n)
+    rng = np.random.default_rng(5)
+    x, y = f16r(rng.standard_normal((m, k))), f16r(rng.standard_normal((m, k)))
+    z = f16r(2.0 * x + y)                                 # exactly representable inputs are not needed:
+    outs = []
+    for v in (x, y, z):
+        o = torch.empty(m, n, dtype=torch.float16, device="cuda")
+        lin.forward(ctx, dev16(torch, v), o, m)
+        outs.append(host(o).astype(np.float64))
+    lhs = outs[2]
+    rhs = None
+    # z was rounded to fp16, so compare against f applied to the exact combination in fp64
+    w = O.dequant_gptq(qw, f16r(sc), qz, 128, k, n).astype(np.float64)
+    rhs = z.astype(np.float64) @ w.T
+    assert nmse(rhs, lhs) < NMSE_FP16_TOL
+    assert nmse(x.astype(np.float64) @ w.T, outs[0]) < NMSE_FP16_TOL
+
+
+# ── dense fp16 GEMM (router / lm_head) ───────────────────────────────────────
+@pytest.mark.parametrize("m,n,k,f32out", [(1, 128, 2048, True), (32, 128, 2048, True), (5, 1511, 1024, True),
+                                          (33, 96, 256, False), (64, 2048, 512, False)])
+def test_dense_gemm(env, m, n, k, f32out):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(m * n + k)
+    a, b = f16r(rng.standard_normal((m, k))), f16r(rng.standard_normal((n, k)) * 0.1)
+    out = torch.empty(m, n, dtype=torch.float32 if f32out else torch.float16, device="cuda")
+    B.gemm(ctx, dev16(torch, a), dev16(torch, b), out, m, n, k)
+    ref = O.gemm(a, b, m, n, k)
+    assert nmse(ref, host(out)) < (1e-10 if f32out else NMSE_FP16_TOL)
+
+
+# ── paged KV write / read ────────────────────────────────────────────────────
+def _rope(O, hd, max_seq, theta=1e6):
+    return O.build_rope_cache(theta, hd, max_seq)
+
+
+@pytest.mark.parametrize("qk_mode,hd", [(1, 128), (2, 128), (3, 128), (0, 128), (1, 64), (2, 256)])
+def test_split_qkv_norm_rope_into_paged_cache_varlen(env, qk_mode, hd):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(qk_mode * 10 + hd)
+    nq, nkv, bs = 8, 2, 16
+    q_lens, pos_offs = [5, 1, 19], [3, 40, 0]               # mixed prefill chunks + a decode row
+    num_seqs, m_total = len(q_lens), sum(q_lens)
+    max_blocks, num_blocks = 8, 32
+    cos, sin = _rope(O, hd, 128)
+    qkv = f16r(rng.standard_normal((m_total, (nq + 2 * nkv) * hd)))
+    qn, kn = f16r(1 + 0.1 * rng.standard_normal(hd)), f16r(1 + 0.1 * rng.standard_normal(hd))
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((num_seqs, max_blocks), np.int32)
+    used = 0
+    for s in range(num_seqs):
+        nb = (pos_offs[s] + q_lens[s] + bs - 1) // bs
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    ck, cv = B.alloc_paged_pool(num_blocks, nkv, hd), B.alloc_paged_pool(num_blocks, nkv, hd)
+    q_out = torch.empty(m_total, nq, hd, dtype=torch.float16, device="cuda")
+    B.split_qkv_norm_rope_into_paged_cache_varlen(
+        ctx, dev16(torch, qkv), dev16(torch, qn), dev16(torch, kn), torch.from_numpy(cos).cuda(),
+        torch.from_numpy(sin).cuda(), q_out, ck, cv, torch.from_numpy(cu).cuda(),
+        torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), num_seqs, m_total, nq,
+        nkv, hd, 1e-6, qk_mode, bs, max_blocks)
+    ctx.sync()
+    for s in range(num_seqs):
+        rows = qkv[cu[s]:cu[s + 1]]
+        q, k, v = O.split_qkv(rows, nq * hd, nkv * hd)
+        T = q_lens[s]
+        q_ref = O.qk_norm_rope(q.reshape(T, nq, hd), qn, cos, sin, T, nq, hd, pos_offs[s], 1e-6, qk_mode).transpose(1, 0, 2)
+        k_ref = O.qk_norm_rope(k.reshape(T, nkv, hd), kn, cos, sin, T, nkv, hd, pos_offs[s], 1e-6, qk_mode).transpose(1, 0, 2)
+        v_ref = v.reshape(T, nkv, hd)
+        assert nmse(q_ref, host(q_out[cu[s]:cu[s + 1]])) < NMSE_FP16_TOL
+        kv_len = pos_offs[s] + T
+        kk, vv = B.paged_kv_read(ctx, ck, cv, torch.from_numpy(tables[s]).cuda(), kv_len, nkv, hd)
+        ctx.sync()
+        kk, vv = host(kk), host(vv)
+        assert nmse(k_ref, kk[pos_offs[s]:]) < NMSE_FP16_TOL
+        assert np.array_equal(vv[pos_offs[s]:], v_ref)                     # V is a copy: exact
+        assert not kk[:pos_offs[s]].any() and not vv[:pos_offs[s]].any()   # earlier slots untouched
+    # bit-exact KV-block indexing: only the blocks named by the tables were written
+    written = set(int(b) for s in range(num_seqs) for b in
+                  tables[s, pos_offs[s] // bs:(pos_offs[s] + q_lens[s] + bs - 1) // bs])
+    pool = host(ck).reshape(num_blocks, -1)
+    for blk in range(num_blocks):
+        assert bool(pool[blk].any()) == (blk in written)
+
+
+# ── paged attention ──────────────────────────────────────────────────────────
+def _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks):
+    """Write per-sequence K/V [len,nkv,hd] into native pools through the product's own writer (mode 0)."""
+    pkg, B, ctx, O, torch = env
+    ck, cv = B.alloc_paged_pool(num_blocks, nkv, hd), B.alloc_paged_pool(num_blocks, nkv, hd)
+    nq = nkv
+    for s, n in enumerate(kv_lens):
+        qkv = np.concatenate([np.zeros((n, nq * hd), np.float32), K[s].reshape(n, -1), V[s].reshape(n, -1)], axis=1)
+        q_out = torch.empty(n, nq, hd, dtype=torch.float16, device="cuda")
+        dummy = dev16(torch, np.ones(hd))
+        cs = torch.zeros(max(kv_lens) + 1, hd // 2, device="cuda")
+        B.split_qkv_norm_rope_into_paged_cache_varlen(
+            ctx, dev16(torch, qkv), dummy, dummy, cs, cs, q_out, ck, cv,
+            torch.tensor([0, n], dtype=torch.int32, device="cuda"), torch.tensor([0], dtype=torch.int32, device="cuda"),
+            torch.from_numpy(tables[s:s + 1].copy()).cuda(), 1, n, nq, nkv, hd, 1e-6, 0, 16, tables.shape[1])
+    ctx.sync()
+    return ck, cv
+
+
+def _ref_attention(O, q, K, V, pos_offset, nq, nkv, hd, window=0):
+    """q [T,nq,hd] at positions pos_offset.. over K/V [len,nkv,hd] → [T,nq,hd] (cpu.rs:2179-2259)."""
+    T, kv_len = q.shape[0], K.shape[0]
+    out = O.cpu_attention(q.transpose(1, 0, 2), K.transpose(1, 0, 2), V.transpose(1, 0, 2), T, kv_len, True, pos_offset,
+                          nq, nkv, hd, sliding_window=window)
+    return out.transpose(1, 0, 2)
+
+
+def test_paged_decode_uniform_scores_golden(env):
+    # ferrum-kv/src/attention.rs:162-195: equal scores → output = mean(V) = 2.0
+    pkg, B, ctx, O, torch = env
+    nq = nkv = 2
+    hd = 64
+    K = [np.ones((3, nkv, hd), np.float32)]
+    V = [np.stack([np.full((nkv, hd), p + 1, np.float32) for p in range(3)])]
+    tables = np.array([[5, 0]], np.int32)
+    ck, cv = _fill_pool(env, K, V, tables, [3], nkv, hd, 8)
+    out = torch.empty(1, nq, hd, dtype=torch.float16, device="cuda")
+    B.paged_batched_decode_attention(ctx, dev16(torch, np.ones((1, nq, hd))), ck, cv, out, torch.from_numpy(tables).cuda(),
+                                     torch.tensor([3], dtype=torch.int32, device="cuda"), 1, 3, nq, nkv, hd, 16, 2)
+    ctx.sync()
+    assert np.all(np.abs(host(out) - 2.0) < 1e-3)
+
+
+@pytest.mark.parametrize("nq,nkv,hd,kv_lens", [(32, 4, 128, [1, 16, 17, 257, 300, 384, 33, 250]),
+                                               (32, 8, 128, [100, 5]), (8, 8, 128, [48]), (16, 1, 128, [700, 31]),
+                                               (4, 2, 64, [77]), (8, 2, 256, [40, 130])])
+def test_paged_batched_decode_attention(env, nq, nkv, hd, kv_lens):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(nq + nkv + hd + len(kv_lens))
+    S = len(kv_lens)
+    max_blocks = (max(kv_lens) + 15) // 16 + 1
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 3
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used = 0
+    K, V = [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    q = f16r(rng.standard_normal((S, nq, hd)))
+    out = torch.empty(S, nq, hd, dtype=torch.float16, device="cuda")
+    B.paged_batched_decode_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(tables).cuda(),
+                                     torch.from_numpy(np.array(kv_lens, np.int32)).cuda(), S, max(kv_lens), nq, nkv, hd,
+                                     16, max_blocks)
+    ctx.sync()
+    got = host(out)
+    for s, n in enumerate(kv_lens):
+        ref = _ref_attention(O, q[s:s + 1], K[s], V[s], n - 1, nq, nkv, hd)
+        assert nmse(ref, got[s:s + 1]) < 1e-5, (s, n)          # far inside the 5e-3 attention bucket
+        # cross-check with the second reference formulation (ferrum-kv attention.rs three-pass softmax)
+    assert NMSE_ATTN_TOL > 1e-5
+
+
+@pytest.mark.parametrize("window", [0, 24])
+def test_paged_varlen_attention_mixed_batch(env, window):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(11 + window)
+    nq, nkv, hd = 8, 2, 128
+    q_lens, pos_offs = [37, 1, 16, 3], [0, 90, 20, 250]       # fresh prefill, decode, chunk, late chunk
+    S = len(q_lens)
+    kv_lens = [p + t for p, t in zip(pos_offs, q_lens)]
+    max_blocks = (max(kv_lens) + 15) // 16
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 1
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used, K, V = 0, [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    m_total = sum(q_lens)
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    q = f16r(rng.standard_normal((m_total, nq, hd)))
+    out = torch.zeros(m_total, nq, hd, dtype=torch.float16, device="cuda")
+    B.paged_varlen_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(cu).cuda(),
+                             torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
+                             m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
+    ctx.sync()
+    got = host(out)
+    for s in range(S):
+        ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
+        assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
+    if window == 0:
+        # the paged reference (attention.rs:30-114) agrees for the fresh-prefill sequence
+        pk = np.zeros((num_blocks, 16, nkv, hd), np.float32)
+        pv = np.zeros_like(pk)
+        for p in range(kv_lens[0]):
+            pk[tables[0, p // 16], p % 16] = K[0][p]
+            pv[tables[0, p // 16], p % 16] = V[0][p]
+        ref2 = O.paged_attention(q[:q_lens[0]], q_lens[0], nq, nkv, hd, pk, pv, tables[0], 16, kv_lens[0])
+        assert nmse(ref2, got[:q_lens[0]]) < 1e-5
+
+
+def test_paged_decode_long_context_split_kv(env):
+    # exercises the grid.z flash-decode split + reduce at a BASELINE-like head config (Qwen3-30B: 32/4 heads)
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(3)
+    nq, nkv, hd, kv_lens = 32, 4, 128, [4096, 1500]
+    S = 2
+    max_blocks = (max(kv_lens) + 15) // 16
+    num_blocks = sum((n + 15) // 16 for n in kv_lens)
+    tables = np.zeros((S, max_blocks), np.int32)
+    perm = rng.permutation(num_blocks)
+    used, K, V = 0, [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    q = f16r(rng.standard_normal((S, nq, hd)))
+    q[0, 3] *= 6.0                                          # a peaked row: forces large online-softmax rescales
+    out = torch.empty(S, nq, hd, dtype=torch.float16, device="cuda")
+    B.paged_batched_decode_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(tables).cuda(),
+                                     torch.from_numpy(np.array(kv_lens, np.int32)).cuda(), S, max(kv_lens), nq, nkv, hd,
+                                     16, max_blocks)
+    ctx.sync()
+    got = host(out)
+    for s, n in enumerate(kv_lens):
+        ref = _ref_attention(O, q[s:s + 1], K[s], V[s], n - 1, nq, nkv, hd)
+        assert nmse(ref, got[s:s + 1]) < 1e-5
+
+
+# ── MoE ──────────────────────────────────────────────────────────────────────
+@pytest.mark.parametrize("batch,ne,k,norm,seed", [(32, 128, 8, True, 0xDEADBEEF), (1, 128, 8, True, 0x1234),
+                                                  (64, 128, 8, True, 0x5678), (8, 64, 4, False, 0xC0FFEE),
+                                                  (4, 16, 1, True, 0x42), (3, 256, 8, True, 7)])
+def test_route_topk_softmax(env, batch, ne, k, norm, seed):
+    # router.rs:203-244 shapes; ids bit-exact, weights within the renorm-divide ulps (1e-6, :219-222)
+    pkg, B, ctx, O, torch = env
+    logits = O.Lcg(seed).array_f32(batch * ne, -3.0, 3.0).reshape(batch, ne)
+    ids = torch.empty(batch, k, dtype=torch.int32, device="cuda")
+    w = torch.empty(batch, k, dtype=torch.float32, device="cuda")
+    B.route_topk_softmax(ctx, torch.from_numpy(logits).cuda(), ids, w, batch, ne, k, norm)
+    ctx.sync()
+    rid, rw = O.route_topk(logits, ne, k, norm)
+    assert np.array_equal(ids.cpu().numpy().astype(np.uint32), rid)
+    assert np.max(np.abs(w.cpu().numpy() - rw)) < 1e-6
+    # fp16-logit entry point (moe_router.cu:32 form)
+    l16 = f16r(logits)
+    B.route_topk_softmax(ctx, dev16(torch, l16), ids, w, batch, ne, k, norm)
+    ctx.sync()
+    rid, rw = O.route_topk(l16, ne, k, norm)
+    assert np.array_equal(ids.cpu().numpy().astype(np.uint32), rid)
+
+
+def test_route_ties_lowest_index(env):
+    pkg, B, ctx, O, torch = env
+    logits = np.full((2, 128), 0.5, np.float32)
+    ids = torch.empty(2, 8, dtype=torch.int32, device="cuda")
+    w = torch.empty(2, 8, dtype=torch.float32, device="cuda")
+    B.route_topk_softmax(ctx, torch.from_numpy(logits).cuda(), ids, w, 2, 128, 8, True)
+    ctx.sync()
+    assert np.array_equal(ids.cpu().numpy(), np.tile(np.arange(8), (2, 1)))
+    assert np.all(np.abs(w.cpu().numpy() - 0.125) < 1e-7)
+
+
+@pytest.mark.parametrize("tokens,ne,k", [(1, 128, 8), (32, 128, 8), (700, 128, 8), (5, 8, 2), (0, 16, 2)])
+def test_moe_align_block_size_bit_exact(env, tokens, ne, k):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens + ne)
+    ids = np.stack([rng.choice(ne, size=k, replace=False) for _ in range(tokens)]).astype(np.int32) if tokens else \
+        np.zeros((0, k), np.int32)
+    n = tokens * k
+    sorted_max = n + ne * 16
+    sd = torch.full((sorted_max,), -7, dtype=torch.int32, device="cuda")
+    bd = torch.full((sorted_max // 16 + 1,), -7, dtype=torch.int32, device="cuda")
+    td = torch.zeros(1, dtype=torch.int32, device="cuda")
+    B.moe_align_block_size_pair_ids(ctx, torch.from_numpy(ids.reshape(-1).copy()).cuda(), sd, bd, td, n, ne, 16, sorted_max)
+    ctx.sync()
+    rs, rb, rt = O.moe_align_block_size(ids, ne, 16)
+    assert int(td.item()) == rt
+    assert np.array_equal(sd.cpu().numpy(), rs)
+    assert np.array_equal(bd.cpu().numpy()[:len(rb)], rb)
+
+
+@pytest.mark.parametrize("tokens,E,K,H,I", [(1, 8, 2, 256, 128), (9, 8, 2, 256, 128), (32, 16, 4, 512, 256)])
+def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
+    # whole expert MLP path vs moe_forward_cpu (dispatch.rs:2208-2288), plain and fused-silu stacks
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens * E + H)
+    gu = [O.make_synthetic_gptq(H, 2 * I, 128, 100 + e, symmetric=True) for e in range(E)]
+    dn = [O.make_synthetic_gptq(I, H, 128, 200 + e, symmetric=True) for e in range(E)]
+    gu = [(q, f16r(s / (0.28 * np.sqrt(H))), z) for q, s, z in gu]
+    dn = [(q, f16r(s / (0.28 * np.sqrt(I))), z) for q, s, z in dn]
+    x = f16r(rng.standard_normal((tokens, H)))
+    logits = rng.standard_normal((tokens, E)).astype(np.float32)
+    rid, rw = O.route_topk(logits, E, K, True)
+    gw = np.stack([O.dequant_gptq(q, s, z, 128, H, 2 * I) for q, s, z in gu])
+    dw = np.stack([O.dequant_gptq(q, s, z, 128, I, H) for q, s, z in dn])
+    ref = O.moe_forward_cpu(x, H, I, K, rid, rw, gw, dw)
+    P = tokens * K
+    sorted_max = P + E * 16
+    ids_d = torch.from_numpy(rid.astype(np.int32).reshape(-1).copy()).cuda()
+    sd = torch.empty(sorted_max, dtype=torch.int32, device="cuda")
+    bd = torch.empty(sorted_max // 16 + 1, dtype=torch.int32, device="cuda")
+    td = torch.zeros(1, dtype=torch.int32, device="cuda")
+    B.moe_align_block_size_pair_ids(ctx, ids_d, sd, bd, td, P, E, 16, sorted_max)
+    max_blocks = sorted_max // 16
+    xd = dev16(torch, x)
+    wd = torch.from_numpy(rw.reshape(-1).copy()).cuda()
+    down_stack = B.load_gptq_stacked([q for q, _, _ in dn], [s for _, s, _ in dn], [z for _, _, z in dn], None, 4, 128, I, H)
+    for fused in (False, True):
+        stack = B.load_gptq_stacked([q for q, _, _ in gu], [s for _, s, _ in gu], [z for _, _, z in gu], None, 4, 128, H,
+                                    2 * I, fuse_gate_up=fused)
+        act = torch.zeros(P, I, dtype=torch.float16, device="cuda")
+        if fused:
+            stack.gemm_phase_vllm(ctx, xd, sd, bd, td, act, P, 16, K, max_blocks, fused_silu_mul=True)
+        else:
+            gup = torch.zeros(P, 2 * I, dtype=torch.float16, device="cuda")
+            stack.gemm_phase_vllm(ctx, xd, sd, bd, td, gup, P, 16, K, max_blocks)
+            B.fused_silu_mul_split(ctx, gup, act, P, I)
+        down = torch.zeros(P, H, dtype=torch.float16, device="cuda")
+        down_stack.gemm_phase_vllm(ctx, act, sd, bd, td, down, P, 16, 1, max_blocks)
+        out = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+        B.moe_combine(ctx, down, wd, out, tokens, K, H)
+        ctx.sync()
+        assert nmse(ref, host(out)) < 3e-6, fused            # three fp16 roundings (act, down, out)
+
+
+# ── sampling ─────────────────────────────────────────────────────────────────
+def test_argmax_rows_first_max_and_mask(env):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(9)
+    m, n = 5, 151936
+    logits = rng.standard_normal((m, n)).astype(np.float32)
+    logits[0, 777] = logits[0, 120000] = 9.0               # tie → first index (traits.rs:1547)
+    logits[1, n - 1] = 50.0
+    logits[2, 0] = 50.0
+    ld = torch.from_numpy(logits).cuda()
+    assert np.array_equal(B.argmax_rows_f16(ctx, ld, m, n), O.argmax_rows(logits))
+    l16 = f16r(logits)
+    assert np.array_equal(B.argmax_rows_f16(ctx, dev16(torch, l16), m, n), O.argmax_rows(l16))
+    mask = np.ones(n, np.uint8)
+    mask[777] = 0
+    mask_len = n - 1                                        # ids ≥ mask_len are invalid
+    got = B.argmax_rows_f16_masked(ctx, ld, torch.from_numpy(mask).cuda(), mask_len, m, n)
+    masked = logits.copy()
+    masked[:, 777] = -np.inf
+    masked[:, mask_len:] = -np.inf
+    assert np.array_equal(got, O.argmax_rows(masked))
+
+
+def test_sparse_repetition_penalty_then_argmax(env):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(10)
+    m, n = 3, 4096
+    logits = rng.standard_normal((m, n)).astype(np.float32)
+    prev = [np.unique(rng.integers(0, n, size=50)).astype(np.uint32) for _ in range(m)]
+    for r in range(m):
+        logits[r, prev[r][0]] = 20.0                        # the penalised id was the winner
+    offs = np.concatenate([[0], np.cumsum([len(p) for p in prev])]).astype(np.int32)
+    pens = np.array([1.1, 1.0, 3.0], np.float32)
+    ld = torch.from_numpy(logits.copy()).cuda()
+    got = B.argmax_rows_f16_sparse_repetition_penalty(
+        ctx, ld, None, torch.from_numpy(offs).cuda(), torch.from_numpy(np.concatenate(prev).astype(np.int32)).cuda(),
+        torch.from_numpy(pens).cuda(), int(offs[-1]), m, n)
+    ref_logits = np.stack([O.repetition_penalty(logits[r], prev[r], float(pens[r])) for r in range(m)])
+    assert np.allclose(ld.cpu().numpy(), ref_logits, rtol=1e-6, atol=0)
+    assert np.array_equal(got, O.argmax_rows(ref_logits))
