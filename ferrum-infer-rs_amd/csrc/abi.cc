@@ -371,7 +371,7 @@ int ferrum_hip_moe_route_topk_softmax_f32(const float* logits, int32_t* ids, flo
 int ferrum_hip_moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
                                     int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
                                     int sorted_max, void* stream) {
-    FH_REQUIRE(expert_ids && sorted_token_ids && block_ids && total_post_pad, "moe_align_block_size: null buffer");
+    FH_REQUIRE((expert_ids || batch_x_topk == 0) && sorted_token_ids && block_ids && total_post_pad, "moe_align_block_size: null buffer");
     return moe_align_block_size(expert_ids, sorted_token_ids, block_ids, total_post_pad, batch_x_topk, num_experts,
                                 block_size, sorted_max, ST(stream));
 }
