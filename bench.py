@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""bench.py — decode throughput of the MI355X-native ferrum hot path.
+
+Workload (BASELINE.json metric): Qwen3-30B-A3B GPTQ-INT4 architecture (48 layers, H 2048, 32/4 heads × 128,
+128 experts top-8, expert-I 768, V 151936), synthetic GPTQ weights generated on the device (no checkpoints
+offline), 256-token random prompts, greedy decode at concurrency c (default 32), KV block 16, fp16 KV.
+A "step" = one decode step of the whole batch (c new tokens) through the C++ runner in libferrum_hip.so
+(hipGraph replay); `value` = output tokens/s summed over all GPUs.  Per SURVEY.md §8(e) the reference does
+not shard this MoE config, so N GPUs run N independent replicas ("scaling": "weak").
+
+Launch: `python bench.py --gpus 1` or
+`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+QWEN3_30B_A3B = dict(num_layers=48, hidden=2048, num_heads=32, num_kv_heads=4, head_dim=128, intermediate=0,
+                     vocab=151936, has_qk_norm=1, activation=0, num_experts=128, top_k=8, expert_inter=768,
+                     norm_topk_prob=1, rms_eps=1e-6, rope_theta=1e6)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_model(pkg, cfg, c, max_seq_len, prefill_tokens, seed, layers=None):
+    d = dict(cfg)
+    if layers:
+        d["num_layers"] = layers
+    blocks = (c + 2) * ((max_seq_len + 15) // 16)
+    m = pkg.HipModel(group_size=128, kv_num_blocks=blocks, max_seqs=max(c, 1), max_tokens=max(prefill_tokens, c),
+                     max_seq_len=max_seq_len, **d)
+    m.init_synthetic(seed)
+    m.finalize()
+    return m
+
+
+def prefill(model, prompts, first_id, chunk_tokens):
+    """Whole-prompt prefill in batches of ≤ chunk_tokens query tokens; returns the first sampled tokens."""
+    out = []
+    per = max(1, chunk_tokens // len(prompts[0]))
+    for i in range(0, len(prompts), per):
+        items = [(first_id + i + j, p, 0, True) for j, p in enumerate(prompts[i:i + per])]
+        toks, _ = model.unified_forward(items, greedy=True)
+        out.extend(int(t) for t in toks)
+    return np.array(out, np.uint32)
+
+
+def moe_gemm_bytes(cfg, blocks, tokens, which):
+    """Algorithmic HBM bytes of one MoE grouped-GEMM launch: every routed expert's INT4
+    weights + fp16 group scales once, plus the fp16 activations in and out."""
+    H, I, K = cfg["hidden"], cfg["expert_inter"], cfg["top_k"]
+    P = tokens * K
+    if which == "moe_gate_up":
+        w = H * 2 * I // 2 + (H // 128) * 2 * I * 2
+        act = tokens * H * 2 + P * I * 2
+    else:
+        w = I * H // 2 + (I // 128) * H * 2
+        act = P * I * 2 + P * H * 2
+    return blocks * w + act
+
+
+def cpu_baseline(cfg, seed=1):
+    """Reference CPU path restated in C (oracle/, f64-accumulating GEMM, 1 thread like cpu.rs:483-491),
+    timed on a bounded sample: ONE of the 48 layers at the full Qwen3-30B-A3B dims, 16-token prefill then 6
+    decode tokens, plus one lm_head; scaled to 48 layers → decode tokens/s at c=1."""
+    from oracle import oracle as O
+    t_build = time.time()
+    H, E, I = cfg["hidden"], cfg["num_experts"], cfg["expert_inter"]
+    nq, nkv, hd, V = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"], cfg["vocab"]
+    rng = np.random.default_rng(seed)
+    om = O.OracleModel(num_layers=1, hidden=H, num_heads=nq, num_kv_heads=nkv, head_dim=hd, intermediate=0, vocab=V,
+                       max_seq_len=64, has_qk_norm=1, num_experts=E, top_k=cfg["top_k"], expert_inter=I,
+                       norm_topk_prob=1, rms_eps=1e-6, rope_theta=1e6)
+    emb = (rng.standard_normal((V, H)) * 0.02).astype(np.float32)
+    om.set_global("embed", emb)
+    om.set_global("final_norm", np.ones(H, np.float32))      # lm_head tied to embed (llama_family.rs:969-1001)
+    for name in ("input_ln", "post_ln"):
+        om.set_layer_dense(0, name, np.ones(H, np.float32))
+    om.set_layer_dense(0, "q_norm", np.ones(hd, np.float32))
+    om.set_layer_dense(0, "k_norm", np.ones(hd, np.float32))
+    om.set_layer_dense(0, "router", (rng.standard_normal((E, H)) * 0.02).astype(np.float32))
+
+    def gptq(k, n, s):
+        qw, sc, qz = O.make_synthetic_gptq(k, n, 128, s, symmetric=True)
+        return qw, sc / np.float32(0.28 * np.sqrt(k)), qz
+    qd = nq * hd
+    om.set_gptq(0, "qkv", *gptq(H, qd + 2 * nkv * hd, 11), 128, H, qd + 2 * nkv * hd)
+    om.set_gptq(0, "o", *gptq(qd, H, 12), 128, qd, H)
+    gu, dn = gptq(H, 2 * I, 13), gptq(I, H, 14)               # same tensors for every expert: timing only
+    for e in range(E):
+        om.set_gptq(0, "expert_gate_up", *gu, 128, H, 2 * I, expert=e)
+        om.set_gptq(0, "expert_down", *dn, 128, I, H, expert=e)
+    build_s = time.time() - t_build
+    toks = rng.integers(256, V, size=16).astype(np.uint32)
+    om.forward(0, toks, 0)
+    n_dec = 6
+    t0 = time.perf_counter()
+    for i in range(n_dec):
+        om.forward(0, np.array([toks[i]], np.uint32), 16 + i)
+    t_total = (time.perf_counter() - t0) / n_dec               # one layer + final norm + lm_head
+    x = rng.standard_normal((1, H)).astype(np.float32)
+    t1 = time.perf_counter()
+    O.gemm(x, emb, 1, V, H)
+    t_head = time.perf_counter() - t1
+    t_layer = max(t_total - t_head, 1e-9)
+    tok_s = 1.0 / (cfg["num_layers"] * t_layer + t_head)
+    return {"value": round(tok_s, 4), "unit": "tok/s", "cores": 1, "kind": "port",
+            "sample": f"oracle C restatement, 1 of {cfg['num_layers']} layers at full Qwen3-30B-A3B dims, 16-token "
+                      f"prefill + {n_dec} decode tokens (c=1) + 1 lm_head, scaled to {cfg['num_layers']} layers; "
+                      f"layer {t_layer * 1e3:.1f} ms, lm_head {t_head * 1e3:.1f} ms, setup {build_s:.0f} s",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--concurrency", type=int, default=32)
+    ap.add_argument("--prompt-len", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=0, help="debug: fewer layers (result is then NOT the metric)")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    pkg.load_library()
+    cfg = dict(QWEN3_30B_A3B)
+    c, K, W, PL = args.concurrency, args.steps, args.warmup, args.prompt_len
+    max_seq_len = ((PL + W + K + 8 + 15) // 16) * 16
+    chunk = 2048
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_case(model, conc, steps, warm, first_id):
+        rng = np.random.default_rng(9271 + rank)               # seed of the reference's bench-serve command
+        prompts = [rng.integers(256, cfg["vocab"], size=PL).astype(np.uint32) for _ in range(conc)]
+        first = prefill(model, prompts, first_id, chunk)
+        ids = list(range(first_id, first_id + conc))
+        warm_toks = model.decode_steps(ids, first, warm) if warm > 0 else None
+        nxt = warm_toks[-1] if warm > 0 else first
+        barrier()
+        t0 = time.perf_counter()
+        model.decode_steps(ids, nxt, steps)
+        torch.cuda.synchronize()
+        t_local = time.perf_counter() - t0
+        barrier()
+        return t_local, PL + warm + steps
+
+    model = build_model(pkg, cfg, c, max_seq_len, chunk, 9271 + rank, layers=args.layers or None)
+    t_local, kv_end = run_case(model, c, K, W, 0)
+    t = torch.tensor([t_local], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_max = float(t.item())
+    value = world * c * K / t_max
+
+    extra = {}
+    if rank == 0:
+        # dominant kernel: MoE gate_up grouped INT4 GEMM — live HIP-event timing on the runner's stream
+        kernels = {}
+        for name in ("moe_gate_up", "moe_down", "attention", "qkv", "o", "lm_head"):
+            us, blocks = model.time_kernel(name, c, kv_end, reps=3)
+            entry = {"avg_us": round(us, 2)}
+            if name.startswith("moe"):
+                b = moe_gemm_bytes(cfg, blocks, c, name)
+                entry.update(expert_blocks=blocks, bytes=b, gbs=round(b / us / 1e3, 1))
+            elif name == "attention":
+                mean_kv = kv_end - 0.5
+                b = int(c * mean_kv * cfg["num_kv_heads"] * cfg["head_dim"] * 2 * 2 + 2 * c * cfg["num_heads"] * cfg["head_dim"] * 2)
+                entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
+            elif name in ("qkv", "o"):
+                kk, nn = (cfg["hidden"], (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * cfg["head_dim"]) if name == "qkv" \
+                    else (cfg["num_heads"] * cfg["head_dim"], cfg["hidden"])
+                b = kk * nn // 2 + (kk // 128) * nn * 2 + c * (kk + nn) * 2
+                entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
+            else:
+                b = cfg["vocab"] * cfg["hidden"] * 2 + c * cfg["vocab"] * 4
+                entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
+            kernels[name] = entry
+        dom = kernels["moe_gate_up"]
+        extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_kernel<1,false,2> (MoE gate_up INT4 grouped GEMM + silu*mul)",
+                             "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                             "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"]}
+        extra["kernels"] = kernels
+        # whole-step roofline: weights touched + KV + lm_head per step
+        L = model.cfg.num_layers
+        step_bytes = L * (kernels["moe_gate_up"]["bytes"] + kernels["moe_down"]["bytes"] + kernels["attention"]["bytes"] +
+                          kernels["qkv"]["bytes"] + kernels["o"]["bytes"]) + kernels["lm_head"]["bytes"]
+        extra["step_roofline"] = {"bytes_per_step": int(step_bytes), "achieved_gbs": round(step_bytes / (t_max / K) / 1e9, 1),
+                                  "frac": round(step_bytes / (t_max / K) / 1e9 / HBM_PEAK_GBS, 4)}
+        for sid in range(c):
+            model.release(sid)
+        if not args.no_sweep and world == 1:
+            sweep = {str(c): round(value, 1)}
+            ttft = []
+            for conc in (1, 4, 16):
+                tl, _ = run_case(model, conc, min(K, 32), 4, 1000 * conc)
+                sweep[str(conc)] = round(conc * min(K, 32) / tl, 1)
+                for s in range(1000 * conc, 1000 * conc + conc):
+                    model.release(s)
+            rng = np.random.default_rng(1)
+            for i in range(5):                                 # TTFT: 256-token prompt, idle engine (c=1)
+                p = rng.integers(256, cfg["vocab"], size=PL).astype(np.uint32)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                model.unified_forward([(5000 + i, p, 0, True)], greedy=True)
+                ttft.append((time.perf_counter() - t0) * 1e3)
+                model.release(5000 + i)
+            extra["sweep_tok_s"] = sweep
+            extra["ttft_ms_p50_c1"] = round(float(np.median(ttft)), 2)
+        if not args.no_cpu_baseline and world == 1:
+            extra["cpu_baseline"] = cpu_baseline(cfg)
+
+    if rank == 0:
+        line = {"metric": "output tok/s at c=32, Qwen3-30B-A3B GPTQ-INT4 (256-in/128-out decode)", "value": round(value, 1),
+                "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(t_max / K * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int4-weights/f16-activations/f32-accumulate",
+                "data": "synthetic",
+                "config": {"workload": "Qwen3-30B-A3B GPTQ-INT4 (BASELINE configs[2]), TP=1 per GPU, replicas across GPUs",
+                           "concurrency": c, "prompt_len": PL, "kv_len_range": [PL + W, PL + W + K], "kv_block": 16,
+                           "layers": model.cfg.num_layers, "parallelism": f"replica x{world}"}}
+        line.update(extra)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

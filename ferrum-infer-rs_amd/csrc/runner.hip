@@ -122,9 +122,15 @@ __device__ __forceinline__ uint64_t splitmix(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
+// packed INT4 words with zero-mean codes: nibble 0 is remapped to 8, so q − 8 ∈ [−7, 7] has mean 0
+// (a non-zero mean would give every GEMM output a token-independent common mode and collapse the
+// synthetic router onto a handful of experts — not the traffic pattern of a trained model).
 __global__ void synth_u32_kernel(uint32_t* p, long n, uint64_t seed) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = (uint32_t)(splitmix(seed + (uint64_t)i) >> 16);
+    if (i >= n) return;
+    uint32_t w = (uint32_t)(splitmix(seed + (uint64_t)i) >> 16);
+    uint32_t zero_nibbles = ~(w | (w >> 1) | (w >> 2) | (w >> 3)) & 0x11111111u;   // 1 where a nibble is 0
+    p[i] = w | (zero_nibbles << 3);
 }
 __global__ void synth_f16_uniform_kernel(__half* p, long n, uint64_t seed, float lo, float hi) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,7 +340,7 @@ static void launch1d(void (*k)(__half*, long, uint64_t, float, float), __half* p
 }
 
 // Synthetic weights generated on the device (bench only: no checkpoints are available offline).
-// qweight nibbles uniform, scales uniform [0.01,0.1)·f with f = 1/(0.28·sqrt(K)) so that
+// qweight nibbles uniform, scales uniform [0.01,0.1)·f with f = 1/(0.25·sqrt(K)) so that
 // dequantised W has std ≈ 1/sqrt(K) and activations stay O(1) through all layers,
 // zero point 8 (sym), norm weights 1, embeddings / lm_head / router N(0, 0.02).
 static int synth_w4(W4Device* w, int k, int n, int E, bool fused, uint64_t seed, hipStream_t s) {
@@ -344,7 +350,7 @@ static int synth_w4(W4Device* w, int k, int n, int E, bool fused, uint64_t seed,
     FH_CHECK_HIP(hipMalloc((void**)&w->qw, qw * 4));
     FH_CHECK_HIP(hipMalloc((void**)&w->sc, sc * 2));
     hipLaunchKernelGGL(synth_u32_kernel, dim3(cdiv(qw, 256)), dim3(256), 0, s, w->qw, qw, seed);
-    float f = 1.0f / (0.28f * sqrtf((float)k));
+    float f = 1.0f / (0.25f * sqrtf((float)k));   // std(q-8)·mean(scale) ≈ 4.5·0.055
     launch1d(synth_f16_uniform_kernel, w->sc, sc, seed ^ 0x5ca1e5ull, 0.01f * f, 0.1f * f, s);
     FH_CHECK_LAUNCH();
     return 0;
@@ -839,6 +845,65 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
         FH_CHECK_HIP(hipMemcpyAsync(out_tokens, m->history, (size_t)steps * n * 4, hipMemcpyDeviceToHost, m->stream));
     FH_CHECK_HIP(hipStreamSynchronize(m->stream));
     for (int i = 0; i < n; i++) m->seqs[seq_ids[i]].len += steps;
+    return 0;
+}
+
+// Bench instrumentation: average device time of ONE launch of a hot kernel, measured with HIP events
+// on the model's stream.  The launch is repeated over every layer's weights (L distinct weight sets,
+// far larger than the 256 MiB Infinity Cache) using the routing / index state the last forward left
+// in the scratch buffers, `reps` rounds.  which: 0 MoE gate_up (+silu·mul), 1 MoE down,
+// 2 paged decode attention, 3 qkv GEMM, 4 o GEMM, 5 lm_head GEMM.  Returns the mean microseconds per
+// launch and (for MoE) the number of 16-row expert blocks the routing holds.
+int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int max_kv_len, int reps, float* avg_us,
+                                 int* moe_blocks) {
+    FH_REQUIRE(m && m->finalized && avg_us && reps > 0, "time_kernel: bad argument");
+    const FerrumHipModelConfig& c = m->cfg;
+    hipStream_t s = m->stream;
+    const int T = n_seqs, H = c.hidden;
+    hipEvent_t e0, e1;
+    FH_CHECK_HIP(hipEventCreate(&e0));
+    FH_CHECK_HIP(hipEventCreate(&e1));
+    int blocks = 0;
+    if (c.num_experts > 0) {
+        int32_t total = 0;
+        FH_CHECK_HIP(hipMemcpyAsync(&total, m->total_post_pad, 4, hipMemcpyDeviceToHost, s));
+        FH_CHECK_HIP(hipStreamSynchronize(s));
+        blocks = total / 16;
+    }
+    if (moe_blocks) *moe_blocks = blocks;
+    const int P = T * std::max(c.top_k, 1), E = c.num_experts;
+    const int max_blocks = E > 0 ? std::min((P + E * 16) / 16, P / 16 + std::min(P, E)) : 0;
+    int launches = 0, rc = 0;
+    auto one = [&](int li) -> int {
+        LayerWeights& L = m->layers[li];
+        switch (which) {
+        case 0: return w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, c.top_k, 1, s);
+        case 1: return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
+        case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),
+                                                          idx<uint32_t>(m, m->il.kv_lens), T, max_kv_len, c.num_heads, c.num_kv_heads,
+                                                          c.head_dim, KV_BLOCK, m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s);
+        case 3: return w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s);
+        case 4: return w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s);
+        case 5: return f16_gemm_f32out(m->sampled_hidden, m->lm_head ? m->lm_head : m->embed, m->logits, T, c.vocab, H, m->workspace, m->workspace_bytes, s);
+        }
+        fh::set_error("time_kernel: which=%d", which);
+        return FERRUM_HIP_INVALID;
+    };
+    FH_REQUIRE(which >= 2 || E > 0, "time_kernel: MoE kernel on a dense model");
+    // warm-up round (code objects, TLBs), then the timed rounds
+    for (int li = 0; li < c.num_layers && !rc; li++) rc = one(li);
+    if (rc) return rc;
+    FH_CHECK_HIP(hipEventRecord(e0, s));
+    for (int r = 0; r < reps && !rc; r++)
+        for (int li = 0; li < c.num_layers && !rc; li++) { rc = one(which == 5 ? 0 : li); launches++; }
+    FH_CHECK_HIP(hipEventRecord(e1, s));
+    FH_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    FH_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *avg_us = ms * 1000.0f / (float)launches;
     return 0;
 }
 

@@ -163,6 +163,14 @@ class HipModel:
         _check(self.lib.ferrum_hip_model_read_taps(self.h, out.ctypes.data_as(C.POINTER(C.c_float)), tokens), "read_taps")
         return out
 
+    def time_kernel(self, which, n_seqs, max_kv_len, reps=3):
+        """Mean µs per launch of a hot kernel (HIP events on the model stream) and the MoE block count."""
+        names = {"moe_gate_up": 0, "moe_down": 1, "attention": 2, "qkv": 3, "o": 4, "lm_head": 5}
+        us, blocks = C.c_float(), C.c_int()
+        _check(self.lib.ferrum_hip_model_time_kernel(self.h, names[which], n_seqs, max_kv_len, reps, C.byref(us),
+                                                     C.byref(blocks)), "time_kernel")
+        return us.value, blocks.value
+
     def stream(self):
         s = C.c_void_p()
         _check(self.lib.ferrum_hip_model_stream(self.h, C.byref(s)), "model_stream")

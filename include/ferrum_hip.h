@@ -289,8 +289,12 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* model, const uint64_t* seq_ids
 /* Tap for parity tests: hidden state after each layer of the LAST forward, fp32 [layers, T, H]. */
 int ferrum_hip_model_enable_taps(FerrumHipModel* model, int enable);
 int ferrum_hip_model_read_taps(FerrumHipModel* model, float* out_host, int max_tokens);
-/* Per-kernel-class device time of the last decode_steps call (hipEvent based), microseconds. */
 int ferrum_hip_model_stream(FerrumHipModel* model, void** stream);
+/* Bench instrumentation: mean device time (µs, HIP events on the model stream) of one launch of a hot
+ * kernel, cycled over every layer's weights with the index/routing state of the last forward.
+ * which: 0 MoE gate_up(+silu·mul), 1 MoE down, 2 paged decode attention, 3 qkv GEMM, 4 o GEMM, 5 lm_head. */
+int ferrum_hip_model_time_kernel(FerrumHipModel* model, int which, int n_seqs, int max_kv_len, int reps,
+                                 float* avg_us, int* moe_blocks);
 /* Tensor parallel: 128-byte RCCL unique id created on rank 0 and broadcast by the host. */
 int ferrum_hip_tp_unique_id(uint8_t id[128]);
 int ferrum_hip_model_tp_init(FerrumHipModel* model, const uint8_t id[128]);
