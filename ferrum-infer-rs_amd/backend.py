@@ -130,6 +130,14 @@ class ExpertStack(GptqLinear):
                "moe_gemm_phase")
 
 
+    def gemm_phase_inline_align(self, ctx, inp, expert_ids_per_pair, output, prob_m, num_experts, top_k, max_blocks,
+                                fused_silu_mul=False):
+        _check(ctx.lib.ferrum_hip_moe_gemm_phase_inline_align_f16(self.handle, _ptr(inp), _ptr(expert_ids_per_pair),
+                                                                  _ptr(output), prob_m, num_experts, top_k, max_blocks,
+                                                                  int(fused_silu_mul), ctx.stream),
+               "moe_gemm_phase_inline_align")
+
+
 def _np_i32(a):
     import numpy as np
     return np.ascontiguousarray(a, dtype=np.int32)
@@ -157,6 +165,22 @@ class HipBackend:
         import torch
         fn = ctx.lib.ferrum_hip_gemm_f16_f32out if out.dtype == torch.float32 else ctx.lib.ferrum_hip_gemm_f16
         _check(fn(_ptr(a), _ptr(b), _ptr(out), m, n, k, ctx.ws, ctx.stream), "gemm")
+
+    @staticmethod
+    def dense_repack_f16t(ctx, w_rowmajor, n, k):
+        """Load-time transform of a dense fp16 weight [N,K] into MFMA-fragment-major tiles (DenseLinear)."""
+        import torch
+        ctx.lib.ferrum_hip_dense_f16t_bytes.restype = C.c_size_t
+        nbytes = ctx.lib.ferrum_hip_dense_f16t_bytes(n, k)
+        out = torch.empty(nbytes // 2, dtype=torch.float16, device=w_rowmajor.device)
+        _check(ctx.lib.ferrum_hip_dense_repack_f16t(_ptr(w_rowmajor), _ptr(out), n, k, ctx.stream), "dense_repack_f16t")
+        return out
+
+    @staticmethod
+    def gemm_f16t(ctx, a, b_tiled, out, m, n, k):
+        import torch
+        fn = ctx.lib.ferrum_hip_gemm_f16t_f32out if out.dtype == torch.float32 else ctx.lib.ferrum_hip_gemm_f16t
+        _check(fn(_ptr(a), _ptr(b_tiled), _ptr(out), m, n, k, ctx.ws, ctx.stream), "gemm_f16t")
 
     @staticmethod
     def rms_norm(ctx, x, w, eps, out, tokens, dim):
@@ -327,6 +351,24 @@ class HipBackend:
     def moe_combine(ctx, down, weights, out, tokens, top_k, hidden, accumulate=False):
         _check(ctx.lib.ferrum_hip_moe_combine_f16(_ptr(down), _ptr(weights), _ptr(out), tokens, top_k, hidden,
                                                   int(accumulate), ctx.stream), "moe_combine")
+
+
+    # ── fused chains (csrc/fused.hip) ────────────────────────────────────────
+    @staticmethod
+    def fused_add_rms_norm_route(ctx, residual, x, w, eps, norm_out, router_w, num_experts, top_k, norm_topk_prob,
+                                 expert_ids, expert_weights, logits_out, tokens, hidden):
+        """fused_add_rms_norm → router gemm → route_topk_softmax in one launch."""
+        _check(ctx.lib.ferrum_hip_fused_add_rms_norm_route_f16(
+            _ptr(residual), _ptr(x), _ptr(w), C.c_float(eps), _ptr(norm_out), _ptr(router_w), num_experts, top_k,
+            int(norm_topk_prob), _ptr(expert_ids), _ptr(expert_weights), _ptr(logits_out), tokens, hidden, ctx.stream),
+            "fused_add_rms_norm_route")
+
+    @staticmethod
+    def moe_combine_add_rms_norm(ctx, down, weights, residual, next_norm_w, eps, norm_out, tokens, top_k, hidden):
+        """moe_combine → add_inplace → (next layer's) rms_norm in one launch."""
+        _check(ctx.lib.ferrum_hip_moe_combine_add_rms_norm_f16(
+            _ptr(down), _ptr(weights), _ptr(residual), _ptr(next_norm_w), C.c_float(eps), _ptr(norm_out), tokens, top_k,
+            hidden, ctx.stream), "moe_combine_add_rms_norm")
 
 
 class BlockAllocator:

@@ -154,6 +154,21 @@ int ferrum_hip_gemm_f16_f32out(const void* a, const void* b, float* out, int m, 
     return f16_gemm_f32out(CH(a), CH(b), out, m, n, k, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
 }
 
+size_t ferrum_hip_dense_f16t_bytes(int n, int k) { return f16t_elems(n, k) * 2; }
+int ferrum_hip_dense_repack_f16t(const void* w, void* out, int n, int k, void* stream) {
+    FH_REQUIRE(w && out, "dense_repack_f16t: null buffer");
+    return f16t_repack(CH(w), H(out), n, k, ST(stream));
+}
+int ferrum_hip_gemm_f16t(const void* a, const void* b, void* out, int m, int n, int k, FerrumHipWorkspace* ws, void* stream) {
+    FH_REQUIRE(m == 0 || (a && b && out), "gemm_f16t: null buffer");
+    return f16t_gemm(CH(a), CH(b), H(out), m, n, k, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+}
+int ferrum_hip_gemm_f16t_f32out(const void* a, const void* b, float* out, int m, int n, int k, FerrumHipWorkspace* ws,
+                                void* stream) {
+    FH_REQUIRE(m == 0 || (a && b && out), "gemm_f16t: null buffer");
+    return f16t_gemm_f32out(CH(a), CH(b), out, m, n, k, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+}
+
 // ── GPTQ ────────────────────────────────────────────────────────────────────
 static int upload(const void* host, size_t bytes, void** dev) {
     *dev = nullptr;
@@ -306,6 +321,19 @@ int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input,
                        max_blocks, top_k, fused_silu_mul, ST(stream));
 }
 
+int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const void* input,
+                                               const int32_t* expert_ids_per_pair, void* output, int prob_m,
+                                               int num_experts, int top_k, int max_blocks, int fused_silu_mul,
+                                               void* stream) {
+    FH_REQUIRE(stack && input && expert_ids_per_pair && output, "moe_gemm_phase_inline_align: null argument");
+    FH_REQUIRE(top_k >= 1, "moe_gemm_phase_inline_align: top_k=%d", top_k);
+    FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase_inline_align: fused epilogue needs a stack loaded with fuse_gate_up");
+    FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase_inline_align: stack was loaded with fuse_gate_up; plain output is column-permuted");
+    if (prob_m > 1024) { fh::set_error("moe_gemm_phase_inline_align: prob_m=%d > 1024 (use moe_align_block_size + moe_gemm_phase)", prob_m); return FERRUM_HIP_UNSUPPORTED; }
+    return w4_gemm_moe_inline_align(stack->dev, CH(input), H(output), expert_ids_per_pair, num_experts, prob_m, max_blocks,
+                                    top_k, fused_silu_mul, nullptr, nullptr, nullptr, ST(stream));
+}
+
 // ── paged KV ────────────────────────────────────────────────────────────────
 size_t ferrum_hip_paged_pool_bytes(int num_blocks, int kv_heads, int head_dim) {
     return (size_t)num_blocks * kv_heads * 16 * head_dim * 2;
@@ -378,6 +406,23 @@ int ferrum_hip_moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_t
 int ferrum_hip_moe_combine_f16(const void* down, const float* weights, void* out, int tokens, int top_k, int hidden,
                                int accumulate, void* stream) {
     return moe_combine_f16(CH(down), weights, H(out), tokens, top_k, hidden, accumulate, ST(stream));
+}
+
+int ferrum_hip_fused_add_rms_norm_route_f16(void* residual, const void* x, const void* w, float eps, void* norm_out,
+                                            const void* router_w, int num_experts, int top_k, int norm_topk_prob,
+                                            int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens,
+                                            int hidden, void* stream) {
+    FH_REQUIRE(tokens == 0 || (residual && x && w && norm_out), "fused_add_rms_norm_route: null buffer");
+    FH_REQUIRE(num_experts == 0 || (router_w && expert_ids && expert_weights), "fused_add_rms_norm_route: null router buffers");
+    return fused_add_rms_norm_route_f16(H(residual), CH(x), CH(w), eps, H(norm_out), CH(router_w), num_experts, top_k,
+                                        norm_topk_prob, expert_ids, expert_weights, logits_out, tokens, hidden, ST(stream));
+}
+int ferrum_hip_moe_combine_add_rms_norm_f16(const void* down, const float* weights, void* residual,
+                                            const void* next_norm_w, float eps, void* norm_out, int tokens, int top_k,
+                                            int hidden, void* stream) {
+    FH_REQUIRE(tokens == 0 || (down && weights && residual && (!next_norm_w || norm_out)), "moe_combine_add_rms_norm: null buffer");
+    return moe_combine_add_rms_norm_f16(CH(down), weights, H(residual), CH(next_norm_w), eps, H(norm_out), tokens, top_k,
+                                        hidden, ST(stream));
 }
 
 // ── sampling ────────────────────────────────────────────────────────────────

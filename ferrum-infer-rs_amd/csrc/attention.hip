@@ -246,7 +246,8 @@ static int choose_splits(int num_tiles_total, int nkv, int max_kv_len) {
     long wgs = (long)num_tiles_total * nkv;
     int pairs = cdiv(cdiv(max_kv_len, KV_BLOCK), 2);
     int s = 1;
-    while (wgs * s < 512 && pairs / (s * 2) >= 8 && s < 32) s *= 2;
+    // a split costs a second (reduce) launch ≈ 5 µs: only worth it for ≥ 512 keys per split
+    while (wgs * s < 256 && pairs / (s * 2) >= 16 && s < 32) s *= 2;
     return s;
 }
 
@@ -278,6 +279,7 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     a.scale = 1.0f / sqrtf((float)head_dim);
     const int tiles = num_seqs * a.tiles_per_seq;
     int nsplit = choose_splits(tiles, num_kv_heads, max_kv_len);
+    if (const char* e = getenv("FERRUM_HIP_ATTN_SPLITS")) nsplit = atoi(e);   // tuning override (development)
     size_t need = (size_t)tiles * num_kv_heads * nsplit * 16 * (head_dim + 2) * sizeof(float);
     if (nsplit > 1 && (workspace == nullptr || need > workspace_bytes)) nsplit = 1;
     a.nsplit = nsplit;

@@ -1,0 +1,240 @@
+// Launch-count fusions of the MoE decode layer (gfx950).
+//
+// At c ≤ 32 every small op of the layer is latency-bound (≈5 µs per dependent launch on MI355X while
+// the arithmetic is nanoseconds), so the runner merges the chains the reference issues one op at a time
+// (qwen3_moe_forward_unified_layer.rs:380-451):
+//   B  fused_add_rms_norm → router GEMM → route_topk_softmax            → ONE launch per token row
+//      (router weights in the f16t tile layout of w4_gemm.hip, padded to a multiple of 16 experts)
+//   A  moe_combine (weighted_sum) → add_inplace → next layer's rms_norm  → ONE launch per token row
+// The arithmetic per element is unchanged: same rounding points as the unfused HIP ops (residual stored
+// fp16, norm taken from the rounded residual, router logits fp32 from fp16 operands, top-k by k
+// argmax-mask passes with lowest-index ties).
+#include "common.h"
+#include "kernels.h"
+
+namespace fh {
+
+__device__ __forceinline__ float block_sum_256(float v, float* smem) {
+    v = wave_reduce_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    float t = smem[0] + smem[1] + smem[2] + smem[3];
+    __syncthreads();
+    return t;
+}
+
+// ── B: residual += x; norm_out = rms(residual)·w; logits = norm_out·routerᵀ; top-k softmax ────────
+// One 1024-thread workgroup per token.  H ≤ 8192, E ≤ 512, top_k ≤ 64.
+// The router GEMV runs on the matrix cores: the token row is row 0 of a 16-row A operand (other rows
+// zero), router rows are the B operand (16 experts per tile, fetched as 1-KiB fragment loads), and the
+// 16 waves split (expert tile × K slice) so ≥ 8 independent loads per lane are in flight — the naive
+// lane-per-K GEMV was latency-bound at 70 µs per launch.
+__device__ __forceinline__ float block_sum_1024(float v, float* smem) {
+    v = wave_reduce_sum(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; w++) t += smem[w];
+    __syncthreads();
+    return t;
+}
+
+__global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
+    __half* __restrict__ residual, const __half* __restrict__ x, const __half* __restrict__ w, float eps,
+    __half* __restrict__ norm_out, const __half* __restrict__ router_w, int num_experts, int top_k,
+    int norm_topk_prob, int32_t* __restrict__ ids, float* __restrict__ weights, float* __restrict__ logits_out,
+    int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __half* xs = reinterpret_cast<__half*>(smem_raw);                      // normalised row [H]
+    const int tiles = (num_experts + 15) >> 4;
+    const int ksplit = tiles >= 16 ? 1 : 16 / (tiles > 0 ? tiles : 1);
+    float* part = reinterpret_cast<float*>(smem_raw + (size_t)H * 2);      // partial logits [ksplit][tiles·16]
+    __shared__ float red[16];
+    const long row = blockIdx.x;
+    const int nvec = H >> 3;
+    const int i = threadIdx.x;
+    half8 v;
+    float ss = 0.f;
+    if (i < nvec) {
+        half8 xv = *reinterpret_cast<const half8*>(x + row * H + i * 8);
+        half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + (float)xv[j]);
+        *reinterpret_cast<half8*>(residual + row * H + i * 8) = rv;
+        v = rv;
+#pragma unroll
+        for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
+    }
+    const float total = block_sum_1024(ss, red);
+    const float inv = 1.0f / sqrtf(total / (float)H + eps);
+    if (i < nvec) {
+        half8 wv = *reinterpret_cast<const half8*>(w + i * 8);
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[j] * inv * (float)wv[j]);
+        *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+        *reinterpret_cast<half8*>(xs + i * 8) = o;
+    }
+    __syncthreads();
+    if (num_experts <= 0) return;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int ksteps = H >> 5;
+    for (int u = wave; u < tiles * ksplit; u += 16) {
+        const int tile = u / ksplit, ks = u % ksplit;
+        const int s0 = ksteps * ks / ksplit, s1 = ksteps * (ks + 1) / ksplit;
+        // router weights are in f16t tiles: [tile][k-step][64 lanes][8] → contiguous 1-KiB wave loads
+        const __half* wrow = router_w + ((long)tile * ksteps * 64 + lane) * 8;
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        constexpr int U = 16;
+        int s = s0;
+        for (; s + U <= s1; s += U) {
+            half8 bw[U];
+#pragma unroll
+            for (int q = 0; q < U; q++) bw[q] = *reinterpret_cast<const half8*>(wrow + (long)(s + q) * 512);
+#pragma unroll
+            for (int q = 0; q < U; q++) {
+                half8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (b == 0) av = *reinterpret_cast<const half8*>(xs + (s + q) * 32 + 8 * a);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bw[q], acc, 0, 0, 0);
+            }
+        }
+        for (; s < s1; s++) {
+            half8 bwv = *reinterpret_cast<const half8*>(wrow + (long)s * 512);
+            half8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (b == 0) av = *reinterpret_cast<const half8*>(xs + s * 32 + 8 * a);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bwv, acc, 0, 0, 0);
+        }
+        // D[row 4a+r][col b]: the token is row 0 → lanes with a == 0, register 0
+        if (a == 0) part[ks * tiles * 16 + tile * 16 + b] = acc[0];
+    }
+    __syncthreads();
+    // softmax + top-k (ferrum-models/src/moe/router.rs:113-195 semantics).  Selection is by RANK —
+    // rank(e) = #{j : p_j > p_e or (p_j == p_e and j < e)} — computed with broadcast LDS reads, which
+    // gives the same ids as k argmax-mask passes with lowest-index ties but without 8 × 12 dependent
+    // cross-lane shuffles on the critical path.
+    float* prob = part + ksplit * tiles * 16;          // [E]
+    float* sel_w = prob + tiles * 16;                  // [top_k]
+    int* sel_id = reinterpret_cast<int*>(sel_w + 64);  // [top_k]
+    const int t = threadIdx.x;
+    float l = -INFINITY;
+    if (t < num_experts) {
+        l = 0.f;
+        for (int ks = 0; ks < ksplit; ks++) l += part[ks * tiles * 16 + t];
+        if (logits_out) logits_out[row * num_experts + t] = l;
+    }
+    // max and sum over ≤ 512 experts: the first 8 waves hold them, reduce through LDS
+    float mx = wave_reduce_max(l);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+    __syncthreads();
+    float ex = t < num_experts ? expf(l - mx) : 0.f;
+    float sm = wave_reduce_sum(ex);
+    if (lane == 0) red[wave] = sm;
+    __syncthreads();
+    // sequential-ish order (wave partials 0..7) — fp32, within the 1e-6 weight tolerance of router.rs:219-222
+    sm = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    const float p_mine = ex * (1.0f / sm);
+    if (t < tiles * 16) prob[t] = t < num_experts ? p_mine : -INFINITY;
+    __syncthreads();
+    if (t < num_experts) {
+        int rank = 0;
+        for (int j = 0; j < num_experts; j++) {
+            float pj = prob[j];
+            rank += (pj > p_mine || (pj == p_mine && j < t)) ? 1 : 0;
+        }
+        if (rank < top_k) { sel_w[rank] = p_mine; sel_id[rank] = t; }
+    }
+    __syncthreads();
+    if (t < top_k) {
+        float sel_sum = 0.f;
+        for (int k = 0; k < top_k; k++) sel_sum += sel_w[k];          // descending order, as route_into adds them
+        float ww = sel_w[t];
+        if (norm_topk_prob) ww = sel_sum > 0.f ? ww * (1.0f / sel_sum) : 1.0f / (float)top_k;
+        ids[row * top_k + t] = sel_id[t];
+        weights[row * top_k + t] = ww;
+    }
+}
+
+int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half* w, float eps, __half* norm_out,
+                                 const __half* router_w, int num_experts, int top_k, int norm_topk_prob,
+                                 int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
+                                 hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(H % 32 == 0 && H <= 8192, "fused_add_rms_norm_route: hidden=%d must be a multiple of 32, <= 8192", H);
+    FH_REQUIRE(num_experts <= 512 && top_k <= 64 && (num_experts == 0 || (top_k > 0 && top_k <= num_experts)),
+               "fused_add_rms_norm_route: experts=%d top_k=%d", num_experts, top_k);
+    const int tiles = (num_experts + 15) / 16;
+    const int ksplit = tiles >= 16 ? 1 : 16 / std::max(tiles, 1);
+    const size_t lds = (size_t)H * 2 + ((size_t)std::max(tiles, 1) * 16 * (ksplit + 1) + 128) * 4;
+    hipLaunchKernelGGL(add_rmsnorm_route_kernel, dim3(tokens), dim3(1024), lds, s, residual, x, w, eps, norm_out, router_w,
+                       num_experts, top_k, norm_topk_prob, expert_ids, expert_weights, logits_out, H);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// ── A: residual += Σ_k w[b,k]·down[b·K+k];  norm_out = rms(residual)·next_w (optional) ───────────
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
+    const __half* __restrict__ down, const float* __restrict__ weights, __half* __restrict__ residual,
+    const __half* __restrict__ next_w, float eps, __half* __restrict__ norm_out, int top_k, int H) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int nvec = H >> 3;
+    half8 v[CHUNKS];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < top_k; k++) {
+                float wk = weights[row * top_k + k];
+                half8 d = *reinterpret_cast<const half8*>(down + (row * top_k + k) * H + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += wk * (float)d[j];
+            }
+            half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + acc[j]);
+            *reinterpret_cast<half8*>(residual + row * H + i * 8) = rv;
+            v[c] = rv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
+        }
+    }
+    if (!next_w) return;
+    const float total = block_sum_256(ss, red);
+    const float inv = 1.0f / sqrtf(total / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            half8 wv = *reinterpret_cast<const half8*>(next_w + i * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
+            *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+        }
+    }
+}
+
+int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, __half* residual, const __half* next_w,
+                                 float eps, __half* norm_out, int tokens, int top_k, int H, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(H % 8 == 0 && H <= 8 * 256 * 4, "moe_combine_add_rms_norm: hidden=%d must be a multiple of 8, <= 8192", H);
+    const int chunks = cdiv(H / 8, 256);
+#define FH_A(C) hipLaunchKernelGGL((moe_combine_add_rmsnorm_kernel<C>), dim3(tokens), dim3(256), 0, s, down, weights, \
+                                   residual, next_w, eps, norm_out, top_k, H)
+    if (chunks <= 1) FH_A(1); else if (chunks <= 2) FH_A(2); else FH_A(4);
+#undef FH_A
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace fh

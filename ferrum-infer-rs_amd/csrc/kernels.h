@@ -35,10 +35,21 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
                 const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs,
                 int max_blocks, int top_k, int fused_silu, hipStream_t stream);
+int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
+                             int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
+                             int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream);
 int f16_gemm(const __half* x, const __half* w, __half* out, int m, int n, int k, float* workspace,
              size_t workspace_bytes, hipStream_t stream);
 int f16_gemm_f32out(const __half* x, const __half* w, float* out, int m, int n, int k, float* workspace,
                     size_t workspace_bytes, hipStream_t stream);
+
+// fp16 weights in MFMA-fragment-major tiles (w4_gemm.hip "f16t"): [N/16][K/32][64 lanes][8]
+int f16t_repack(const __half* w_rowmajor, __half* out_tiled, int n, int k, hipStream_t stream);
+size_t f16t_elems(int n, int k);
+int f16t_gemm(const __half* x, const __half* wt, __half* out, int m, int n, int k, float* workspace,
+              size_t workspace_bytes, hipStream_t stream);
+int f16t_gemm_f32out(const __half* x, const __half* wt, float* out, int m, int n, int k, float* workspace,
+                     size_t workspace_bytes, hipStream_t stream);
 
 // ── norms / elementwise (norm.hip) ───────────────────────────────────────────
 int rms_norm_f16(const __half* x, const __half* w, float eps, __half* out, int tokens, int dim, hipStream_t s);
@@ -88,6 +99,14 @@ int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, i
                          int sorted_max, hipStream_t s);
 int moe_combine_f16(const __half* down, const float* weights, __half* out, int tokens, int top_k, int hidden,
                     int accumulate_into_residual, hipStream_t s);
+
+// ── launch-count fusions (fused.hip) ─────────────────────────────────────────
+int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half* w, float eps, __half* norm_out,
+                                 const __half* router_w, int num_experts, int top_k, int norm_topk_prob,
+                                 int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
+                                 hipStream_t s);
+int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, __half* residual, const __half* next_w,
+                                 float eps, __half* norm_out, int tokens, int top_k, int H, hipStream_t s);
 
 // ── sampling (sampling.hip) ──────────────────────────────────────────────────
 int argmax_rows_f16(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,

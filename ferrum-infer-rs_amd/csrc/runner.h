@@ -45,7 +45,8 @@ struct FerrumHipModel {
 
     // weights
     __half* embed = nullptr;
-    __half* lm_head = nullptr;     // null → tied
+    __half* lm_head = nullptr;     // row-major upload; null → tied.  Freed once repacked.
+    __half* lm_head_t = nullptr;   // f16t tiles used by the forward
     __half* final_norm = nullptr;
     float* cos_t = nullptr;
     float* sin_t = nullptr;

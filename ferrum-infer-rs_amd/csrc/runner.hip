@@ -246,7 +246,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
             if (p) (void)hipFree(p);
         free_w4(L.qkv); free_w4(L.o); free_w4(L.gate_up); free_w4(L.down); free_w4(L.exp_gate_up); free_w4(L.exp_down);
     }
-    for (void* p : {(void*)m->embed, (void*)m->lm_head, (void*)m->final_norm, (void*)m->cos_t, (void*)m->sin_t,
+    for (void* p : {(void*)m->embed, (void*)m->lm_head, (void*)m->lm_head_t, (void*)m->final_norm, (void*)m->cos_t, (void*)m->sin_t,
                     (void*)m->residual, (void*)m->norm_out, (void*)m->qkv_out, (void*)m->q_out, (void*)m->attn_out,
                     (void*)m->o_out, (void*)m->gate_up_out, (void*)m->act_out, (void*)m->mlp_out,
                     (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->router_logits,
@@ -417,6 +417,26 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         }
     }
     const size_t T = c.max_tokens, S = c.max_seqs, H = c.hidden;
+    // dense fp16 weights that are streamed every step → fragment-major tiles (f16t)
+    {
+        const __half* head = m->lm_head ? m->lm_head : m->embed;     // tied lm_head (llama_family.rs:969-1001)
+        FH_CHECK_HIP(hipMalloc((void**)&m->lm_head_t, f16t_elems(c.vocab, c.hidden) * 2));
+        if (int rc = f16t_repack(head, m->lm_head_t, c.vocab, c.hidden, m->stream)) return rc;
+        if (m->lm_head) {
+            FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+            (void)hipFree(m->lm_head);
+            m->lm_head = nullptr;
+        }
+        for (auto& L : m->layers)
+            if (L.router) {
+                __half* t = nullptr;
+                FH_CHECK_HIP(hipMalloc((void**)&t, f16t_elems(c.num_experts, c.hidden) * 2));
+                if (int rc = f16t_repack(L.router, t, c.num_experts, c.hidden, m->stream)) return rc;
+                FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+                (void)hipFree(L.router);
+                L.router = t;
+            }
+    }
     // KV pools, zero-initialised
     for (auto& L : m->layers) {
         size_t elems = (size_t)c.kv_num_blocks * c.num_kv_heads * kv_tile_elems(c.head_dim);
@@ -621,10 +641,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
     int rc;
 #define RUN(x) if ((rc = (x))) return rc
     RUN(embedding_lookup_f16(m->embed, tokens, m->residual, T, H, s));
+    // the input norm of layer 0; later layers get theirs fused into the previous layer's tail
+    RUN(rms_norm_f16(m->residual, m->layers[0].input_ln, c.rms_eps, m->norm_out, T, H, s));
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
-        RUN(rms_norm_f16(m->residual, L.input_ln, c.rms_eps, m->norm_out, T, H, s));
+        const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
         RUN(w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s));
         RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
                                                             m->cos_t, m->sin_t, m->q_out, L.k_pool, L.v_pool, cu, pos, bt,
@@ -641,22 +663,33 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         }
         RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
         RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
-        RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
         if (c.num_experts > 0) {
             const int E = c.num_experts, K = c.top_k, P = T * K, sorted_max = P + E * 16;
-            RUN(f16_gemm_f32out(m->norm_out, L.router, m->router_logits, T, E, H, m->workspace, m->workspace_bytes, s));
-            RUN(moe_route_topk_softmax_f32(m->router_logits, m->expert_ids, m->expert_w, T, E, K, c.norm_topk_prob, s));
-            RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
+            // residual += o; post-attention norm; router logits; top-k — one launch (fused.hip B)
+            RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
+                                             c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
             // Σ_e ceil(cnt_e/16) ≤ P/16 + min(P, E): the grid covers every block that can exist
             const int max_blocks = std::min(sorted_max / 16, P / 16 + std::min(P, E));
-            RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                            max_blocks, K, 1, s));
-            RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                            max_blocks, 1, 0, s));
-            // combine + residual add in one pass (tp: experts are not sharded — SURVEY.md §8e)
-            RUN(moe_combine_f16(m->moe_down, m->expert_w, m->residual, T, K, H, 1, s));
+            if (P <= 1024) {
+                // decode-sized batch: the grouped GEMMs derive their blocks from the raw expert ids
+                // (gate_up publishes the blocks it derived; down reads them)
+                RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
+                                             m->sorted_ids, m->block_ids, m->total_post_pad, s));
+                RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                max_blocks, 1, 0, s));
+            } else {
+                RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
+                RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                max_blocks, K, 1, s));
+                RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                max_blocks, 1, 0, s));
+            }
+            // weighted combine + residual add + next layer's input norm — one launch (fused.hip A)
+            // (tp: experts are not sharded — SURVEY.md §8e)
+            RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, next_ln, c.rms_eps, m->norm_out, T, K, H, s));
         } else {
             const int I = c.intermediate;
+            RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
             RUN(w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s));
             if (c.activation == 1) {
                 RUN(fused_gelu_tanh_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
@@ -665,7 +698,11 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             }
             RUN(w4_gemm_dense(L.down, m->act_out, m->mlp_out, T, m->workspace, m->workspace_bytes, s));
             RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
-            RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
+            if (next_ln) {
+                RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s));
+            } else {
+                RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
+            }
         }
         if (m->taps_enabled && m->taps) {
             hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)T * H, 256)), dim3(256), 0, s, m->residual,
@@ -678,8 +715,8 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         // qwen3_moe_forward_unified.rs:365-392)
         RUN(gather_rows_f16(m->residual, sampled_idx, m->sampled_hidden, sh.num_sampled, H, s));
         RUN(rms_norm_f16(m->sampled_hidden, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
-        RUN(f16_gemm_f32out(m->sampled_hidden, m->lm_head ? m->lm_head : m->embed, m->logits, sh.num_sampled, c.vocab, H,
-                            m->workspace, m->workspace_bytes, s));
+        RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, c.vocab, H, m->workspace,
+                             m->workspace_bytes, s));
         if (greedy) RUN(argmax_rows_f32(m->logits, m->out_tokens, nullptr, 0, sh.num_sampled, c.vocab, s));
     }
 #undef RUN
@@ -864,27 +901,31 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     FH_CHECK_HIP(hipEventCreate(&e0));
     FH_CHECK_HIP(hipEventCreate(&e1));
     int blocks = 0;
-    if (c.num_experts > 0) {
-        int32_t total = 0;
-        FH_CHECK_HIP(hipMemcpyAsync(&total, m->total_post_pad, 4, hipMemcpyDeviceToHost, s));
+    const int P = T * std::max(c.top_k, 1), E = c.num_experts;
+    if (E > 0) {
+        FH_REQUIRE(P <= 1024, "time_kernel: MoE timing uses the decode (inline-align) path, pairs=%d > 1024", P);
+        std::vector<int32_t> ids(P);
+        FH_CHECK_HIP(hipMemcpyAsync(ids.data(), m->expert_ids, (size_t)P * 4, hipMemcpyDeviceToHost, s));
         FH_CHECK_HIP(hipStreamSynchronize(s));
-        blocks = total / 16;
+        std::vector<int> cnt(E, 0);
+        for (int v : ids) if (v >= 0 && v < E) cnt[v]++;
+        for (int e = 0; e < E; e++) blocks += (cnt[e] + 15) / 16;
     }
     if (moe_blocks) *moe_blocks = blocks;
-    const int P = T * std::max(c.top_k, 1), E = c.num_experts;
     const int max_blocks = E > 0 ? std::min((P + E * 16) / 16, P / 16 + std::min(P, E)) : 0;
     int launches = 0, rc = 0;
     auto one = [&](int li) -> int {
         LayerWeights& L = m->layers[li];
         switch (which) {
-        case 0: return w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, c.top_k, 1, s);
+        case 0: return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
+                                                m->sorted_ids, m->block_ids, m->total_post_pad, s);
         case 1: return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
         case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),
                                                           idx<uint32_t>(m, m->il.kv_lens), T, max_kv_len, c.num_heads, c.num_kv_heads,
                                                           c.head_dim, KV_BLOCK, m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s);
         case 3: return w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s);
         case 4: return w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s);
-        case 5: return f16_gemm_f32out(m->sampled_hidden, m->lm_head ? m->lm_head : m->embed, m->logits, T, c.vocab, H, m->workspace, m->workspace_bytes, s);
+        case 5: return f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, T, c.vocab, H, m->workspace, m->workspace_bytes, s);
         }
         fh::set_error("time_kernel: which=%d", which);
         return FERRUM_HIP_INVALID;

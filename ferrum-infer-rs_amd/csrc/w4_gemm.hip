@@ -134,15 +134,26 @@ __device__ __forceinline__ half2v u32_as_half2(uint32_t u) {
     return c.h;
 }
 
-// Expand one packed dword (8 nibbles) to 8 exact fp16 integers (q − zero).
+// (w & mask) | magic in ONE VALU op.  hipcc emits v_and_b32 + v_or_b32 (two literal-operand VOP2s) for the
+// C expression; v_and_or_b32 is VOP3 (no literals on gfx9-family encodings), so the mask comes from an SGPR
+// and the magic from a VGPR.  Plain VALU → VALU: no hazard padding needed (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_sgpr, uint32_t magic_vgpr) {
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_sgpr), "v"(magic_vgpr));
+    return r;
+}
+
+// Expand one packed dword (8 nibbles) to 8 exact fp16 integers (q − zero): 9 VALU ops.
 // c_lo = −(1024+zero), c_hi = −(64+zero), both broadcast to the two fp16 lanes.
 __device__ __forceinline__ half8 dequant8(uint32_t w, half2v c_lo, half2v c_hi) {
     const half2v sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
+    const uint32_t magic = 0x64006400u;
+    const uint32_t m_lo = __builtin_amdgcn_readfirstlane(0x000F000Fu), m_hi = __builtin_amdgcn_readfirstlane(0x00F000F0u);
     uint32_t w8 = w >> 8;
-    half2v p0 = u32_as_half2((w & 0x000F000Fu) | 0x64006400u) + c_lo;                                      // k0,k1
-    half2v p1 = __builtin_elementwise_fma(u32_as_half2((w & 0x00F000F0u) | 0x64006400u), sixteenth, c_hi);  // k2,k3
-    half2v p2 = u32_as_half2((w8 & 0x000F000Fu) | 0x64006400u) + c_lo;                                     // k4,k5
-    half2v p3 = __builtin_elementwise_fma(u32_as_half2((w8 & 0x00F000F0u) | 0x64006400u), sixteenth, c_hi); // k6,k7
+    half2v p0 = u32_as_half2(and_or(w, m_lo, magic)) + c_lo;                                      // k0,k1
+    half2v p1 = __builtin_elementwise_fma(u32_as_half2(and_or(w, m_hi, magic)), sixteenth, c_hi);  // k2,k3
+    half2v p2 = u32_as_half2(and_or(w8, m_lo, magic)) + c_lo;                                     // k4,k5
+    half2v p3 = __builtin_elementwise_fma(u32_as_half2(and_or(w8, m_hi, magic)), sixteenth, c_hi); // k6,k7
     half8 r;
     r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
     r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
@@ -158,6 +169,7 @@ struct W4Args {
     const __half* x;      // activations [rows, K]
     __half* out;          // fp16 output [rows, ldo] (non-split, or fused-act)
     float* partial;       // fp32 slabs [S][rows_pad][n_pad] when split-K
+    const __half* bias;   // optional [N] (wgsplit kernel)
     int M;                // rows (dense) / number of valid pair ids (MoE: T·k)
     int K, N, G, n64;
     int ldo;              // output row stride (elements)
@@ -169,14 +181,84 @@ struct W4Args {
     int top_k;            // input row = id / top_k
     int rows_pad;         // slab row count
     int n_pad;            // slab column count (= n64·64)
+    // inline align (decode-sized batches): raw per-pair expert ids instead of the three arrays above
+    const int32_t* pair_expert_ids;
+    int num_experts;
+    // when set, the inline align publishes its result so the NEXT grouped GEMM (down) can read it
+    int32_t* pub_sorted_token_ids;
+    int32_t* pub_block_ids;
+    int32_t* pub_total_post_pad;
 };
+
+// Align-block-size computed INSIDE the grouped GEMM (P ≤ 1024 pairs): every workgroup derives its
+// 16-row block (expert + ascending pair ids) from the raw router output with an LDS histogram, a wave
+// scan of the padded counts and a ballot compaction — identical result to moe_align_block_size
+// (ascending pair id inside an expert), but no separate ≈8 µs launch on the decode critical path.
+__device__ __forceinline__ bool inline_align_block(const int32_t* __restrict__ ids, int P, int E, int rb, int* s_cnt,
+                                                   int* s_rows, int* expert_out, int* total_blocks_out) {
+    // one wave per workgroup (MoE kernels launch 64-thread workgroups)
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < E; i += 64) s_cnt[i] = 0;
+    if (lane < 16) s_rows[lane] = P;      // sentinel
+    __syncthreads();
+    for (int p = lane; p < P; p += 64) {
+        int e = ids[p];
+        if (e >= 0 && e < E) atomicAdd(&s_cnt[e], 1);
+    }
+    __syncthreads();
+    // lane owns experts [8·lane, 8·lane+8): blocks per expert, then an exclusive wave scan
+    int nb[8], local = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        int e = lane * 8 + i;
+        nb[i] = e < E ? (s_cnt[e] + 15) >> 4 : 0;
+        local += nb[i];
+    }
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    const int total = __shfl(incl, 63, 64);
+    *total_blocks_out = total;
+    if (rb >= total) return false;
+    const int excl = incl - local;
+    int found = -1;          // (expert << 16) | block-within-expert, on the owning lane
+    if (rb >= excl && rb < incl) {
+        int base = excl;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (rb >= base && rb < base + nb[i]) found = ((lane * 8 + i) << 16) | (rb - base);
+            base += nb[i];
+        }
+    }
+    const unsigned long long owner = __ballot(found >= 0);
+    found = __shfl(found, __ffsll((long long)owner) - 1, 64);
+    const int e_star = found >> 16, j = found & 0xffff;
+    int base = 0;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+        int p = p0 + lane;
+        bool mine = p < P && ids[p] == e_star;
+        unsigned long long bal = __ballot(mine);
+        int r = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (mine && (r >> 4) == j) s_rows[r & 15] = p;
+        base += __popcll(bal);
+    }
+    __syncthreads();
+    *expert_out = e_star;
+    return true;
+}
 
 // MODE: 0 dense, 1 MoE (plain output), 2 MoE gate_up with fused silu·mul epilogue
 template <int MT, bool HAS_ZP, int MODE>
 __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int st = blockIdx.x * 4 + wave;          // 64-column supertile owned by this wave
+    // dense: 4 waves per workgroup, one 64-column supertile each.  MoE: ONE wave per workgroup — the
+    // grouped GEMM is bound by the per-CU fetch rate (≈10 B/clk/CU), so its time is the byte count of the
+    // most loaded CU; wave-granular workgroups balance 64-KiB streams over the 256 CUs to ±1.
+    const int st = MODE == 0 ? blockIdx.x * 4 + wave : blockIdx.x;
     if (st >= p.n64) return;
     const int rb = blockIdx.y;                     // row block (16·MT rows)
     const int z = blockIdx.z;                      // K split
@@ -196,13 +278,28 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
         }
     } else {
         // MoE: one 16-row block of sorted pair ids, all of one expert.
-        const int total = *p.total_post_pad;
-        if (rb * 16 >= total) return;
-        const int e = p.block_ids[rb];
+        __shared__ int s_cnt[512], s_rows[16];
+        int e, id;
+        if (p.pair_expert_ids) {
+            int total_blocks;
+            if (!inline_align_block(p.pair_expert_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
+            id = s_rows[b];
+            if (p.pub_sorted_token_ids && blockIdx.x == 0) {
+                if (threadIdx.x < 16) p.pub_sorted_token_ids[rb * 16 + threadIdx.x] = s_rows[threadIdx.x];
+                if (threadIdx.x == 0) {
+                    p.pub_block_ids[rb] = e;
+                    if (rb == 0) *p.pub_total_post_pad = total_blocks * 16;
+                }
+            }
+        } else {
+            const int total = *p.total_post_pad;
+            if (rb * 16 >= total) return;
+            e = p.block_ids[rb];
+            id = p.sorted_token_ids[rb * 16 + b];
+        }
         qw += (long)e * p.expert_stride_qw;
         sc += (long)e * p.expert_stride_sc;
         if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
-        int id = p.sorted_token_ids[rb * 16 + b];
         row_ok[0] = id < p.M;
         row_out[0] = id;
         row_in[0] = row_ok[0] ? id / p.top_k : 0;
@@ -268,23 +365,33 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
         }
     };
 
+    // sched_barrier(0) pins "issue next group" ABOVE "consume this group": without it hipcc sinks the
+    // loads below the MFMAs (to shorten live ranges) and every group pays its full HBM latency.
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
     if (g0 < g1) {
         issue(0, g0);
+        FH_PIN();
         int g = g0;
         for (; g + 2 <= g1 - 1; g += 2) {   // two groups per trip keeps buffer indices static
             issue(1, g + 1);
+            FH_PIN();
             consume(0);
+            FH_PIN();
             issue(0, g + 2);
+            FH_PIN();
             consume(1);
+            FH_PIN();
         }
         if (g + 1 < g1) {
             issue(1, g + 1);
+            FH_PIN();
             consume(0);
             consume(1);
         } else {
             consume(0);
         }
     }
+#undef FH_PIN
 
     // accumulator map (v_mfma_f32_16x16x32): column = lane&15 → n, row = 4·(lane>>4)+r → token.
     // Lanes exchange nothing: every lane owns token rows 4a..4a+3 of column b.  The A operand
@@ -356,12 +463,145 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, OutT* __
     out[(long)row * ldo + col] = (OutT)s;
 }
 
+
+// ── dense skinny GEMM, K split ACROSS THE WAVES of one workgroup ─────────────────────────────────
+// The small projections of the decode layer (qkv, o) are latency-bound: a slab split-K needs a second
+// launch (≈5 µs) to reduce.  Here the W waves of a workgroup take K-slices of the same NT column
+// tiles and reduce their fp32 accumulators through LDS, so the GEMM is ONE launch with fp16 output.
+template <int MT, int NT, bool HAS_ZP>
+__global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) : 256)) void w4_gemm_wgsplit_kernel(W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    const int W = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int tile0 = blockIdx.x * NT;            // first 16-column tile of this workgroup
+    const int st = tile0 >> 2, nt0 = tile0 & 3;   // NT divides 4 → all tiles in one supertile
+    const int rb = blockIdx.y;
+    constexpr int V = MT * NT * 4;
+
+    const __half* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int r = rb * 16 * MT + mt * 16 + b;
+        xrow[mt] = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + 8 * a;
+    }
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4 + nt0) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp) + ((long)st * p.G) * 16 + b : nullptr;
+
+    float4v acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    const int g0 = (int)((long)p.G * wave / W), g1 = (int)((long)p.G * (wave + 1) / W);
+    u32x4g wq[2][NT];
+    uint2 scv[2], zpv[2];
+    half8 af[2][MT][4];
+    auto issue = [&](int buf, int g) {
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) wq[buf][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[buf] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[buf] = zp_lane[(long)g * 16];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) af[buf][mt][s] = *reinterpret_cast<const half8*>(xrow[mt] + g * 128 + 32 * s);
+    };
+    auto consume = [&](int buf) {
+        // 4 packed fp16 per lane; nt0 is a runtime value → select by shifting, never by indexing
+        const unsigned long long sbits = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
+        const unsigned long long zbits = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
+        auto half_at = [](unsigned long long bits, int i) {
+            union { uint16_t u; _Float16 h; } c;
+            c.u = (uint16_t)(bits >> (16 * i));
+            return c.h;
+        };
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
+            _Float16 zero = HAS_ZP ? half_at(zbits, nt0 + nt) : (_Float16)8.0f;
+            _Float16 clo = (_Float16)(-1024.0f) - zero, chi = (_Float16)(-64.0f) - zero;
+            half2v c_lo = {clo, clo}, c_hi = {chi, chi};
+            float4v tmp[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) tmp[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                half8 bf = dequant8(wq[buf][nt][s], c_lo, c_hi);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[buf][mt][s], bf, tmp[mt], 0, 0, 0);
+            }
+            float s_f = (float)half_at(sbits, nt0 + nt);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[mt][nt][r] += s_f * tmp[mt][r];
+        }
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    if (g0 < g1) {
+        issue(0, g0);
+        FH_PIN();
+        int g = g0;
+        for (; g + 2 <= g1 - 1; g += 2) {
+            issue(1, g + 1);
+            FH_PIN();
+            consume(0);
+            FH_PIN();
+            issue(0, g + 2);
+            FH_PIN();
+            consume(1);
+            FH_PIN();
+        }
+        if (g + 1 < g1) {
+            issue(1, g + 1);
+            FH_PIN();
+            consume(0);
+            consume(1);
+        } else {
+            consume(0);
+        }
+    }
+#undef FH_PIN
+    // cross-wave reduction through LDS: red[wave][v][lane]
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[((wave * V) + (mt * NT + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+    __syncthreads();
+    for (int v = wave; v < V; v += W) {
+        float sum = 0.f;
+        for (int w = 0; w < W; w++) sum += red[(w * V + v) * 64 + lane];
+        const int r = v & 3, nt = (v >> 2) % NT, mt = (v >> 2) / NT;
+        const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+        const int col = (tile0 + nt) * 16 + b;
+        if (row < p.M && col < p.N) {
+            if (p.bias) sum += __half2float(p.bias[col]);
+            p.out[(long)row * p.ldo + col] = __float2half(sum);
+        }
+    }
+}
+
+template <int MT, int NT>
+static int launch_wgsplit(const W4Args& a, bool has_zp, dim3 grid, int W, hipStream_t stream) {
+    size_t lds = (size_t)W * MT * NT * 4 * 64 * sizeof(float);
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_wgsplit_kernel<MT, NT, true>), grid, dim3(W * 64), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_wgsplit_kernel<MT, NT, false>), grid, dim3(W * 64), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 // ─────────────────────────────── host launchers ────────────────────────────
 
 template <int MODE>
 static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_t stream) {
 #define FH_W4_CASE(MTV, ZPV)                                                       \
-    hipLaunchKernelGGL((w4_gemm_kernel<MTV, ZPV, MODE>), grid, dim3(256), 0, stream, a)
+    hipLaunchKernelGGL((w4_gemm_kernel<MTV, ZPV, MODE>), grid, dim3(MODE == 0 ? 256 : 64), 0, stream, a)
     if constexpr (MODE != 0) {
         if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false);
     } else {
@@ -374,38 +614,64 @@ static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_
     return 0;
 }
 
-// Dense y[M,N] = x[M,K]·Wᵀ.  `workspace` holds split-K slabs (w4_workspace_bytes()).
+// Dense y[M,N] = x[M,K]·Wᵀ (+bias).  One launch: K is split across the waves of each workgroup.
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
+    (void)workspace; (void)workspace_bytes;
     if (m <= 0) return 0;
     W4Args a{};
-    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
-    a.x = x; a.out = out; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n;
-    int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
-    int row_blocks = cdiv(m, 16 * mt);
-    int wg_x = cdiv(w.n64, 4);
-    // split K until there are enough wave-tasks to cover the chip (≈8 waves/CU), keeping ≥2
-    // groups per slice; only when the slabs fit the workspace.
-    long tasks = (long)w.n64 * row_blocks;
-    int S = 1;
-    while (tasks * S < 2048 && S * 2 <= w.G / 2) S *= 2;
-    a.rows_pad = row_blocks * 16 * mt;
-    a.n_pad = w.n64 * 64;
-    if (S > 1 && (size_t)S * a.rows_pad * a.n_pad * sizeof(float) > workspace_bytes) S = 1;
-    a.S = S;
-    a.partial = workspace;
-    int rc = launch_w4<0>(a, mt, w.zp != nullptr, dim3(wg_x, row_blocks, S), stream);
-    if (rc) return rc;
-    if (S > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel<__half>, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, S,
-                           m, w.n, a.rows_pad, a.n_pad, w.n);
-        FH_CHECK_LAUNCH();
-    }
-    return 0;
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp; a.bias = w.bias;
+    a.x = x; a.out = out; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n; a.S = 1;
+    const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    const int row_blocks = cdiv(m, 16 * mt);
+    const int n16 = w.n64 * 4;
+    // column tiles per workgroup: as wide as possible (A-fragment reuse) while ≥ ~384 workgroups exist
+    int nt = 4;
+    while (nt > 1 && (long)cdiv(n16, nt) * row_blocks < 384) nt >>= 1;
+    // with ≥ 2 row tiles the activation fragments dominate the load traffic: share each across two
+    // column tiles as long as ≥ 128 workgroups remain (measured: qkv 2048→5120 at T=32 10.4 → 7.2 µs)
+    if (mt >= 2 && nt == 1 && (long)cdiv(n16, 2) * row_blocks >= 128) nt = 2;
+    // waves per workgroup (= K slices): enough waves to cover the chip, ≥ 1 group each, LDS ≤ 128 KiB
+    const long wgs = (long)cdiv(n16, nt) * row_blocks;
+    const int w_cap = mt == 1 ? 16 : (mt == 2 ? (nt == 1 ? 16 : 8) : 4);    // matches the kernel's __launch_bounds__
+    int W = 4;
+    while (wgs * W < 2048 && W * 2 <= std::min(w_cap, w.G) && W * 2 * mt * nt * 4 <= 512) W <<= 1;
+    while (W > w.G && W > 1) W >>= 1;
+    if (const char* e = getenv("FERRUM_HIP_W4_NT")) nt = atoi(e);        // tuning overrides (development)
+    if (const char* e = getenv("FERRUM_HIP_W4_W")) W = atoi(e);
+    dim3 grid(cdiv(n16, nt), row_blocks, 1);
+    const bool zp = w.zp != nullptr;
+#define FH_WG(MTV, NTV) return launch_wgsplit<MTV, NTV>(a, zp, grid, W, stream)
+    if (mt == 1) { if (nt == 4) FH_WG(1, 4); if (nt == 2) FH_WG(1, 2); FH_WG(1, 1); }
+    if (mt == 2) { if (nt == 4) FH_WG(2, 4); if (nt == 2) FH_WG(2, 2); FH_WG(2, 1); }
+    if (nt == 4) FH_WG(4, 4);
+    if (nt == 2) FH_WG(4, 2);
+    FH_WG(4, 1);
+#undef FH_WG
 }
 
 // MoE grouped GEMM over align-block routing arrays (block size 16).
 // out row = pair id, in row = pair id / top_k (vLLM marlin_moe convention, ops.cu:942).
+int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
+                             int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
+                             int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream) {
+    if (num_valid_pairs <= 0 || max_blocks <= 0) return 0;
+    FH_REQUIRE(num_valid_pairs <= 1024 && num_experts <= 512, "inline align: pairs=%d experts=%d out of range", num_valid_pairs, num_experts);
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
+    a.expert_stride_sc = (long)w.n64 * w.G * 16 * 4;
+    a.x = x; a.out = out; a.M = num_valid_pairs; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64;
+    a.ldo = fused_silu ? w.n / 2 : w.n;
+    a.S = 1;
+    a.pair_expert_ids = pair_expert_ids; a.num_experts = num_experts;
+    a.pub_sorted_token_ids = pub_sorted; a.pub_block_ids = pub_block_ids; a.pub_total_post_pad = pub_total;
+    a.top_k = top_k;
+    dim3 grid(w.n64, max_blocks, 1);
+    if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
+    return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
+}
+
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
                 const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs, int max_blocks,
                 int top_k, int fused_silu, hipStream_t stream) {
@@ -419,7 +685,7 @@ int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* 
     a.S = 1;
     a.sorted_token_ids = sorted_token_ids; a.block_ids = block_ids; a.total_post_pad = total_post_pad;
     a.top_k = top_k;
-    dim3 grid(cdiv(w.n64, 4), max_blocks, 1);
+    dim3 grid(w.n64, max_blocks, 1);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
 }
@@ -539,6 +805,150 @@ int f16_gemm(const __half* x, const __half* w, __half* out, int m, int n, int k,
 int f16_gemm_f32out(const __half* x, const __half* w, float* out, int m, int n, int k, float* workspace,
                     size_t workspace_bytes, hipStream_t stream) {
     return f16_gemm_impl<float>(x, w, out, m, n, k, workspace, workspace_bytes, stream);
+}
+
+// ───────────── fp16 weights in MFMA-fragment-major tiles ("f16t") ─────────────
+// Dense fp16 weights that are streamed once per step (lm_head, MoE router) are re-laid at load from
+// row-major [N,K] to [N/16 tiles][K/32 k-steps][64 lanes][8 halves]: lane (a,b) of k-step s holds
+// W[16·tile + b][32s + 8a .. +8], i.e. exactly its B-operand fragment, so every wave load is one
+// contiguous 1-KiB line burst (the row-major form makes each lane of a load touch a different 4-KiB-
+// strided row — 64 separate 16-byte segments per instruction).
+__global__ void f16t_repack_kernel(const __half* __restrict__ w, __half* __restrict__ out, int N, int K) {
+    const long chunk = (long)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte chunk per thread
+    const int ksteps = K >> 5;
+    const long total = (long)((N + 15) >> 4) * ksteps * 64;
+    if (chunk >= total) return;
+    const int lane = (int)(chunk & 63);
+    const long ts = chunk >> 6;
+    const int s = (int)(ts % ksteps);
+    const long tile = ts / ksteps;
+    const int a = lane >> 4, b = lane & 15;
+    const long n = tile * 16 + b;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n < N) v = *reinterpret_cast<const half8*>(w + n * K + 32 * s + 8 * a);
+    *reinterpret_cast<half8*>(out + chunk * 8) = v;
+}
+
+int f16t_repack(const __half* w_rowmajor, __half* out_tiled, int n, int k, hipStream_t stream) {
+    FH_REQUIRE(k % 32 == 0, "f16t repack: K=%d must be a multiple of 32", k);
+    long total = (long)cdiv(n, 16) * (k / 32) * 64;
+    hipLaunchKernelGGL(f16t_repack_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, w_rowmajor, out_tiled, n, k);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+size_t f16t_elems(int n, int k) { return (size_t)cdiv(n, 16) * 16 * k; }
+
+template <int MT, typename OutT>
+__global__ __launch_bounds__(256) void f16t_gemm_kernel(const __half* __restrict__ x, const __half* __restrict__ wt,
+                                                        OutT* __restrict__ out, float* __restrict__ partial, int M, int N,
+                                                        int K, int S, int rows_pad, int n_pad) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int ntile2 = blockIdx.x * 4 + wave;       // pair of 16-column tiles
+    const int n0 = ntile2 * 32;
+    if (n0 >= N) return;
+    const int rb = blockIdx.y, z = blockIdx.z;
+    const int ksteps = K >> 5;
+    const int tiles = (N + 15) >> 4;
+    const int s0 = (int)((long)ksteps * z / S), s1 = (int)((long)ksteps * (z + 1) / S);
+    const __half* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        int r = rb * 16 * MT + mt * 16 + b;
+        xrow[mt] = x + (long)(r < M ? r : M - 1) * K + 8 * a;
+    }
+    const __half* wtile[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        int t = ntile2 * 2 + j;
+        wtile[j] = wt + ((long)(t < tiles ? t : tiles - 1) * ksteps * 64 + lane) * 8;
+    }
+    float4v acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[mt][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    int s = s0;
+    for (; s + U <= s1; s += U) {
+        half8 bw[U][2], ax[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+                bw[u][j] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(wtile[j] + (long)(s + u) * 512));
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) ax[u][mt] = *reinterpret_cast<const half8*>(xrow[mt] + (s + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[u][mt], bw[u][j], acc[mt][j], 0, 0, 0);
+    }
+    for (; s < s1; s++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            half8 bwv = *reinterpret_cast<const half8*>(wtile[j] + (long)s * 512);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                half8 axv = *reinterpret_cast<const half8*>(xrow[mt] + s * 32);
+                acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(axv, bwv, acc[mt][j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                int col = n0 + j * 16 + b;
+                if (S > 1) {
+                    partial[((long)z * rows_pad + row) * n_pad + col] = acc[mt][j][r];
+                } else if (row < M && col < N) {
+                    out[(long)row * N + col] = (OutT)acc[mt][j][r];
+                }
+            }
+        }
+}
+
+template <typename OutT>
+static int f16t_gemm_impl(const __half* x, const __half* wt, OutT* out, int m, int n, int k, float* workspace,
+                          size_t workspace_bytes, hipStream_t stream) {
+    if (m <= 0) return 0;
+    FH_REQUIRE(k % 32 == 0, "f16t_gemm: K=%d must be a multiple of 32", k);
+    int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    int row_blocks = cdiv(m, 16 * mt);
+    int ntile2 = cdiv(n, 32);
+    int ksteps = k / 32;
+    long tasks = (long)ntile2 * row_blocks;
+    int S = 1;
+    while (tasks * S < 2048 && S * 2 <= ksteps / 8) S *= 2;
+    int rows_pad = row_blocks * 16 * mt, n_pad = ntile2 * 32;
+    if (S > 1 && (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes) S = 1;
+    dim3 grid(cdiv(ntile2, 4), row_blocks, S);
+    if (mt == 1) hipLaunchKernelGGL((f16t_gemm_kernel<1, OutT>), grid, dim3(256), 0, stream, x, wt, out, workspace, m, n, k, S, rows_pad, n_pad);
+    else if (mt == 2) hipLaunchKernelGGL((f16t_gemm_kernel<2, OutT>), grid, dim3(256), 0, stream, x, wt, out, workspace, m, n, k, S, rows_pad, n_pad);
+    else hipLaunchKernelGGL((f16t_gemm_kernel<4, OutT>), grid, dim3(256), 0, stream, x, wt, out, workspace, m, n, k, S, rows_pad, n_pad);
+    FH_CHECK_LAUNCH();
+    if (S > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel<OutT>, dim3(cdiv(n, 256), m), dim3(256), 0, stream, workspace, out, S, m, n,
+                           rows_pad, n_pad, n);
+        FH_CHECK_LAUNCH();
+    }
+    return 0;
+}
+int f16t_gemm(const __half* x, const __half* wt, __half* out, int m, int n, int k, float* workspace,
+              size_t workspace_bytes, hipStream_t stream) {
+    return f16t_gemm_impl<__half>(x, wt, out, m, n, k, workspace, workspace_bytes, stream);
+}
+int f16t_gemm_f32out(const __half* x, const __half* wt, float* out, int m, int n, int k, float* workspace,
+                     size_t workspace_bytes, hipStream_t stream) {
+    return f16t_gemm_impl<float>(x, wt, out, m, n, k, workspace, workspace_bytes, stream);
 }
 
 }  // namespace fh

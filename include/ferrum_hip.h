@@ -91,6 +91,17 @@ int ferrum_hip_gemm_f16(const void* a, const void* b, void* out, int m, int n, i
 int ferrum_hip_gemm_f16_f32out(const void* a, const void* b, float* out, int m, int n, int k,
                                FerrumHipWorkspace* ws, void* stream);
 
+/* Dense fp16 weights streamed once per step (lm_head, MoE router) can be re-laid into MFMA-fragment-major
+ * tiles ("f16t": [ceil(N/16)][K/32][64 lanes][8 halves]) so every wave load is one contiguous 1-KiB burst —
+ * the `DenseLinear` load-time transform of this backend (weights are owned by the backend after load,
+ * capabilities.rs:136-193 ownership rule).  K % 32 == 0. */
+size_t ferrum_hip_dense_f16t_bytes(int n, int k);
+int ferrum_hip_dense_repack_f16t(const void* w_rowmajor_dev, void* out_tiled_dev, int n, int k, void* stream);
+int ferrum_hip_gemm_f16t(const void* a, const void* b_tiled, void* out, int m, int n, int k, FerrumHipWorkspace* ws,
+                         void* stream);
+int ferrum_hip_gemm_f16t_f32out(const void* a, const void* b_tiled, float* out, int m, int n, int k,
+                                FerrumHipWorkspace* ws, void* stream);
+
 /* ── GPTQ-INT4 linear: BackendQuantMarlin::load_gptq / load_gptq_stacked (capabilities.rs:136-193;
  *    CPU cpu.rs:2283-2379) and Linear<B>::forward (linear.rs:109-129), MarlinExpertStack::
  *    gemm_phase_vllm (marlin_expert_stack.rs:86).  Weights are handed over ONCE as HOST slices
@@ -119,6 +130,14 @@ int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input,
                                   const int32_t* expert_ids, const int32_t* num_tokens_past_padded, void* output,
                                   int prob_m, int moe_block_size, int top_k, int max_blocks, int fused_silu_mul,
                                   void* stream);
+
+/* Same GEMM with the align-block-size step computed inside the kernel from the raw router output
+ * (expert_ids_per_pair [prob_m] i32; prob_m ≤ 1024, i.e. decode-sized batches): identical blocks and
+ * row order as ferrum_hip_moe_align_block_size, without the separate launch. */
+int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const void* input,
+                                               const int32_t* expert_ids_per_pair, void* output, int prob_m,
+                                               int num_experts, int top_k, int max_blocks, int fused_silu_mul,
+                                               void* stream);
 
 /* ── paged KV: BackendPagedKv (traits.rs:1622-1904).  Block tables and block ids are the
  *    reference's (ferrum-models/src/common/paged_pool.rs); the bytes inside a block use the native
@@ -169,6 +188,19 @@ int ferrum_hip_moe_align_block_size(const int32_t* expert_ids_per_pair, int32_t*
 /* out[b] = Σ_k weights[b,k]·down[b·top_k+k]; accumulate != 0 adds into out (fused residual add). */
 int ferrum_hip_moe_combine_f16(const void* down, const float* weights, void* out, int tokens, int top_k,
                                int hidden, int accumulate, void* stream);
+
+/* Fused forms of op chains the reference issues back to back (qwen3_moe_forward_unified_layer.rs:380-451);
+ * same per-element arithmetic as the unfused entry points, one launch each:
+ *   fused_add_rms_norm + router gemm + route_topk_softmax  (router_w_tiled: [E,H] in the f16t layout from
+ *     ferrum_hip_dense_repack_f16t; logits_out optional fp32 [T,E])
+ *   moe_combine + add_inplace (+ the NEXT layer's rms_norm when next_norm_w != NULL) */
+int ferrum_hip_fused_add_rms_norm_route_f16(void* residual, const void* x, const void* w, float eps, void* norm_out,
+                                            const void* router_w_tiled, int num_experts, int top_k, int norm_topk_prob,
+                                            int32_t* expert_ids, float* expert_weights, float* logits_out,
+                                            int tokens, int hidden, void* stream);
+int ferrum_hip_moe_combine_add_rms_norm_f16(const void* down, const float* weights, void* residual,
+                                            const void* next_norm_w, float eps, void* norm_out, int tokens,
+                                            int top_k, int hidden, void* stream);
 
 /* ── device sampling: Backend::argmax_rows_f16[_masked|_sparse_repetition_penalty]
  *    (traits.rs:1534-1591).  First maximum wins.  valid_token_mask may be NULL. ───────────────── */

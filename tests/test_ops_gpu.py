@@ -167,6 +167,12 @@ def test_dense_gemm(env, m, n, k, f32out):
     B.gemm(ctx, dev16(torch, a), dev16(torch, b), out, m, n, k)
     ref = O.gemm(a, b, m, n, k)
     assert nmse(ref, host(out)) < (1e-10 if f32out else NMSE_FP16_TOL)
+    # same product through the load-time fragment-major layout (lm_head / router path)
+    bt = B.dense_repack_f16t(ctx, dev16(torch, b), n, k)
+    out2 = torch.zeros_like(out)
+    B.gemm_f16t(ctx, dev16(torch, a), bt, out2, m, n, k)
+    ctx.sync()
+    assert nmse(ref, host(out2)) < (1e-10 if f32out else NMSE_FP16_TOL)
 
 
 # ── paged KV write / read ────────────────────────────────────────────────────
@@ -470,6 +476,64 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
         B.moe_combine(ctx, down, wd, out, tokens, K, H)
         ctx.sync()
         assert nmse(ref, host(out)) < 3e-6, fused            # three fp16 roundings (act, down, out)
+        if fused:
+            # align computed inside the GEMM from the raw expert ids: bit-identical outputs
+            act2 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
+            down2 = torch.zeros(P, H, dtype=torch.float16, device="cuda")
+            stack.gemm_phase_inline_align(ctx, xd, ids_d, act2, P, E, K, max_blocks, fused_silu_mul=True)
+            down_stack.gemm_phase_inline_align(ctx, act2, ids_d, down2, P, E, 1, max_blocks)
+            ctx.sync()
+            assert torch.equal(act, act2) and torch.equal(down, down2)
+
+
+@pytest.mark.parametrize("tokens,H,E,K", [(1, 2048, 128, 8), (32, 2048, 128, 8), (5, 1024, 64, 4), (3, 4096, 16, 2)])
+def test_fused_add_rms_norm_route_equals_op_chain(env, tokens, H, E, K):
+    # fused.hip B ≡ fused_add_rms_norm → gemm(router) → route_topk_softmax, each as the oracle defines it
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens + H + E)
+    r, x = f16r(rng.standard_normal((tokens, H)) * 2), f16r(rng.standard_normal((tokens, H)))
+    w = f16r(1 + 0.1 * rng.standard_normal(H))
+    rw = f16r(rng.standard_normal((E, H)) * 0.05)
+    rd, nd = dev16(torch, r), torch.empty(tokens, H, dtype=torch.float16, device="cuda")
+    ids = torch.empty(tokens, K, dtype=torch.int32, device="cuda")
+    wt = torch.empty(tokens, K, dtype=torch.float32, device="cuda")
+    lg = torch.empty(tokens, E, dtype=torch.float32, device="cuda")
+    B.fused_add_rms_norm_route(ctx, rd, dev16(torch, x), dev16(torch, w), 1e-6, nd,
+                               B.dense_repack_f16t(ctx, dev16(torch, rw), E, H), E, K, True, ids, wt, lg, tokens, H)
+    ctx.sync()
+    r_ref, _ = O.fused_add_rms_norm(r, x, w, 1e-6)
+    assert nmse(r_ref, host(rd)) < NMSE_FP16_TOL
+    n_ref = O.rms_norm(host(rd), w, 1e-6)                                  # norm of the fp16-rounded residual
+    assert nmse(n_ref, host(nd)) < NMSE_FP16_TOL
+    logits_ref = O.gemm(host(nd), rw, tokens, E, H)                        # router sees the fp16 norm_out
+    assert nmse(logits_ref, lg.cpu().numpy()) < 1e-10
+    rid, rwt = O.route_topk(lg.cpu().numpy(), E, K, True)                  # routing of the device logits: bit-exact ids
+    assert np.array_equal(ids.cpu().numpy().astype(np.uint32), rid)
+    assert np.max(np.abs(wt.cpu().numpy() - rwt)) < 1e-6
+
+
+@pytest.mark.parametrize("tokens,H,K,with_norm", [(1, 2048, 8, True), (32, 2048, 8, True), (7, 1024, 2, False)])
+def test_moe_combine_add_rms_norm_equals_op_chain(env, tokens, H, K, with_norm):
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens * H + K)
+    down = f16r(rng.standard_normal((tokens * K, H)))
+    wts = rng.random((tokens, K)).astype(np.float32)
+    wts /= wts.sum(axis=1, keepdims=True)
+    r = f16r(rng.standard_normal((tokens, H)))
+    nw = f16r(1 + 0.1 * rng.standard_normal(H))
+    rd, nd = dev16(torch, r), torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+    B.moe_combine_add_rms_norm(ctx, dev16(torch, down), torch.from_numpy(wts).cuda(), rd,
+                               dev16(torch, nw) if with_norm else None, 1e-6, nd, tokens, K, H)
+    ctx.sync()
+    comb = np.zeros((tokens, H), np.float32)
+    for b in range(tokens):
+        for k in range(K):
+            comb[b] += wts[b, k] * down[b * K + k]                         # moe_forward_cpu order (dispatch.rs:2277-2283)
+    assert nmse(r + comb, host(rd)) < NMSE_FP16_TOL
+    if with_norm:
+        assert nmse(O.rms_norm(host(rd), nw, 1e-6), host(nd)) < NMSE_FP16_TOL
+    else:
+        assert not host(nd).any()
 
 
 # ── sampling ─────────────────────────────────────────────────────────────────

@@ -1,0 +1,68 @@
+// Development micro-benchmark: HBM read ceilings for the access patterns of the INT4 grouped GEMM.
+// hipcc --offload-arch=gfx950 -O3 tools/membw.hip -o /tmp/membw && /tmp/membw
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1);} } while (0)
+
+// each wave streams `bytes_per_wave` contiguous bytes, U loads (1 KiB each) in flight
+template <int U, bool NT>
+__global__ void stream_waves(const u32x4* __restrict__ src, unsigned* __restrict__ sink, long bytes_per_wave, long nwaves) {
+    long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    int lane = threadIdx.x & 63;
+    if (wave >= nwaves) return;
+    const u32x4* p = src + wave * (bytes_per_wave / 16) + lane;
+    long iters = bytes_per_wave / 1024;
+    u32x4 acc = {0, 0, 0, 0};
+    for (long i = 0; i < iters; i += U) {
+        u32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = NT ? __builtin_nontemporal_load(p + (i + u) * 64) : p[(i + u) * 64];
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= v[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
+}
+
+template <typename F> float timeit(F f, int reps) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; i++) f();
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms * 1000.f / reps;
+}
+
+int main() {
+    const long total = 4L << 30;            // 4 GiB pool, rotate through it so nothing stays in the 256 MiB cache
+    u32x4* buf; unsigned* sink;
+    CK(hipMalloc(&buf, total)); CK(hipMalloc(&sink, 4));
+    CK(hipMemset(buf, 1, total));
+    long region = 185L << 20;                // one "launch" reads 185 MB like the MoE gate_up GEMM
+    int nreg = (int)(total / region);
+    int rot = 0;
+    auto run = [&](auto kern, long bytes_per_wave, int wg_threads, const char* name) {
+        long nwaves = region / bytes_per_wave;
+        long threads = nwaves * 64;
+        dim3 grid((threads + wg_threads - 1) / wg_threads), block(wg_threads);
+        float us = timeit([&]() { const u32x4* src = (const u32x4*)((const char*)buf + (long)(rot++ % nreg) * region);
+                                  hipLaunchKernelGGL(kern, grid, block, 0, 0, src, sink, bytes_per_wave, nwaves); }, 40);
+        printf("%-44s waves=%6ld wg=%4d : %7.2f us  %6.2f TB/s\n", name, nwaves, wg_threads, us, region / us / 1e6);
+    };
+    run(stream_waves<4, true>, 64 << 10, 64, "64KB/wave U=4 nt wg64");
+    run(stream_waves<4, false>, 64 << 10, 64, "64KB/wave U=4 plain wg64");
+    run(stream_waves<8, true>, 64 << 10, 64, "64KB/wave U=8 nt wg64");
+    run(stream_waves<8, true>, 64 << 10, 256, "64KB/wave U=8 nt wg256");
+    run(stream_waves<16, true>, 64 << 10, 64, "64KB/wave U=16 nt wg64");
+    run(stream_waves<8, true>, 16 << 10, 256, "16KB/wave U=8 nt wg256");
+    run(stream_waves<8, true>, 32 << 10, 256, "32KB/wave U=8 nt wg256");
+    run(stream_waves<16, true>, 16 << 10, 256, "16KB/wave U=16 nt wg256");
+    run(stream_waves<8, false>, 16 << 10, 256, "16KB/wave U=8 plain wg256");
+    run(stream_waves<4, true>, 8 << 10, 256, "8KB/wave U=4 nt wg256");
+    run(stream_waves<8, true>, 8 << 10, 256, "8KB/wave U=8 nt wg256");
+    run(stream_waves<8, true>, 256 << 10, 64, "256KB/wave U=8 nt wg64");
+    return 0;
+}
