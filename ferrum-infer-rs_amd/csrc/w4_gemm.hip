@@ -10,9 +10,10 @@
 //    fully coalesced) fetches a 16-column × 128-row (= one quant group) tile whose per-lane dwords
 //    ARE the B-operand fragments of four v_mfma_f32_16x16x32_f16 k-steps.
 //  * weights go HBM → VGPR directly (no LDS round trip: each weight byte is used once);
-//    nibbles are expanded to exact fp16 integers (q − zero) with the 0x6400 magic-number trick
-//    (9 VALU per 8 weights) and the group scale is applied to the fp32 MFMA partial sum, so the
-//    only rounding is fp32 accumulation.
+//    nibbles are expanded to exact fp16 integers with the 0x6400 magic-number trick at 5 VALU per
+//    8 weights (the kernel is VALU-issue-bound, not HBM-bound, above that); the 1024/zero-point
+//    offsets are removed by four extra MFMAs per group instead of per-weight subtracts, and the group
+//    scale is applied to the fp32 MFMA chain result, so the only rounding is fp32 accumulation.
 //  * activations are the A operand (rows = tokens, padded to 16); a wave owns a 64-column
 //    "supertile" so every A fragment feeds four MFMAs.
 //  * split-K writes fp32 slabs that a small epilogue kernel sums in fixed order (deterministic).
@@ -22,18 +23,19 @@
 namespace fh {
 
 // ───────────────────────────── repacked layout ─────────────────────────────
-// qw : u32  [n64][G][4 nt][64 lanes][4 ksteps]          (G = K/128, n64 = ceil(N/64))
-//      lane l=(a=l>>4, b=l&15); dword s holds k = g·128 + 32s + 8a + {0..7} for column
-//      n = st·64 + nt·16 + b, nibble order [k0,k2,k4,k6,k1,k3,k5,k7] (cheap pair extraction).
+// qw : u32  [n64][G][4 nt][64 lanes][4 dwords]          (G = K/128, n64 = ceil(N/64))
+//      lane l=(a=l>>4, b=l&15), column n = st·64 + nt·16 + b.  Dwords come in pairs: (d0,d1) carry
+//      k-steps 0 ("lo") and 1 ("hi") of the group, (d2,d3) k-steps 2 and 3.  Element j (0..7) of k-step s
+//      is k = g·128 + 32s + 8a + j.  Inside dword d_{2p+h} (h = j>>2, jj = j&3) the LO k-step sits in
+//      nibbles {0,4,2,6}[jj] and the HI k-step in nibbles {1,5,3,7}[jj]: a lo nibble masked in place is
+//      the fp16 1024+q, a hi nibble masked in place is 1024+16q — 5 VALU ops expand a dword (see below).
 // sc : f16  [n64][G][16 b][4 nt]                         group scale of column st·64+nt·16+b
 // zp : f16  [n64][G][16 b][4 nt]  (only when asymmetric)  value (z+1) as fp16
 
-static inline uint32_t permute_nibbles(const uint8_t q[8]) {
-    // output nibble i ← k index order [0,2,4,6,1,3,5,7]
-    static const int order[8] = {0, 2, 4, 6, 1, 3, 5, 7};
-    uint32_t w = 0;
-    for (int i = 0; i < 8; i++) w |= (uint32_t)(q[order[i]] & 0xF) << (4 * i);
-    return w;
+// nibble slot of (hi k-step?, jj) inside a dword
+static inline int nibble_slot(int hi, int jj) {
+    static const int lo_slots[4] = {0, 4, 2, 6}, hi_slots[4] = {1, 5, 3, 7};
+    return hi ? hi_slots[jj] : lo_slots[jj];
 }
 
 static inline uint16_t f32_to_f16_bits(float f) {
@@ -96,16 +98,18 @@ int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* q
                     int a = lane >> 4, b = lane & 15;
                     int np = st * 64 + nt * 16 + b;          // packed column
                     int col = np < n ? (col_perm ? col_perm[np] : np) : -1;
-                    for (int s = 0; s < 4; s++) {
-                        uint8_t q[8];
+                    uint32_t dw[4] = {0, 0, 0, 0};
+                    for (int s = 0; s < 4; s++)
                         for (int j = 0; j < 8; j++) {
                             int kk = src_k(g * 128 + 32 * s + 8 * a + j);
                             // padded columns decode to q − zero = 0 (zero point 8 when symmetric)
-                            q[j] = col < 0 ? 8
-                                           : (uint8_t)(((uint32_t)qweight[(long)(kk / 8) * n + col] >> (4 * (kk % 8))) & 0xF);
+                            uint32_t q = col < 0 ? 8u
+                                                 : (((uint32_t)qweight[(long)(kk / 8) * n + col] >> (4 * (kk % 8))) & 0xFu);
+                            int d = 2 * (s >> 1) + (j >> 2);
+                            dw[d] |= q << (4 * nibble_slot(s & 1, j & 3));
                         }
-                        out->qw[((((size_t)st * G + g) * 4 + nt) * 64 + lane) * 4 + s] = permute_nibbles(q);
-                    }
+                    for (int d = 0; d < 4; d++)
+                        out->qw[((((size_t)st * G + g) * 4 + nt) * 64 + lane) * 4 + d] = dw[d];
                 }
             for (int b = 0; b < 16; b++)
                 for (int nt = 0; nt < 4; nt++) {
@@ -134,30 +138,105 @@ __device__ __forceinline__ half2v u32_as_half2(uint32_t u) {
     return c.h;
 }
 
-// (w & mask) | magic in ONE VALU op.  hipcc emits v_and_b32 + v_or_b32 (two literal-operand VOP2s) for the
-// C expression; v_and_or_b32 is VOP3 (no literals on gfx9-family encodings), so the mask comes from an SGPR
-// and the magic from a VGPR.  Plain VALU → VALU: no hazard padding needed (cdna_hip_programming.md §5.7).
-__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask_sgpr, uint32_t magic_vgpr) {
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask_sgpr), "v"(magic_vgpr));
-    return r;
+// (w & mask) | magic in ONE VALU op (v_and_or_b32).  With literal constants hipcc emits v_and_b32 +
+// v_or_b32 (VOP3 has no literal operands on gfx9-family encodings), so the constants are made opaque
+// register values (mask in an SGPR, magic in a VGPR) and the plain C expression then selects
+// v_and_or_b32.  No inline-asm instruction is involved, so the compiler still tracks the
+// VALU-write → MFMA-read hazard itself (an asm v_and_or feeding an MFMA directly read stale operands).
+__device__ __forceinline__ uint32_t opaque_sgpr(uint32_t v) {
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm volatile("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t opaque_vgpr(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t and_or(uint32_t w, uint32_t mask, uint32_t magic) { return (w & mask) | magic; }
+
+__device__ __forceinline__ half8 pack_half8(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3) {
+    union { uint32_t u[4]; half8 h; } c;
+    c.u[0] = r0; c.u[1] = r1; c.u[2] = r2; c.u[3] = r3;
+    return c.h;
+}
+__device__ __forceinline__ half8 splat_half8(float v) {
+    _Float16 h = (_Float16)v;
+    return (half8){h, h, h, h, h, h, h, h};
 }
 
-// Expand one packed dword (8 nibbles) to 8 exact fp16 integers (q − zero): 9 VALU ops.
-// c_lo = −(1024+zero), c_hi = −(64+zero), both broadcast to the two fp16 lanes.
-__device__ __forceinline__ half8 dequant8(uint32_t w, half2v c_lo, half2v c_hi) {
-    const half2v sixteenth = {(_Float16)0.0625f, (_Float16)0.0625f};
-    const uint32_t magic = 0x64006400u;
-    const uint32_t m_lo = __builtin_amdgcn_readfirstlane(0x000F000Fu), m_hi = __builtin_amdgcn_readfirstlane(0x00F000F0u);
-    uint32_t w8 = w >> 8;
-    half2v p0 = u32_as_half2(and_or(w, m_lo, magic)) + c_lo;                                      // k0,k1
-    half2v p1 = __builtin_elementwise_fma(u32_as_half2(and_or(w, m_hi, magic)), sixteenth, c_hi);  // k2,k3
-    half2v p2 = u32_as_half2(and_or(w8, m_lo, magic)) + c_lo;                                     // k4,k5
-    half2v p3 = __builtin_elementwise_fma(u32_as_half2(and_or(w8, m_hi, magic)), sixteenth, c_hi); // k6,k7
-    half8 r;
-    r[0] = p0[0]; r[1] = p0[1]; r[2] = p1[0]; r[3] = p1[1];
-    r[4] = p2[0]; r[5] = p2[1]; r[6] = p3[0]; r[7] = p3[1];
-    return r;
+// One quant group (128 k) of NT column tiles × MT row tiles.
+//   wq[nt]  : the lane's 4 packed dwords of tile nt          af[mt][s] : activation fragments, k-steps 0..3
+//   acc     : fp32 accumulators                              sbits/zbits: 4 packed fp16 scales / zeros
+// Nibble expansion costs 5 VALU per dword (1 shift + 4 v_and_or): a lo nibble masked in place is the exact
+// fp16 1024+q, a hi nibble is 1024+16q.  The hi k-steps use activations pre-multiplied by 1/16 (exact in
+// fp16), so  Σ_lo (1024+q)x + Σ_hi (1024+16q)(x/16) = Σ q·x + 1024·S_lo + 64·S_hi.  The offset (and the
+// zero point: −zero·(S_lo+S_hi)) is removed with NO per-weight work: four extra MFMAs per group against a
+// constant B operand produce −(1024+zero)·S_lo − (64+zero)·S_hi per token row, and that is used as the
+// starting accumulator of every tile's MFMA chain.  The group scale multiplies the fp32 chain result.
+template <int MT, int NT, bool HAS_ZP, typename WQ>
+__device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned long long sbits,
+                                                 unsigned long long zbits, int nt0, half8 (&af)[MT][4],
+                                                 float4v (&acc)[MT][NT]) {
+    const uint32_t magic = opaque_vgpr(0x64006400u);
+    const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
+    const half8 sixteenth = splat_half8(0.0625f);
+    auto half_at = [](unsigned long long bits, int i) {
+        union { uint16_t u; _Float16 h; } c;
+        c.u = (uint16_t)(bits >> (16 * i));
+        return c.h;
+    };
+    float4v neg_off[MT], s_sum[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        af[mt][1] = af[mt][1] * sixteenth;
+        af[mt][3] = af[mt][3] * sixteenth;
+        // symmetric: −1032·S_lo − 72·S_hi  (72·16 = 1152 against x/16);  asymmetric: −1024·S_lo − 64·S_hi
+        const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -1024.0f : -1152.0f);
+        float4v t = {0.f, 0.f, 0.f, 0.f};
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0], b_lo, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][1], b_hi, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2], b_lo, t, 0, 0, 0);
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][3], b_hi, t, 0, 0, 0);
+        neg_off[mt] = t;
+        if (HAS_ZP) {   // Σ x over the group (hi k-steps hold x/16 → ×16)
+            const half8 o_lo = splat_half8(1.0f), o_hi = splat_half8(16.0f);
+            float4v u = {0.f, 0.f, 0.f, 0.f};
+            u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0], o_lo, u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][1], o_hi, u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2], o_lo, u, 0, 0, 0);
+            u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][3], o_hi, u, 0, 0, 0);
+            s_sum[mt] = u;
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        float4v tmp[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) tmp[mt] = neg_off[mt];
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const uint32_t d0 = wq[nt][2 * pr], d1 = wq[nt][2 * pr + 1];
+            const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
+            const half8 lo = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic),
+                                        and_or(d1s, m_lo, magic));
+            const half8 hi = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic),
+                                        and_or(d1s, m_hi, magic));
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr], lo, tmp[mt], 0, 0, 0);
+                tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr + 1], hi, tmp[mt], 0, 0, 0);
+            }
+        }
+        const float s_f = (float)half_at(sbits, nt0 + nt);
+        const float z_f = HAS_ZP ? (float)half_at(zbits, nt0 + nt) : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = HAS_ZP ? tmp[mt][r] - z_f * s_sum[mt][r] : tmp[mt][r];
+                acc[mt][nt][r] += s_f * v;
+            }
+    }
 }
 
 struct W4Args {
@@ -338,31 +417,9 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
                 af[buf][mt][s] = *reinterpret_cast<const half8*>(xrow[mt] + g * 128 + 32 * s);
     };
     auto consume = [&](int buf) {
-        union { uint2 u; _Float16 h[4]; } su, zu;
-        su.u = scv[buf];
-        if (HAS_ZP) zu.u = zpv[buf];
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) {
-            _Float16 zero = HAS_ZP ? zu.h[nt] : (_Float16)8.0f;
-            _Float16 clo = (_Float16)(-1024.0f) - zero, chi = (_Float16)(-64.0f) - zero;
-            half2v c_lo = {clo, clo}, c_hi = {chi, chi};
-            uint32_t words[4] = {wq[buf][nt][0], wq[buf][nt][1], wq[buf][nt][2], wq[buf][nt][3]};
-            float4v tmp[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) tmp[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                half8 bf = dequant8(words[s], c_lo, c_hi);
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-                    tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[buf][mt][s], bf, tmp[mt], 0, 0, 0);
-            }
-            float s_f = (float)su.h[nt];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[mt][nt][r] += s_f * tmp[mt][r];
-        }
+        const unsigned long long sb = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
+        w4_consume_group<MT, 4, HAS_ZP>(wq[buf], sb, zb, 0, af[buf], acc);
     };
 
     // sched_barrier(0) pins "issue next group" ABOVE "consume this group": without it hipcc sinks the
@@ -511,35 +568,9 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) 
             for (int s = 0; s < 4; s++) af[buf][mt][s] = *reinterpret_cast<const half8*>(xrow[mt] + g * 128 + 32 * s);
     };
     auto consume = [&](int buf) {
-        // 4 packed fp16 per lane; nt0 is a runtime value → select by shifting, never by indexing
-        const unsigned long long sbits = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
-        const unsigned long long zbits = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
-        auto half_at = [](unsigned long long bits, int i) {
-            union { uint16_t u; _Float16 h; } c;
-            c.u = (uint16_t)(bits >> (16 * i));
-            return c.h;
-        };
-#pragma unroll
-        for (int nt = 0; nt < NT; nt++) {
-            _Float16 zero = HAS_ZP ? half_at(zbits, nt0 + nt) : (_Float16)8.0f;
-            _Float16 clo = (_Float16)(-1024.0f) - zero, chi = (_Float16)(-64.0f) - zero;
-            half2v c_lo = {clo, clo}, c_hi = {chi, chi};
-            float4v tmp[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) tmp[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                half8 bf = dequant8(wq[buf][nt][s], c_lo, c_hi);
-#pragma unroll
-                for (int mt = 0; mt < MT; mt++)
-                    tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[buf][mt][s], bf, tmp[mt], 0, 0, 0);
-            }
-            float s_f = (float)half_at(sbits, nt0 + nt);
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[mt][nt][r] += s_f * tmp[mt][r];
-        }
+        const unsigned long long sb = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
+        w4_consume_group<MT, NT, HAS_ZP>(wq[buf], sb, zb, nt0, af[buf], acc);
     };
 #define FH_PIN() __builtin_amdgcn_sched_barrier(0)
     if (g0 < g1) {
