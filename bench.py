@@ -138,7 +138,7 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:               # launched by torch.distributed.run (any world size)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -157,10 +157,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    prefill_ms = {}
+
     def run_case(model, conc, steps, warm, first_id):
         rng = np.random.default_rng(9271 + rank)               # seed of the reference's bench-serve command
         prompts = [rng.integers(256, cfg["vocab"], size=PL).astype(np.uint32) for _ in range(conc)]
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
         first = prefill(model, prompts, first_id, chunk)
+        prefill_ms[conc] = (time.perf_counter() - tp0) * 1e3   # all `conc` prompts prefilled (≤ 2048 tokens per forward)
         ids = list(range(first_id, first_id + conc))
         warm_toks = model.decode_steps(ids, first, warm) if warm > 0 else None
         nxt = warm_toks[-1] if warm > 0 else first
@@ -235,6 +240,7 @@ def main():
                 model.release(5000 + i)
             extra["sweep_tok_s"] = sweep
             extra["ttft_ms_p50_c1"] = round(float(np.median(ttft)), 2)
+            extra["prefill_ms_all_prompts"] = {str(k): round(v, 2) for k, v in sorted(prefill_ms.items())}
         if not args.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline(cfg)
 

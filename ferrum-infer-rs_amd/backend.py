@@ -138,6 +138,15 @@ class ExpertStack(GptqLinear):
                "moe_gemm_phase_inline_align")
 
 
+    def gemm_phase_merge_route(self, ctx, inp, cand, stats, output, tokens, num_parts, top_k, norm_topk_prob, num_experts,
+                               max_blocks, expert_ids_out, expert_weights_out, sorted_out, block_ids_out, total_out,
+                               fused_silu_mul=False):
+        _check(ctx.lib.ferrum_hip_moe_gemm_phase_merge_route_f16(
+            self.handle, _ptr(inp), _ptr(cand), _ptr(stats), _ptr(output), tokens, num_parts, top_k, int(norm_topk_prob),
+            num_experts, max_blocks, int(fused_silu_mul), _ptr(expert_ids_out), _ptr(expert_weights_out), _ptr(sorted_out),
+            _ptr(block_ids_out), _ptr(total_out), ctx.stream), "moe_gemm_phase_merge_route")
+
+
 def _np_i32(a):
     import numpy as np
     return np.ascontiguousarray(a, dtype=np.int32)
@@ -362,6 +371,15 @@ class HipBackend:
             _ptr(residual), _ptr(x), _ptr(w), C.c_float(eps), _ptr(norm_out), _ptr(router_w), num_experts, top_k,
             int(norm_topk_prob), _ptr(expert_ids), _ptr(expert_weights), _ptr(logits_out), tokens, hidden, ctx.stream),
             "fused_add_rms_norm_route")
+
+    @staticmethod
+    def fused_add_rms_norm_route_parts(ctx, residual_in, residual_out, x, x_slabs, num_slabs, slab_stride, ld_slab, w, eps,
+                                       norm_out, router_w_tiled, num_experts, top_k, num_parts, cand, stats, logits_out,
+                                       tokens, hidden):
+        _check(ctx.lib.ferrum_hip_fused_add_rms_norm_route_parts_f16(
+            _ptr(residual_in), _ptr(residual_out), _ptr(x), _ptr(x_slabs), num_slabs, C.c_long(slab_stride), ld_slab, _ptr(w),
+            C.c_float(eps), _ptr(norm_out), _ptr(router_w_tiled), num_experts, top_k, num_parts, _ptr(cand), _ptr(stats),
+            _ptr(logits_out), tokens, hidden, ctx.stream), "fused_add_rms_norm_route_parts")
 
     @staticmethod
     def moe_combine_add_rms_norm(ctx, down, weights, residual, next_norm_w, eps, norm_out, tokens, top_k, hidden):

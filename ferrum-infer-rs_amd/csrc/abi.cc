@@ -421,8 +421,34 @@ int ferrum_hip_moe_combine_add_rms_norm_f16(const void* down, const float* weigh
                                             const void* next_norm_w, float eps, void* norm_out, int tokens, int top_k,
                                             int hidden, void* stream) {
     FH_REQUIRE(tokens == 0 || (down && weights && residual && (!next_norm_w || norm_out)), "moe_combine_add_rms_norm: null buffer");
-    return moe_combine_add_rms_norm_f16(CH(down), weights, H(residual), CH(next_norm_w), eps, H(norm_out), tokens, top_k,
-                                        hidden, ST(stream));
+    return moe_combine_add_rms_norm_f16(CH(down), weights, CH(residual), H(residual), CH(next_norm_w), eps, H(norm_out),
+                                        tokens, top_k, hidden, ST(stream));
+}
+
+int ferrum_hip_fused_add_rms_norm_route_parts_f16(const void* residual_in, void* residual_out, const void* x_f16,
+                                                  const float* x_slabs, int num_slabs, long slab_stride, int ld_slab,
+                                                  const void* w, float eps, void* norm_out, const void* router_w_tiled,
+                                                  int num_experts, int top_k, int num_parts, void* cand, float* stats,
+                                                  float* logits_out, int tokens, int hidden, void* stream) {
+    FH_REQUIRE(tokens == 0 || (residual_in && residual_out && w && norm_out && (x_f16 || x_slabs)), "route_parts: null buffer");
+    FH_REQUIRE(num_experts == 0 || (router_w_tiled && cand && stats), "route_parts: null router buffers");
+    return fused_add_rms_norm_route_parts_f16(CH(residual_in), H(residual_out), CH(x_f16), x_slabs, num_slabs, slab_stride,
+                                              ld_slab, CH(w), eps, H(norm_out), CH(router_w_tiled), num_experts, top_k,
+                                              num_parts, reinterpret_cast<RouteCand*>(cand), stats, logits_out, tokens, hidden,
+                                              ST(stream));
+}
+int ferrum_hip_moe_gemm_phase_merge_route_f16(const FerrumHipGptq* stack, const void* input, const void* cand,
+                                              const float* stats, void* output, int tokens, int num_parts, int top_k,
+                                              int norm_topk_prob, int num_experts, int max_blocks, int fused_silu_mul,
+                                              int32_t* expert_ids_out, float* expert_weights_out,
+                                              int32_t* sorted_token_ids_out, int32_t* block_ids_out,
+                                              int32_t* total_post_pad_out, void* stream) {
+    FH_REQUIRE(stack && input && cand && stats && output && expert_ids_out && expert_weights_out, "merge_route: null argument");
+    FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "merge_route: fused epilogue needs a stack loaded with fuse_gate_up");
+    FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "merge_route: stack was loaded with fuse_gate_up; plain output is column-permuted");
+    return w4_gemm_moe_merge_route(stack->dev, CH(input), H(output), reinterpret_cast<const RouteCand*>(cand), stats, tokens,
+                                   num_parts, top_k, norm_topk_prob, num_experts, max_blocks, fused_silu_mul, expert_ids_out,
+                                   expert_weights_out, sorted_token_ids_out, block_ids_out, total_post_pad_out, ST(stream));
 }
 
 // ── sampling ────────────────────────────────────────────────────────────────

@@ -42,8 +42,10 @@ __device__ __forceinline__ float block_sum_1024(float v, float* smem) {
     return t;
 }
 
+template <bool SLABS>
 __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
-    __half* __restrict__ residual, const __half* __restrict__ x, const __half* __restrict__ w, float eps,
+    __half* __restrict__ residual, const __half* __restrict__ x, const float* __restrict__ x_slabs, int S,
+    long slab_stride, int ld_slab, const __half* __restrict__ w, float eps,
     __half* __restrict__ norm_out, const __half* __restrict__ router_w, int num_experts, int top_k,
     int norm_topk_prob, int32_t* __restrict__ ids, float* __restrict__ weights, float* __restrict__ logits_out,
     int H) {
@@ -59,10 +61,26 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
     half8 v;
     float ss = 0.f;
     if (i < nvec) {
-        half8 xv = *reinterpret_cast<const half8*>(x + row * H + i * 8);
+        float o[8];
+        if (SLABS) {     // o_proj arrives as S fp32 split-K slabs: reduce in slab order, round like the fp16 op output
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = 0.f;
+            for (int z = 0; z < S; z++) {
+                const float4v* sp = reinterpret_cast<const float4v*>(x_slabs + z * slab_stride + row * ld_slab + i * 8);
+                float4v s0 = sp[0], s1 = sp[1];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { o[j] += s0[j]; o[4 + j] += s1[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (float)(_Float16)o[j];
+        } else {
+            half8 xv = *reinterpret_cast<const half8*>(x + row * H + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (float)xv[j];
+        }
         half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
 #pragma unroll
-        for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + (float)xv[j]);
+        for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + o[j]);
         *reinterpret_cast<half8*>(residual + row * H + i * 8) = rv;
         v = rv;
 #pragma unroll
@@ -161,10 +179,23 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
     }
 }
 
+int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const float* x_slabs, int S, long slab_stride,
+                                       int ld_slab, const __half* w, float eps, __half* norm_out, const __half* router_w,
+                                       int num_experts, int top_k, int norm_topk_prob, int32_t* expert_ids,
+                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s);
+
 int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half* w, float eps, __half* norm_out,
                                  const __half* router_w, int num_experts, int top_k, int norm_topk_prob,
                                  int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
                                  hipStream_t s) {
+    return fused_add_rms_norm_route_slabs_f16(residual, x, nullptr, 0, 0, 0, w, eps, norm_out, router_w, num_experts, top_k,
+                                              norm_topk_prob, expert_ids, expert_weights, logits_out, tokens, H, s);
+}
+
+int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const float* x_slabs, int S, long slab_stride,
+                                       int ld_slab, const __half* w, float eps, __half* norm_out, const __half* router_w,
+                                       int num_experts, int top_k, int norm_topk_prob, int32_t* expert_ids,
+                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(H % 32 == 0 && H <= 8192, "fused_add_rms_norm_route: hidden=%d must be a multiple of 32, <= 8192", H);
     FH_REQUIRE(num_experts <= 512 && top_k <= 64 && (num_experts == 0 || (top_k > 0 && top_k <= num_experts)),
@@ -172,8 +203,208 @@ int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half
     const int tiles = (num_experts + 15) / 16;
     const int ksplit = tiles >= 16 ? 1 : 16 / std::max(tiles, 1);
     const size_t lds = (size_t)H * 2 + ((size_t)std::max(tiles, 1) * 16 * (ksplit + 1) + 128) * 4;
-    hipLaunchKernelGGL(add_rmsnorm_route_kernel, dim3(tokens), dim3(1024), lds, s, residual, x, w, eps, norm_out, router_w,
-                       num_experts, top_k, norm_topk_prob, expert_ids, expert_weights, logits_out, H);
+    if (x_slabs)
+        hipLaunchKernelGGL(add_rmsnorm_route_kernel<true>, dim3(tokens), dim3(1024), lds, s, residual, x, x_slabs, S, slab_stride,
+                           ld_slab, w, eps, norm_out, router_w, num_experts, top_k, norm_topk_prob, expert_ids, expert_weights,
+                           logits_out, H);
+    else
+        hipLaunchKernelGGL(add_rmsnorm_route_kernel<false>, dim3(tokens), dim3(1024), lds, s, residual, x, x_slabs, S, slab_stride,
+                           ld_slab, w, eps, norm_out, router_w, num_experts, top_k, norm_topk_prob, expert_ids, expert_weights,
+                           logits_out, H);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// ── B, split over expert quarters: grid (tokens, Q) ───────────────────────────────────────────────
+// One token's router GEMV is bound by the ≈70 GB/s a single CU can pull from L2 (512 KB → 7 µs), so the
+// experts are split over Q workgroups per token.  Every part repeats the (tiny) add + norm of its token,
+// computes the logits of its E/Q experts on the matrix cores and emits its best min(8, E/Q) candidates
+// (sorted by logit, ties → lower id) plus its softmax statistics (max, Σexp).  The consumer — the prologue
+// of the gate_up grouped GEMM — merges the Q sorted lists per token (merge_route_candidates in w4_gemm.hip).
+// The o-projection may arrive as S fp32 split-K slabs, reduced here in slab order (deterministic).
+template <bool SLABS>
+__global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
+    const __half* __restrict__ residual, __half* __restrict__ residual_out, const __half* __restrict__ x,
+    const float* __restrict__ x_slabs, int S,
+    long slab_stride, int ld_slab, const __half* __restrict__ w, float eps, __half* __restrict__ norm_out,
+    const __half* __restrict__ router_w, int num_experts, int top_k, RouteCand* __restrict__ cand,
+    float* __restrict__ stats, float* __restrict__ logits_out, int H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __half* xs = reinterpret_cast<__half*>(smem_raw);
+    float* part = reinterpret_cast<float*>(smem_raw + (size_t)H * 2);
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const int q = blockIdx.y, Q = gridDim.y;
+    const int nvec = H >> 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int CH = 2;                        // H ≤ 8192 with 512 threads
+    half8 v[CH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 512;
+        if (i < nvec) {
+            float o[8];
+            if (SLABS) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = 0.f;
+                for (int z = 0; z < S; z++) {
+                    const float4v* sp = reinterpret_cast<const float4v*>(x_slabs + z * slab_stride + row * ld_slab + i * 8);
+                    float4v s0 = sp[0], s1 = sp[1];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { o[j] += s0[j]; o[4 + j] += s1[j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = (float)(_Float16)o[j];      // the fp16 o_proj output the unfused op stores
+            } else {
+                half8 xv = *reinterpret_cast<const half8*>(x + row * H + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = (float)xv[j];
+            }
+            half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + o[j]);
+            v[c] = rv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
+        }
+    }
+    ss = wave_reduce_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float total = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    const float inv = 1.0f / sqrtf(total / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 512;
+        if (i < nvec) {
+            half8 wv = *reinterpret_cast<const half8*>(w + i * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
+            *reinterpret_cast<half8*>(xs + i * 8) = o;
+            if (q == 0) {     // part 0 owns the stores (all parts computed identical values)
+                *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+            }
+        }
+    }
+    // Parts of one token run concurrently and all read `residual`, so the updated residual goes to a
+    // SEPARATE buffer (the runner ping-pongs two residual buffers between this kernel and kernel A).
+    if (q == 0) {
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            const int i = threadIdx.x + c * 512;
+            if (i < nvec) *reinterpret_cast<half8*>(residual_out + row * H + i * 8) = v[c];
+        }
+    }
+    __syncthreads();
+    if (num_experts <= 0) return;
+    const int tiles = (num_experts + 15) >> 4;
+    const int tiles_q = tiles / Q;                      // launcher guarantees divisibility
+    const int ksplit = tiles_q >= 8 ? 1 : 8 / tiles_q;
+    const int a = lane >> 4, b = lane & 15;
+    const int ksteps = H >> 5;
+    for (int u = wave; u < tiles_q * ksplit; u += 8) {
+        const int tl = u / ksplit, ks = u % ksplit;
+        const int tile = q * tiles_q + tl;
+        const int s0 = ksteps * ks / ksplit, s1 = ksteps * (ks + 1) / ksplit;
+        const __half* wrow = router_w + ((long)tile * ksteps * 64 + lane) * 8;
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        constexpr int U = 16;
+        int s = s0;
+        for (; s + U <= s1; s += U) {
+            half8 bw[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) bw[k] = *reinterpret_cast<const half8*>(wrow + (long)(s + k) * 512);
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                half8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (b == 0) av = *reinterpret_cast<const half8*>(xs + (s + k) * 32 + 8 * a);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bw[k], acc, 0, 0, 0);
+            }
+        }
+        for (; s < s1; s++) {
+            half8 bwv = *reinterpret_cast<const half8*>(wrow + (long)s * 512);
+            half8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (b == 0) av = *reinterpret_cast<const half8*>(xs + s * 32 + 8 * a);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bwv, acc, 0, 0, 0);
+        }
+        if (a == 0) part[ks * tiles_q * 16 + tl * 16 + b] = acc[0];
+    }
+    __syncthreads();
+    const int EQ = tiles_q * 16;                         // experts of this part (≤ 128)
+    float* lgs = part + ksplit * EQ;                     // [EQ] summed logits
+    const int t = threadIdx.x;
+    const int e_glob = q * EQ + t;
+    float l = -INFINITY;
+    if (t < EQ && e_glob < num_experts) {
+        l = 0.f;
+        for (int ks = 0; ks < ksplit; ks++) l += part[ks * EQ + t];
+        if (logits_out) logits_out[row * num_experts + e_glob] = l;
+    }
+    if (t < EQ) lgs[t] = l;
+    // part statistics (EQ ≤ 128 → waves 0,1)
+    float mx = wave_reduce_max(l);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(red[0], red[1]);
+    __syncthreads();
+    float ex = (t < EQ && e_glob < num_experts) ? expf(l - mx) : 0.f;
+    float sm = wave_reduce_sum(ex);
+    if (lane == 0) red[wave] = sm;
+    __syncthreads();
+    if (t == 0) {
+        stats[(row * Q + q) * 2 + 0] = mx;
+        stats[(row * Q + q) * 2 + 1] = red[0] + red[1];
+    }
+    const int keep = top_k < EQ ? top_k : EQ;
+    if (t < EQ) {
+        int rank = 0;
+        for (int j = 0; j < EQ; j++) {
+            float lj = lgs[j];
+            rank += (lj > l || (lj == l && j < t)) ? 1 : 0;
+        }
+        if (rank < keep) {
+            RouteCand c;
+            c.logit = l;
+            c.id = e_glob;
+            cand[(row * Q + q) * 8 + rank] = c;
+        }
+    }
+    if (t >= keep && t < 8) {                            // unused slots of a short list
+        RouteCand c;
+        c.logit = -INFINITY;
+        c.id = 0x7fffffff;
+        cand[(row * Q + q) * 8 + t] = c;
+    }
+}
+
+int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residual_out, const __half* x,
+                                       const float* x_slabs, int S, long slab_stride, int ld_slab, const __half* w,
+                                       float eps, __half* norm_out, const __half* router_w, int num_experts, int top_k,
+                                       int Q, RouteCand* cand, float* stats, float* logits_out, int tokens, int H,
+                                       hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(H % 32 == 0 && H <= 8192, "route_parts: hidden=%d must be a multiple of 32, <= 8192", H);
+    FH_REQUIRE(residual_in != residual_out || (Q == 1), "route_parts: in-place residual needs Q == 1");
+    const int tiles = std::max(1, (num_experts + 15) / 16);
+    if (num_experts > 0) {
+        FH_REQUIRE(Q >= 1 && tiles % Q == 0 && tiles / Q <= 8, "route_parts: %d expert tiles not divisible into %d parts of <= 8", tiles, Q);
+        FH_REQUIRE(top_k >= 1 && top_k <= 8, "route_parts: top_k=%d must be in [1,8]", top_k);
+    } else {
+        Q = 1;
+    }
+    const int tiles_q = std::max(1, tiles / Q), ksplit = tiles_q >= 8 ? 1 : 8 / tiles_q;
+    const size_t lds = (size_t)H * 2 + (size_t)tiles_q * 16 * (ksplit + 1) * 4;
+    dim3 grid(tokens, Q);
+    if (x_slabs)
+        hipLaunchKernelGGL(add_rmsnorm_route_part_kernel<true>, grid, dim3(512), lds, s, residual_in, residual_out, x,
+                           x_slabs, S, slab_stride, ld_slab, w, eps, norm_out, router_w, num_experts, top_k, cand, stats,
+                           logits_out, H);
+    else
+        hipLaunchKernelGGL(add_rmsnorm_route_part_kernel<false>, grid, dim3(512), lds, s, residual_in, residual_out, x,
+                           x_slabs, S, slab_stride, ld_slab, w, eps, norm_out, router_w, num_experts, top_k, cand, stats,
+                           logits_out, H);
     FH_CHECK_LAUNCH();
     return 0;
 }
@@ -181,8 +412,9 @@ int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half
 // ── A: residual += Σ_k w[b,k]·down[b·K+k];  norm_out = rms(residual)·next_w (optional) ───────────
 template <int CHUNKS>
 __global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
-    const __half* __restrict__ down, const float* __restrict__ weights, __half* __restrict__ residual,
-    const __half* __restrict__ next_w, float eps, __half* __restrict__ norm_out, int top_k, int H) {
+    const __half* __restrict__ down, const float* __restrict__ weights, const __half* __restrict__ residual,
+    __half* __restrict__ residual_out, const __half* __restrict__ next_w, float eps, __half* __restrict__ norm_out,
+    int top_k, int H) {
     __shared__ float red[4];
     const long row = blockIdx.x;
     const int nvec = H >> 3;
@@ -202,7 +434,7 @@ __global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
             half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
 #pragma unroll
             for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + acc[j]);
-            *reinterpret_cast<half8*>(residual + row * H + i * 8) = rv;
+            *reinterpret_cast<half8*>(residual_out + row * H + i * 8) = rv;
             v[c] = rv;
 #pragma unroll
             for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
@@ -224,13 +456,14 @@ __global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
     }
 }
 
-int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, __half* residual, const __half* next_w,
-                                 float eps, __half* norm_out, int tokens, int top_k, int H, hipStream_t s) {
+int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, const __half* residual,
+                                 __half* residual_out, const __half* next_w, float eps, __half* norm_out, int tokens,
+                                 int top_k, int H, hipStream_t s) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(H % 8 == 0 && H <= 8 * 256 * 4, "moe_combine_add_rms_norm: hidden=%d must be a multiple of 8, <= 8192", H);
     const int chunks = cdiv(H / 8, 256);
 #define FH_A(C) hipLaunchKernelGGL((moe_combine_add_rmsnorm_kernel<C>), dim3(tokens), dim3(256), 0, s, down, weights, \
-                                   residual, next_w, eps, norm_out, top_k, H)
+                                   residual, residual_out, next_w, eps, norm_out, top_k, H)
     if (chunks <= 1) FH_A(1); else if (chunks <= 2) FH_A(2); else FH_A(4);
 #undef FH_A
     FH_CHECK_LAUNCH();

@@ -7,6 +7,9 @@
 
 namespace fh {
 
+// one router candidate (fused.hip part kernel → w4_gemm.hip merge)
+struct RouteCand { float logit; int id; };
+
 // ── GPTQ-INT4 (w4_gemm.hip) ──────────────────────────────────────────────────
 struct W4HostPacked {
     int k = 0, n = 0, n64 = 0, G = 0;
@@ -38,6 +41,12 @@ int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* 
 int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
                              int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
                              int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream);
+int w4_gemm_moe_merge_route(const W4Device& w, const __half* x, __half* out, const RouteCand* cand, const float* stats,
+                            int tokens, int Q, int top_k, int norm_topk, int num_experts, int max_blocks, int fused_silu,
+                            int32_t* pub_expert_ids, float* pub_expert_w, int32_t* pub_sorted, int32_t* pub_block_ids,
+                            int32_t* pub_total, hipStream_t stream);
+int w4_gemm_dense_slabs(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int S,
+                        int* rows_pad_out, int* n_pad_out, hipStream_t stream);
 int f16_gemm(const __half* x, const __half* w, __half* out, int m, int n, int k, float* workspace,
              size_t workspace_bytes, hipStream_t stream);
 int f16_gemm_f32out(const __half* x, const __half* w, float* out, int m, int n, int k, float* workspace,
@@ -105,8 +114,20 @@ int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half
                                  const __half* router_w, int num_experts, int top_k, int norm_topk_prob,
                                  int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
                                  hipStream_t s);
-int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, __half* residual, const __half* next_w,
-                                 float eps, __half* norm_out, int tokens, int top_k, int H, hipStream_t s);
+int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const float* x_slabs, int S, long slab_stride,
+                                       int ld_slab, const __half* w, float eps, __half* norm_out, const __half* router_w,
+                                       int num_experts, int top_k, int norm_topk_prob, int32_t* expert_ids,
+                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s);
+int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, const __half* residual,
+                                 __half* residual_out, const __half* next_w, float eps, __half* norm_out, int tokens,
+                                 int top_k, int H, hipStream_t s);
+// B split over Q expert parts per token (+ optional fp32 split-K slabs of the o projection); the Q sorted
+// candidate lists are merged by the gate_up grouped GEMM (w4_gemm_moe_merge_route).
+int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residual_out, const __half* x,
+                                       const float* x_slabs, int S, long slab_stride, int ld_slab, const __half* w,
+                                       float eps, __half* norm_out, const __half* router_w, int num_experts, int top_k,
+                                       int Q, RouteCand* cand, float* stats, float* logits_out, int tokens, int H,
+                                       hipStream_t s);
 
 // ── sampling (sampling.hip) ──────────────────────────────────────────────────
 int argmax_rows_f16(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,

@@ -60,6 +60,11 @@ struct FerrumHipModel {
     __half *residual = nullptr, *norm_out = nullptr, *qkv_out = nullptr, *q_out = nullptr, *attn_out = nullptr,
            *o_out = nullptr, *gate_up_out = nullptr, *act_out = nullptr, *mlp_out = nullptr, *sampled_hidden = nullptr,
            *moe_act = nullptr, *moe_down = nullptr;
+    __half* residual2 = nullptr;          // ping-pong partner of `residual` for the Q-part route kernel
+    fh::RouteCand* route_cand = nullptr;  // [T ≤ 64][Q][8]
+    float* route_stats = nullptr;         // [T][Q][2]
+    int route_parts = 1;                  // expert parts per token in the decode route kernel (>1: candidate-merge path)
+    int o_slabs = 8;                      // split-K slabs of the o projection on the decode path (0 = direct)
     float* router_logits = nullptr;
     int32_t *expert_ids = nullptr, *sorted_ids = nullptr, *block_ids = nullptr, *total_post_pad = nullptr;
     float* expert_w = nullptr;

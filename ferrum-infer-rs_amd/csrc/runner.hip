@@ -233,6 +233,8 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     (void)hipMemcpy(m->cos_t, cs.data(), cs.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(m->sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice);
     m->alloc.reset(new BlockAllocator((uint32_t)cfg->kv_num_blocks));
+    if (const char* e = getenv("FERRUM_HIP_ROUTE_PARTS")) m->route_parts = std::max(1, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_O_SLABS")) m->o_slabs = std::max(0, atoi(e));
     *model = m;
     return 0;
 }
@@ -252,7 +254,8 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->router_logits,
                     (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
-                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter})
+                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
+                    (void*)m->route_cand, (void*)m->route_stats})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -462,6 +465,9 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         rc |= dev_alloc(&m->sorted_ids, sorted_max);
         rc |= dev_alloc(&m->block_ids, sorted_max / 16 + 1);
         rc |= dev_alloc(&m->total_post_pad, (size_t)4);
+        rc |= dev_alloc(&m->residual2, (size_t)64 * H);
+        rc |= dev_alloc(&m->route_cand, (size_t)128 * 8);
+        rc |= dev_alloc(&m->route_stats, (size_t)128 * 2);
         rc |= dev_alloc(&m->moe_act, P * c.expert_inter);
         rc |= dev_alloc(&m->moe_down, P * H);
     } else {
@@ -661,34 +667,74 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                                            sh.max_q_len, sh.max_kv_len, nq, nkv, hd, c.sliding_window, KV_BLOCK,
                                            m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
         }
-        RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
-        RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
         if (c.num_experts > 0) {
             const int E = c.num_experts, K = c.top_k, P = T * K, sorted_max = P + E * 16;
-            // residual += o; post-attention norm; router logits; top-k — one launch (fused.hip B)
-            RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
-                                             c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
             // Σ_e ceil(cnt_e/16) ≤ P/16 + min(P, E): the grid covers every block that can exist
             const int max_blocks = std::min(sorted_max / 16, P / 16 + std::min(P, E));
-            if (P <= 1024) {
-                // decode-sized batch: the grouped GEMMs derive their blocks from the raw expert ids
-                // (gate_up publishes the blocks it derived; down reads them)
-                RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
-                                             m->sorted_ids, m->block_ids, m->total_post_pad, s));
-                RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                max_blocks, 1, 0, s));
+            const int tiles = (E + 15) / 16;
+            int Q = m->route_parts;
+            while (Q > 1 && (tiles % Q != 0 || T * Q > 128)) Q >>= 1;
+            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && c.tp_world == 1 && Q >= 1 && tiles / Q <= 8;
+            if (decode_fast) {
+                // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
+                const float* slabs = nullptr;
+                int S = m->o_slabs, rows_pad = 0, n_pad = 0;
+                if (S > 0) {
+                    RUN(w4_gemm_dense_slabs(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, S, &rows_pad, &n_pad, s));
+                    slabs = m->workspace;
+                    S = std::min(S, L.o.G);
+                } else {
+                    RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+                }
+                if (Q > 1) {
+                    // B over Q expert parts per token: residual → residual2 (ping-pong), norm_out, route candidates;
+                    // gate_up merges the candidate lists, derives its blocks, publishes ids / weights / align arrays.
+                    // (Measured slower than Q = 1 at c=32 — the per-wave merge costs more than the router split
+                    // saves — so it is off by default; FERRUM_HIP_ROUTE_PARTS enables it.)
+                    RUN(fused_add_rms_norm_route_parts_f16(m->residual, m->residual2, m->o_out, slabs, S, (long)rows_pad * n_pad,
+                                                           n_pad, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K, Q,
+                                                           m->route_cand, m->route_stats, nullptr, T, H, s));
+                    RUN(w4_gemm_moe_merge_route(L.exp_gate_up, m->norm_out, m->moe_act, m->route_cand, m->route_stats, T, Q, K,
+                                                c.norm_topk_prob, E, max_blocks, 1, m->expert_ids, m->expert_w, m->sorted_ids,
+                                                m->block_ids, m->total_post_pad, s));
+                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                    max_blocks, 1, 0, s));
+                    RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps,
+                                                     m->norm_out, T, K, H, s));
+                } else {
+                    RUN(fused_add_rms_norm_route_slabs_f16(m->residual, m->o_out, slabs, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
+                                                           c.rms_eps, m->norm_out, L.router, E, K, c.norm_topk_prob, m->expert_ids,
+                                                           m->expert_w, nullptr, T, H, s));
+                    RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
+                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s));
+                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                    max_blocks, 1, 0, s));
+                    RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
+                                                     m->norm_out, T, K, H, s));
+                }
             } else {
-                RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
-                RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                max_blocks, K, 1, s));
+                RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+                RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+                // residual += o; post-attention norm; router logits; top-k — one launch (fused.hip B)
+                RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
+                                                 c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
+                if (P <= 1024) {
+                    RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
+                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s));
+                } else {
+                    RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
+                    RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                    max_blocks, K, 1, s));
+                }
                 RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                                 max_blocks, 1, 0, s));
+                RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
+                                                 m->norm_out, T, K, H, s));
             }
-            // weighted combine + residual add + next layer's input norm — one launch (fused.hip A)
-            // (tp: experts are not sharded — SURVEY.md §8e)
-            RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, next_ln, c.rms_eps, m->norm_out, T, K, H, s));
         } else {
             const int I = c.intermediate;
+            RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+            RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
             RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
             RUN(w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s));
             if (c.activation == 1) {
@@ -917,8 +963,17 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     auto one = [&](int li) -> int {
         LayerWeights& L = m->layers[li];
         switch (which) {
-        case 0: return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
+        case 0: {
+            int Q = m->route_parts;
+            const int tiles = (E + 15) / 16;
+            while (Q > 1 && (tiles % Q != 0 || T * Q > 128)) Q >>= 1;
+            if (Q == 1)
+                return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s);
+            return w4_gemm_moe_merge_route(L.exp_gate_up, m->norm_out, m->moe_act, m->route_cand, m->route_stats, T, Q, c.top_k,
+                                           c.norm_topk_prob, E, max_blocks, 1, m->expert_ids, m->expert_w, m->sorted_ids,
+                                           m->block_ids, m->total_post_pad, s);
+        }
         case 1: return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
         case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),
                                                           idx<uint32_t>(m, m->il.kv_lens), T, max_kv_len, c.num_heads, c.num_kv_heads,

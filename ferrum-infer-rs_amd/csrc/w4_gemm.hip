@@ -267,21 +267,89 @@ struct W4Args {
     int32_t* pub_sorted_token_ids;
     int32_t* pub_block_ids;
     int32_t* pub_total_post_pad;
+    // route merge (decode): Q sorted candidate lists per token from add_rmsnorm_route_part_kernel
+    const RouteCand* cand;
+    const float* stats;
+    int route_T, route_Q, route_K, norm_topk;
+    int32_t* pub_expert_ids;   // [T·K] merged ids  (published by one workgroup)
+    float* pub_expert_w;       // [T·K] combine weights
 };
 
 // Align-block-size computed INSIDE the grouped GEMM (P ≤ 1024 pairs): every workgroup derives its
 // 16-row block (expert + ascending pair ids) from the raw router output with an LDS histogram, a wave
 // scan of the padded counts and a ballot compaction — identical result to moe_align_block_size
 // (ascending pair id inside an expert), but no separate ≈8 µs launch on the decode critical path.
-__device__ __forceinline__ bool inline_align_block(const int32_t* __restrict__ ids, int P, int E, int rb, int* s_cnt,
-                                                   int* s_rows, int* expert_out, int* total_blocks_out) {
-    // one wave per workgroup (MoE kernels launch 64-thread workgroups)
+// Merge the Q per-part candidate lists of every token (each sorted by logit desc, id asc) into the token's
+// top-K, in the same order route_into picks them (ferrum-models/src/moe/router.rs:159-178: descending
+// probability, ties → lower expert id), and derive the combine weights (softmax over all experts from the
+// parts' (max, Σexp) statistics, optional renormalisation over the K picked — router.rs:141-157,180-193).
+// One wave; lane t ↔ token t (T ≤ 64).  Results: s_ids[t·K+k] in LDS; one workgroup also publishes them.
+__device__ __forceinline__ void merge_route_candidates(const RouteCand* __restrict__ cand, const float* __restrict__ stats,
+                                                       int T, int Q, int K, int norm_topk, RouteCand* s_cand, int* s_ids,
+                                                       bool publish, int32_t* pub_ids, float* pub_w) {
+    const int lane = threadIdx.x & 63;
+    const int n = T * Q * 8;
+    for (int i = lane; i < n; i += 64) s_cand[i] = cand[i];
+    __syncthreads();
+    if (lane < T) {
+        const int t = lane;
+        float M = -INFINITY;
+        for (int q = 0; q < Q; q++) M = fmaxf(M, stats[(t * Q + q) * 2]);
+        float S = 0.f;
+        for (int q = 0; q < Q; q++) S += stats[(t * Q + q) * 2 + 1] * expf(stats[(t * Q + q) * 2] - M);
+        const float inv_sum = 1.0f / S;
+        uint32_t heads = 0;                         // 4 bits per part: next unread candidate
+        float pk[8];
+        int idk[8];
+        float sel_sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            pk[k] = 0.f;
+            idk[k] = 0;
+            if (k < K) {
+                float best_l = -INFINITY;
+                int best_id = 0x7fffffff, best_q = 0;
+                for (int q = 0; q < Q; q++) {
+                    const int h = (heads >> (4 * q)) & 15;
+                    if (h < 8) {
+                        const RouteCand c = s_cand[(t * Q + q) * 8 + h];
+                        if (c.logit > best_l || (c.logit == best_l && c.id < best_id)) { best_l = c.logit; best_id = c.id; best_q = q; }
+                    }
+                }
+                heads += 1u << (4 * best_q);
+                if (best_id == 0x7fffffff) best_id = 0;
+                const float p = expf(best_l - M) * inv_sum;
+                pk[k] = p;
+                idk[k] = best_id;
+                sel_sum += p;
+                s_ids[t * K + k] = best_id;
+            }
+        }
+        if (publish) {
+            const float scale = norm_topk ? (sel_sum > 0.f ? 1.0f / sel_sum : 0.f) : 1.0f;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < K) {
+                    pub_ids[t * K + k] = idk[k];
+                    pub_w[t * K + k] = (norm_topk && !(sel_sum > 0.f)) ? 1.0f / (float)K : pk[k] * scale;
+                }
+        }
+    }
+    __syncthreads();
+}
+
+// Align-block-size computed INSIDE the grouped GEMM (P ≤ 1024 pairs) from the per-pair expert ids staged in
+// LDS: LDS histogram, wave scan of the padded counts, ballot compaction — identical result to
+// moe_align_block_size (ascending pair id inside an expert) without the separate ≈8 µs launch.
+// One wave per workgroup.
+__device__ __forceinline__ bool inline_align_block(const int* s_ids, int P, int E, int rb, int* s_cnt, int* s_rows,
+                                                   int* expert_out, int* total_blocks_out) {
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < E; i += 64) s_cnt[i] = 0;
     if (lane < 16) s_rows[lane] = P;      // sentinel
     __syncthreads();
     for (int p = lane; p < P; p += 64) {
-        int e = ids[p];
+        int e = s_ids[p];
         if (e >= 0 && e < E) atomicAdd(&s_cnt[e], 1);
     }
     __syncthreads();
@@ -318,7 +386,7 @@ __device__ __forceinline__ bool inline_align_block(const int32_t* __restrict__ i
     int base = 0;
     for (int p0 = 0; p0 < P; p0 += 64) {
         int p = p0 + lane;
-        bool mine = p < P && ids[p] == e_star;
+        bool mine = p < P && s_ids[p] == e_star;
         unsigned long long bal = __ballot(mine);
         int r = base + __popcll(bal & ((1ull << lane) - 1ull));
         if (mine && (r >> 4) == j) s_rows[r & 15] = p;
@@ -357,11 +425,22 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
         }
     } else {
         // MoE: one 16-row block of sorted pair ids, all of one expert.
-        __shared__ int s_cnt[512], s_rows[16];
+        // LDS: raw[0..8K) holds the route candidates during the merge, then (first 2 KB) the histogram
+        __shared__ __attribute__((aligned(16))) unsigned char s_raw[8192];
+        __shared__ int s_ids[1024], s_rows[16];
+        int* s_cnt = reinterpret_cast<int*>(s_raw);
         int e, id;
-        if (p.pair_expert_ids) {
+        if (p.cand || p.pair_expert_ids) {
+            const bool publisher = blockIdx.x == 0 && rb == 0;
+            if (p.cand) {
+                merge_route_candidates(p.cand, p.stats, p.route_T, p.route_Q, p.route_K, p.norm_topk,
+                                       reinterpret_cast<RouteCand*>(s_raw), s_ids, publisher, p.pub_expert_ids, p.pub_expert_w);
+            } else {
+                for (int i = threadIdx.x; i < p.M; i += 64) s_ids[i] = p.pair_expert_ids[i];
+                __syncthreads();
+            }
             int total_blocks;
-            if (!inline_align_block(p.pair_expert_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
+            if (!inline_align_block(s_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
             id = s_rows[b];
             if (p.pub_sorted_token_ids && blockIdx.x == 0) {
                 if (threadIdx.x < 16) p.pub_sorted_token_ids[rb * 16 + threadIdx.x] = s_rows[threadIdx.x];
@@ -482,7 +561,7 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
         }
         return;
     }
-    if (p.S > 1) {
+    if (p.S > 1 || (MODE == 0 && p.partial)) {
         float* slab = p.partial + (long)z * p.rows_pad * p.n_pad;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
@@ -645,6 +724,10 @@ static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_
     return 0;
 }
 
+static int launch_w4_slabs(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_t stream) {
+    return launch_w4<0>(a, mt, has_zp, grid, stream);
+}
+
 // Dense y[M,N] = x[M,K]·Wᵀ (+bias).  One launch: K is split across the waves of each workgroup.
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
@@ -701,6 +784,55 @@ int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, co
     dim3 grid(w.n64, max_blocks, 1);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
+}
+
+// gate_up phase of a decode step: routing is taken from the Q candidate lists written by
+// fused_add_rms_norm_route_parts_f16; the merged ids / weights and the align arrays are published.
+int w4_gemm_moe_merge_route(const W4Device& w, const __half* x, __half* out, const RouteCand* cand, const float* stats,
+                            int tokens, int Q, int top_k, int norm_topk, int num_experts, int max_blocks, int fused_silu,
+                            int32_t* pub_expert_ids, float* pub_expert_w, int32_t* pub_sorted, int32_t* pub_block_ids,
+                            int32_t* pub_total, hipStream_t stream) {
+    if (tokens <= 0 || max_blocks <= 0) return 0;
+    FH_REQUIRE(tokens <= 64 && tokens * Q <= 128 && tokens * top_k <= 1024 && top_k <= 8 && num_experts <= 512,
+               "merge_route: tokens=%d Q=%d top_k=%d experts=%d out of range", tokens, Q, top_k, num_experts);
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
+    a.expert_stride_sc = (long)w.n64 * w.G * 16 * 4;
+    a.x = x; a.out = out; a.M = tokens * top_k; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64;
+    a.ldo = fused_silu ? w.n / 2 : w.n;
+    a.S = 1;
+    a.num_experts = num_experts;
+    a.cand = cand; a.stats = stats; a.route_T = tokens; a.route_Q = Q; a.route_K = top_k; a.norm_topk = norm_topk;
+    a.pub_expert_ids = pub_expert_ids; a.pub_expert_w = pub_expert_w;
+    a.pub_sorted_token_ids = pub_sorted; a.pub_block_ids = pub_block_ids; a.pub_total_post_pad = pub_total;
+    a.top_k = top_k;
+    dim3 grid(w.n64, max_blocks, 1);
+    if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
+    return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
+}
+
+// Dense projection as S fp32 split-K slabs [S][rows_pad][n_pad] (no reduction here: the consumer kernel sums
+// them in slab order).  Used where the consumer is a fused kernel anyway (o_proj → add+norm+route).
+int w4_gemm_dense_slabs(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int S,
+                        int* rows_pad_out, int* n_pad_out, hipStream_t stream) {
+    if (m <= 0) return 0;
+    FH_REQUIRE(w.perm == nullptr && w.bias == nullptr, "w4_gemm_dense_slabs: act-order / bias weights use the direct path");
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.x = x; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n;
+    const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    const int row_blocks = cdiv(m, 16 * mt);
+    a.rows_pad = row_blocks * 16 * mt;
+    a.n_pad = w.n64 * 64;
+    S = std::max(1, std::min(S, w.G));
+    FH_REQUIRE((size_t)S * a.rows_pad * a.n_pad * sizeof(float) <= slab_bytes, "w4_gemm_dense_slabs: workspace too small");
+    a.S = S;
+    a.partial = slabs;
+    *rows_pad_out = a.rows_pad;
+    *n_pad_out = a.n_pad;
+    // S == 1 still writes a slab (the MODE-0 kernel writes fp16 `out` only when S == 1 → force the slab path)
+    return launch_w4_slabs(a, mt, w.zp != nullptr, dim3(cdiv(w.n64, 4), row_blocks, S), stream);
 }
 
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,

@@ -202,6 +202,25 @@ int ferrum_hip_moe_combine_add_rms_norm_f16(const void* down, const float* weigh
                                             const void* next_norm_w, float eps, void* norm_out, int tokens,
                                             int top_k, int hidden, void* stream);
 
+/* Decode-path form of the same chain with one token's router split over Q workgroups (a single CU can pull only
+ * ≈70 GB/s from L2): every part re-does the token's add+norm, scores E/Q experts and writes its best ≤8
+ * candidates {f32 logit, i32 id} (sorted) to cand[T][Q][8] and (max, Σexp) to stats[T][Q][2].  residual_in and
+ * residual_out must differ when Q > 1.  x may be given as S fp32 split-K slabs (x_slabs, stride slab_stride,
+ * row stride ld_slab; x_f16 ignored) — reduced in slab order.  num_experts = 0 → add + norm only.
+ * ferrum_hip_moe_gemm_phase_merge_route_f16 is the gate_up GEMM that merges the lists (tokens ≤ 64, tokens·Q ≤ 128),
+ * derives its align blocks and publishes expert_ids/weights [T·k] and the three align arrays. */
+int ferrum_hip_fused_add_rms_norm_route_parts_f16(const void* residual_in, void* residual_out, const void* x_f16,
+                                                  const float* x_slabs, int num_slabs, long slab_stride, int ld_slab,
+                                                  const void* w, float eps, void* norm_out, const void* router_w_tiled,
+                                                  int num_experts, int top_k, int num_parts, void* cand, float* stats,
+                                                  float* logits_out, int tokens, int hidden, void* stream);
+int ferrum_hip_moe_gemm_phase_merge_route_f16(const FerrumHipGptq* stack, const void* input, const void* cand,
+                                              const float* stats, void* output, int tokens, int num_parts, int top_k,
+                                              int norm_topk_prob, int num_experts, int max_blocks, int fused_silu_mul,
+                                              int32_t* expert_ids_out, float* expert_weights_out,
+                                              int32_t* sorted_token_ids_out, int32_t* block_ids_out,
+                                              int32_t* total_post_pad_out, void* stream);
+
 /* ── device sampling: Backend::argmax_rows_f16[_masked|_sparse_repetition_penalty]
  *    (traits.rs:1534-1591).  First maximum wins.  valid_token_mask may be NULL. ───────────────── */
 int ferrum_hip_argmax_rows_f16(const void* logits, uint32_t* out_ids_dev, const uint8_t* valid_token_mask,

@@ -512,6 +512,65 @@ def test_fused_add_rms_norm_route_equals_op_chain(env, tokens, H, E, K):
     assert np.max(np.abs(wt.cpu().numpy() - rwt)) < 1e-6
 
 
+@pytest.mark.parametrize("tokens,H,E,K,Q,slabs", [(32, 2048, 128, 8, 4, 0), (1, 2048, 128, 8, 4, 3), (9, 1024, 64, 4, 2, 2),
+                                                     (5, 512, 16, 2, 1, 0), (16, 2048, 128, 8, 8, 0)])
+def test_route_parts_and_merge_equal_single_kernel_route(env, tokens, H, E, K, Q, slabs):
+    """Decode path: router split over Q parts + candidate merge in the gate_up GEMM ≡ route_topk_softmax on the
+    same logits (ids bit-exact, weights 1e-6), residual/norm as the op chain, align arrays as moe_align_block_size."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens + H + E + Q)
+    r = f16r(rng.standard_normal((tokens, H)) * 2)
+    w = f16r(1 + 0.1 * rng.standard_normal(H))
+    rw = f16r(rng.standard_normal((E, H)) * 0.05)
+    if slabs:
+        parts = [rng.standard_normal((tokens, H)).astype(np.float32) * 0.5 for _ in range(slabs)]
+        xs = torch.from_numpy(np.stack(parts)).cuda()                      # [S, T, H] fp32
+        x = f16r(sum(parts[1:], parts[0].copy()))                          # slab-order fp32 sum, rounded like the fp16 o_proj
+        xd = None
+    else:
+        x = f16r(rng.standard_normal((tokens, H)))
+        xs, xd = None, dev16(torch, x)
+    rd, r2 = dev16(torch, r), torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+    nd = torch.empty(tokens, H, dtype=torch.float16, device="cuda")
+    cand = torch.zeros(tokens * Q * 8 * 2, dtype=torch.int32, device="cuda")
+    stats = torch.zeros(tokens * Q * 2, dtype=torch.float32, device="cuda")
+    lg = torch.empty(tokens, E, dtype=torch.float32, device="cuda")
+    B.fused_add_rms_norm_route_parts(ctx, rd, r2, xd, xs, slabs, tokens * H, H, dev16(torch, w), 1e-6, nd,
+                                     B.dense_repack_f16t(ctx, dev16(torch, rw), E, H), E, K, Q, cand, stats, lg, tokens, H)
+    ctx.sync()
+    assert np.array_equal(host(rd), r)                                     # input residual untouched (ping-pong)
+    r_ref, _ = O.fused_add_rms_norm(r, x, w, 1e-6)
+    assert nmse(r_ref, host(r2)) < NMSE_FP16_TOL
+    assert nmse(O.rms_norm(host(r2), w, 1e-6), host(nd)) < NMSE_FP16_TOL
+    logits = lg.cpu().numpy()
+    assert nmse(O.gemm(host(nd), rw, tokens, E, H), logits) < 1e-10
+    # merge inside a grouped GEMM (tiny expert stack; only the routing outputs are checked here)
+    Hs, I = 128, 64
+    gu = [O.make_synthetic_gptq(Hs, 2 * I, 128, 300 + e, symmetric=True) for e in range(E)]
+    stack = B.load_gptq_stacked([q for q, _, _ in gu], [f16r(s) for _, s, _ in gu], [z for _, _, z in gu], None, 4, 128, Hs, 2 * I)
+    P = tokens * K
+    sorted_max = P + E * 16
+    xin = dev16(torch, rng.standard_normal((tokens, Hs)))
+    out = torch.zeros(P, 2 * I, dtype=torch.float16, device="cuda")
+    ids = torch.full((P,), -1, dtype=torch.int32, device="cuda")
+    wts = torch.zeros(P, dtype=torch.float32, device="cuda")
+    sd = torch.full((sorted_max,), P, dtype=torch.int32, device="cuda")
+    bd = torch.zeros(sorted_max // 16 + 1, dtype=torch.int32, device="cuda")
+    td = torch.zeros(1, dtype=torch.int32, device="cuda")
+    stack.gemm_phase_merge_route(ctx, xin, cand, stats, out, tokens, Q, K, True, E, sorted_max // 16, ids, wts, sd, bd, td)
+    ctx.sync()
+    rid, rwt = O.route_topk(logits, E, K, True)
+    assert np.array_equal(ids.cpu().numpy().reshape(tokens, K).astype(np.uint32), rid)
+    assert np.max(np.abs(wts.cpu().numpy().reshape(tokens, K) - rwt)) < 1e-6
+    rs, rb, rt = O.moe_align_block_size(rid.astype(np.int32), E, 16)
+    assert int(td.item()) == rt
+    assert np.array_equal(sd.cpu().numpy()[:rt], rs[:rt]) and np.array_equal(bd.cpu().numpy()[:len(rb)], rb)
+    out2 = torch.zeros_like(out)
+    stack.gemm_phase_inline_align(ctx, xin, ids, out2, P, E, K, sorted_max // 16)
+    ctx.sync()
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("tokens,H,K,with_norm", [(1, 2048, 8, True), (32, 2048, 8, True), (7, 1024, 2, False)])
 def test_moe_combine_add_rms_norm_equals_op_chain(env, tokens, H, K, with_norm):
     pkg, B, ctx, O, torch = env
