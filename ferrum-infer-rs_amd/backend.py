@@ -382,6 +382,17 @@ class HipBackend:
             _ptr(logits_out), tokens, hidden, ctx.stream), "fused_add_rms_norm_route_parts")
 
     @staticmethod
+    def fused_add_rms_norm_route_split(ctx, residual_in, residual_out, x, x_slabs, num_slabs, slab_stride, ld_slab, w, eps,
+                                       norm_out, router_w_tiled, num_experts, top_k, norm_topk_prob, num_parts, cand, stats,
+                                       arrive, expert_ids, expert_weights, logits_out, tokens, hidden):
+        """Split-router form of `fused_add_rms_norm_route` (grid tokens × parts, merge inside the launch)."""
+        _check(ctx.lib.ferrum_hip_fused_add_rms_norm_route_split_f16(
+            _ptr(residual_in), _ptr(residual_out), _ptr(x), _ptr(x_slabs), num_slabs, C.c_long(slab_stride), ld_slab, _ptr(w),
+            C.c_float(eps), _ptr(norm_out), _ptr(router_w_tiled), num_experts, top_k, norm_topk_prob, num_parts, _ptr(cand),
+            _ptr(stats), _ptr(arrive), _ptr(expert_ids), _ptr(expert_weights), _ptr(logits_out), tokens, hidden, ctx.stream),
+            "fused_add_rms_norm_route_split")
+
+    @staticmethod
     def moe_combine_add_rms_norm(ctx, down, weights, residual, next_norm_w, eps, norm_out, tokens, top_k, hidden):
         """moe_combine → add_inplace → (next layer's) rms_norm in one launch."""
         _check(ctx.lib.ferrum_hip_moe_combine_add_rms_norm_f16(

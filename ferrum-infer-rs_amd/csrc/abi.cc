@@ -437,6 +437,21 @@ int ferrum_hip_fused_add_rms_norm_route_parts_f16(const void* residual_in, void*
                                               num_parts, reinterpret_cast<RouteCand*>(cand), stats, logits_out, tokens, hidden,
                                               ST(stream));
 }
+int ferrum_hip_fused_add_rms_norm_route_split_f16(const void* residual_in, void* residual_out, const void* x_f16,
+                                                  const float* x_slabs, int num_slabs, long slab_stride, int ld_slab,
+                                                  const void* w, float eps, void* norm_out, const void* router_w_tiled,
+                                                  int num_experts, int top_k, int norm_topk_prob, int num_parts,
+                                                  void* cand, float* stats, uint32_t* arrive, int32_t* expert_ids,
+                                                  float* expert_weights, float* logits_out, int tokens, int hidden,
+                                                  void* stream) {
+    FH_REQUIRE(tokens == 0 || (residual_in && residual_out && w && norm_out && (x_f16 || x_slabs)), "route_split: null buffer");
+    FH_REQUIRE(num_experts == 0 || (router_w_tiled && cand && stats && arrive && expert_ids && expert_weights),
+               "route_split: null router buffers");
+    return fused_add_rms_norm_route_split_f16(CH(residual_in), H(residual_out), CH(x_f16), x_slabs, num_slabs, slab_stride,
+                                              ld_slab, CH(w), eps, H(norm_out), CH(router_w_tiled), num_experts, top_k,
+                                              num_parts, reinterpret_cast<RouteCand*>(cand), stats, arrive, norm_topk_prob,
+                                              expert_ids, expert_weights, logits_out, tokens, hidden, ST(stream));
+}
 int ferrum_hip_moe_gemm_phase_merge_route_f16(const FerrumHipGptq* stack, const void* input, const void* cand,
                                               const float* stats, void* output, int tokens, int num_parts, int top_k,
                                               int norm_topk_prob, int num_experts, int max_blocks, int fused_silu_mul,

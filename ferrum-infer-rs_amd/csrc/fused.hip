@@ -42,6 +42,34 @@ __device__ __forceinline__ float block_sum_1024(float v, float* smem) {
     return t;
 }
 
+
+// Sum S ≤ 8 fp32 split-K slabs of one 8-element span in slab order.  All 16 loads are issued up front (index
+// clamped, not branched: a load under a runtime condition costs one L2 round trip per slab) and masked in the add.
+__device__ __forceinline__ void reduce_slabs8(const float* __restrict__ base, long slab_stride, int S, float (&o)[8]) {
+    float4v sv[8][2];
+#pragma unroll
+    for (int z = 0; z < 8; z++) {
+        const float4v* sp = reinterpret_cast<const float4v*>(base + (long)(z < S ? z : S - 1) * slab_stride);
+        sv[z][0] = sp[0];
+        sv[z][1] = sp[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll
+    for (int z = 0; z < 8; z++) {
+        if (z < S) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { o[j] += sv[z][0][j]; o[4 + j] += sv[z][1][j]; }
+        }
+    }
+    for (int z = 8; z < S; z++) {          // S > 8: rare, serial
+        const float4v* sp = reinterpret_cast<const float4v*>(base + (long)z * slab_stride);
+        float4v s0 = sp[0], s1 = sp[1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] += s0[j]; o[4 + j] += s1[j]; }
+    }
+}
+
 template <bool SLABS>
 __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
     __half* __restrict__ residual, const __half* __restrict__ x, const float* __restrict__ x_slabs, int S,
@@ -63,14 +91,7 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
     if (i < nvec) {
         float o[8];
         if (SLABS) {     // o_proj arrives as S fp32 split-K slabs: reduce in slab order, round like the fp16 op output
-#pragma unroll
-            for (int j = 0; j < 8; j++) o[j] = 0.f;
-            for (int z = 0; z < S; z++) {
-                const float4v* sp = reinterpret_cast<const float4v*>(x_slabs + z * slab_stride + row * ld_slab + i * 8);
-                float4v s0 = sp[0], s1 = sp[1];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { o[j] += s0[j]; o[4 + j] += s1[j]; }
-            }
+            reduce_slabs8(x_slabs + row * ld_slab + i * 8, slab_stride, S, o);
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (float)(_Float16)o[j];
         } else {
@@ -227,8 +248,9 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
     const __half* __restrict__ residual, __half* __restrict__ residual_out, const __half* __restrict__ x,
     const float* __restrict__ x_slabs, int S,
     long slab_stride, int ld_slab, const __half* __restrict__ w, float eps, __half* __restrict__ norm_out,
-    const __half* __restrict__ router_w, int num_experts, int top_k, RouteCand* __restrict__ cand,
-    float* __restrict__ stats, float* __restrict__ logits_out, int H) {
+    const __half* __restrict__ router_w, int num_experts, int top_k, RouteCand* cand, float* stats,
+    float* __restrict__ logits_out, int H, unsigned* arrive, int norm_topk_prob, int32_t* __restrict__ ids,
+    float* __restrict__ weights) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __half* xs = reinterpret_cast<__half*>(smem_raw);
     float* part = reinterpret_cast<float*>(smem_raw + (size_t)H * 2);
@@ -246,14 +268,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
         if (i < nvec) {
             float o[8];
             if (SLABS) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) o[j] = 0.f;
-                for (int z = 0; z < S; z++) {
-                    const float4v* sp = reinterpret_cast<const float4v*>(x_slabs + z * slab_stride + row * ld_slab + i * 8);
-                    float4v s0 = sp[0], s1 = sp[1];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { o[j] += s0[j]; o[4 + j] += s1[j]; }
-                }
+                reduce_slabs8(x_slabs + row * ld_slab + i * 8, slab_stride, S, o);
 #pragma unroll
                 for (int j = 0; j < 8; j++) o[j] = (float)(_Float16)o[j];      // the fp16 o_proj output the unfused op stores
             } else {
@@ -334,6 +349,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
     __syncthreads();
     const int EQ = tiles_q * 16;                         // experts of this part (≤ 128)
     float* lgs = part + ksplit * EQ;                     // [EQ] summed logits
+    __shared__ unsigned long long cand_s[8];             // this part's sorted candidates {logit bits, id << 32}
     const int t = threadIdx.x;
     const int e_glob = q * EQ + t;
     float l = -INFINITY;
@@ -352,11 +368,6 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
     float ex = (t < EQ && e_glob < num_experts) ? expf(l - mx) : 0.f;
     float sm = wave_reduce_sum(ex);
     if (lane == 0) red[wave] = sm;
-    __syncthreads();
-    if (t == 0) {
-        stats[(row * Q + q) * 2 + 0] = mx;
-        stats[(row * Q + q) * 2 + 1] = red[0] + red[1];
-    }
     const int keep = top_k < EQ ? top_k : EQ;
     if (t < EQ) {
         int rank = 0;
@@ -364,18 +375,62 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
             float lj = lgs[j];
             rank += (lj > l || (lj == l && j < t)) ? 1 : 0;
         }
-        if (rank < keep) {
-            RouteCand c;
-            c.logit = l;
-            c.id = e_glob;
-            cand[(row * Q + q) * 8 + rank] = c;
-        }
+        if (rank < keep) cand_s[rank] = ((unsigned long long)(unsigned)e_glob << 32) | __float_as_uint(l);
     }
-    if (t >= keep && t < 8) {                            // unused slots of a short list
-        RouteCand c;
-        c.logit = -INFINITY;
-        c.id = 0x7fffffff;
-        cand[(row * Q + q) * 8 + t] = c;
+    if (t >= keep && t < 8) cand_s[t] = (0x7fffffffull << 32) | __float_as_uint(-INFINITY);   // unused slots of a short list
+    __syncthreads();
+    if (wave != 0) return;
+    // Publish (wave 0 only): write-through 8-byte stores, drained before the arrival count — the hand-off form
+    // of cdna_hip_programming.md Guideline 16 R1.  Consumers: the gate_up prologue (next launch) or, with
+    // `arrive`, the last-arriving part of this token below.
+    unsigned long long* cand_g = reinterpret_cast<unsigned long long*>(cand) + (row * Q + q) * 8;
+    unsigned long long* stats_g = reinterpret_cast<unsigned long long*>(stats) + (row * Q + q);
+    if (lane < 8) __hip_atomic_store(cand_g + lane, cand_s[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 8)
+        __hip_atomic_store(stats_g, ((unsigned long long)__float_as_uint(red[0] + red[1]) << 32) | __float_as_uint(mx),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (arrive == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(arrive + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != (unsigned)(Q - 1)) return;
+    // Last part of this token to arrive: merge the Q sorted lists (≤ 64 candidates, one per lane).  Every
+    // handed-off byte was stored write-through and drained before its part's ticket; the loads below are sc1
+    // (L1-bypassing) behind an agent acquire (dropping the acquire measured no faster, so it stays).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(arrive + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    const int ncand = Q * 8;
+    unsigned long long c = (0x7fffffffull << 32) | __float_as_uint(-INFINITY);
+    if (lane < ncand)
+        c = __hip_atomic_load(reinterpret_cast<unsigned long long*>(cand) + row * Q * 8 + lane, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
+    float pmx = -INFINITY, psum = 0.f;
+    if (lane < Q) {
+        unsigned long long st = __hip_atomic_load(reinterpret_cast<unsigned long long*>(stats) + row * Q + lane,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pmx = __uint_as_float((unsigned)st);
+        psum = __uint_as_float((unsigned)(st >> 32));
+    }
+    const float gmax = wave_reduce_max(pmx);
+    const float gsum = wave_reduce_sum(lane < Q ? psum * expf(pmx - gmax) : 0.f);
+    const float my_l = __uint_as_float((unsigned)c);
+    const int my_id = (int)(c >> 32);
+    int rank = 0;
+    for (int j = 0; j < ncand; j++) {
+        const float lj = __uint_as_float(__builtin_amdgcn_readlane((int)(unsigned)c, j));
+        const int ij = __builtin_amdgcn_readlane((int)(c >> 32), j);
+        rank += (lj > my_l || (lj == my_l && ij < my_id)) ? 1 : 0;
+    }
+    const float p = expf(my_l - gmax) * (1.0f / gsum);
+    float sel_sum = 0.f;                                  // Σ of the winners in descending order, as route_into adds them
+    for (int k = 0; k < top_k; k++) sel_sum += wave_reduce_sum(rank == k ? p : 0.f);
+    if (rank < top_k) {
+        float ww = p;
+        if (norm_topk_prob) ww = sel_sum > 0.f ? ww * (1.0f / sel_sum) : 1.0f / (float)top_k;
+        ids[row * top_k + rank] = my_id;
+        weights[row * top_k + rank] = ww;
     }
 }
 
@@ -384,7 +439,23 @@ int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residu
                                        float eps, __half* norm_out, const __half* router_w, int num_experts, int top_k,
                                        int Q, RouteCand* cand, float* stats, float* logits_out, int tokens, int H,
                                        hipStream_t s) {
+    return fused_add_rms_norm_route_split_f16(residual_in, residual_out, x, x_slabs, S, slab_stride, ld_slab, w, eps, norm_out,
+                                              router_w, num_experts, top_k, Q, cand, stats, nullptr, 0, nullptr, nullptr,
+                                              logits_out, tokens, H, s);
+}
+
+// With `arrive` (one zeroed counter per token; left zeroed), the last part of each token to arrive merges the
+// lists inside the launch and writes expert_ids / expert_weights [tokens, top_k] — same result as the single-
+// workgroup kernel.  Without it the candidate lists are the output (merged by the gate_up prologue).
+int fused_add_rms_norm_route_split_f16(const __half* residual_in, __half* residual_out, const __half* x,
+                                       const float* x_slabs, int S, long slab_stride, int ld_slab, const __half* w,
+                                       float eps, __half* norm_out, const __half* router_w, int num_experts, int top_k,
+                                       int Q, RouteCand* cand, float* stats, unsigned* arrive, int norm_topk_prob,
+                                       int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
+                                       hipStream_t s) {
     if (tokens <= 0) return 0;
+    FH_REQUIRE(arrive == nullptr || (expert_ids && expert_weights && Q <= 8),
+               "route_split: in-launch merge needs ids/weights outputs and Q <= 8 (got %d)", Q);
     FH_REQUIRE(H % 32 == 0 && H <= 8192, "route_parts: hidden=%d must be a multiple of 32, <= 8192", H);
     FH_REQUIRE(residual_in != residual_out || (Q == 1), "route_parts: in-place residual needs Q == 1");
     const int tiles = std::max(1, (num_experts + 15) / 16);
@@ -400,11 +471,11 @@ int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residu
     if (x_slabs)
         hipLaunchKernelGGL(add_rmsnorm_route_part_kernel<true>, grid, dim3(512), lds, s, residual_in, residual_out, x,
                            x_slabs, S, slab_stride, ld_slab, w, eps, norm_out, router_w, num_experts, top_k, cand, stats,
-                           logits_out, H);
+                           logits_out, H, arrive, norm_topk_prob, expert_ids, expert_weights);
     else
         hipLaunchKernelGGL(add_rmsnorm_route_part_kernel<false>, grid, dim3(512), lds, s, residual_in, residual_out, x,
                            x_slabs, S, slab_stride, ld_slab, w, eps, norm_out, router_w, num_experts, top_k, cand, stats,
-                           logits_out, H);
+                           logits_out, H, arrive, norm_topk_prob, expert_ids, expert_weights);
     FH_CHECK_LAUNCH();
     return 0;
 }

@@ -123,6 +123,12 @@ int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, const
                                  int top_k, int H, hipStream_t s);
 // B split over Q expert parts per token (+ optional fp32 split-K slabs of the o projection); the Q sorted
 // candidate lists are merged by the gate_up grouped GEMM (w4_gemm_moe_merge_route).
+int fused_add_rms_norm_route_split_f16(const __half* residual_in, __half* residual_out, const __half* x,
+                                       const float* x_slabs, int S, long slab_stride, int ld_slab, const __half* w,
+                                       float eps, __half* norm_out, const __half* router_w, int num_experts, int top_k,
+                                       int Q, RouteCand* cand, float* stats, unsigned* arrive, int norm_topk_prob,
+                                       int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
+                                       hipStream_t s);
 int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residual_out, const __half* x,
                                        const float* x_slabs, int S, long slab_stride, int ld_slab, const __half* w,
                                        float eps, __half* norm_out, const __half* router_w, int num_experts, int top_k,

@@ -63,7 +63,8 @@ struct FerrumHipModel {
     __half* residual2 = nullptr;          // ping-pong partner of `residual` for the Q-part route kernel
     fh::RouteCand* route_cand = nullptr;  // [T ≤ 64][Q][8]
     float* route_stats = nullptr;         // [T][Q][2]
-    int route_parts = 1;                  // expert parts per token in the decode route kernel (>1: candidate-merge path)
+    unsigned* route_arrive = nullptr;     // [T] arrival counters of the split route kernel (zero between launches)
+    int route_parts = 4;                  // expert parts per token in the decode route kernel (1 = single-workgroup kernel)
     int o_slabs = 8;                      // split-K slabs of the o projection on the decode path (0 = direct)
     float* router_logits = nullptr;
     int32_t *expert_ids = nullptr, *sorted_ids = nullptr, *block_ids = nullptr, *total_post_pad = nullptr;

@@ -255,7 +255,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
-                    (void*)m->route_cand, (void*)m->route_stats})
+                    (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -466,8 +466,9 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         rc |= dev_alloc(&m->block_ids, sorted_max / 16 + 1);
         rc |= dev_alloc(&m->total_post_pad, (size_t)4);
         rc |= dev_alloc(&m->residual2, (size_t)64 * H);
-        rc |= dev_alloc(&m->route_cand, (size_t)128 * 8);
-        rc |= dev_alloc(&m->route_stats, (size_t)128 * 2);
+        rc |= dev_alloc(&m->route_cand, (size_t)512 * 8);     // [T ≤ 64][Q ≤ 8][8]
+        rc |= dev_alloc(&m->route_stats, (size_t)512 * 2);
+        rc |= dev_alloc(&m->route_arrive, (size_t)64);         // zeroed here; the route kernel re-arms it
         rc |= dev_alloc(&m->moe_act, P * c.expert_inter);
         rc |= dev_alloc(&m->moe_down, P * H);
     } else {
@@ -673,7 +674,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             const int max_blocks = std::min(sorted_max / 16, P / 16 + std::min(P, E));
             const int tiles = (E + 15) / 16;
             int Q = m->route_parts;
-            while (Q > 1 && (tiles % Q != 0 || T * Q > 128)) Q >>= 1;
+            while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
             const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && c.tp_world == 1 && Q >= 1 && tiles / Q <= 8;
             if (decode_fast) {
                 // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
@@ -687,16 +688,15 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                     RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
                 }
                 if (Q > 1) {
-                    // B over Q expert parts per token: residual → residual2 (ping-pong), norm_out, route candidates;
-                    // gate_up merges the candidate lists, derives its blocks, publishes ids / weights / align arrays.
-                    // (Measured slower than Q = 1 at c=32 — the per-wave merge costs more than the router split
-                    // saves — so it is off by default; FERRUM_HIP_ROUTE_PARTS enables it.)
-                    RUN(fused_add_rms_norm_route_parts_f16(m->residual, m->residual2, m->o_out, slabs, S, (long)rows_pad * n_pad,
+                    // B over Q expert parts per token (one CU pulls the 512-KB router at ≈70 GB/s; Q CUs share it):
+                    // residual → residual2 (ping-pong), norm_out; each token's last-arriving part merges the Q
+                    // candidate lists inside the launch and writes expert_ids / expert_w.
+                    RUN(fused_add_rms_norm_route_split_f16(m->residual, m->residual2, m->o_out, slabs, S, (long)rows_pad * n_pad,
                                                            n_pad, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K, Q,
-                                                           m->route_cand, m->route_stats, nullptr, T, H, s));
-                    RUN(w4_gemm_moe_merge_route(L.exp_gate_up, m->norm_out, m->moe_act, m->route_cand, m->route_stats, T, Q, K,
-                                                c.norm_topk_prob, E, max_blocks, 1, m->expert_ids, m->expert_w, m->sorted_ids,
-                                                m->block_ids, m->total_post_pad, s));
+                                                           m->route_cand, m->route_stats, m->route_arrive, c.norm_topk_prob,
+                                                           m->expert_ids, m->expert_w, nullptr, T, H, s));
+                    RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
+                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s));
                     RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                                     max_blocks, 1, 0, s));
                     RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps,
@@ -964,15 +964,8 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
         LayerWeights& L = m->layers[li];
         switch (which) {
         case 0: {
-            int Q = m->route_parts;
-            const int tiles = (E + 15) / 16;
-            while (Q > 1 && (tiles % Q != 0 || T * Q > 128)) Q >>= 1;
-            if (Q == 1)
-                return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
-                                                m->sorted_ids, m->block_ids, m->total_post_pad, s);
-            return w4_gemm_moe_merge_route(L.exp_gate_up, m->norm_out, m->moe_act, m->route_cand, m->route_stats, T, Q, c.top_k,
-                                           c.norm_topk_prob, E, max_blocks, 1, m->expert_ids, m->expert_w, m->sorted_ids,
-                                           m->block_ids, m->total_post_pad, s);
+            return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
+                                            m->sorted_ids, m->block_ids, m->total_post_pad, s);
         }
         case 1: return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
         case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),

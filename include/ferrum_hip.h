@@ -214,6 +214,16 @@ int ferrum_hip_fused_add_rms_norm_route_parts_f16(const void* residual_in, void*
                                                   const void* w, float eps, void* norm_out, const void* router_w_tiled,
                                                   int num_experts, int top_k, int num_parts, void* cand, float* stats,
                                                   float* logits_out, int tokens, int hidden, void* stream);
+/* Same kernel, merge done INSIDE the launch: `arrive` is one zeroed uint32 per token (the kernel leaves it zeroed);
+ * the last part of a token to arrive merges the lists and writes expert_ids / expert_weights [tokens, top_k]
+ * exactly as ferrum_hip_fused_add_rms_norm_route_f16 does.  num_parts ≤ 8. */
+int ferrum_hip_fused_add_rms_norm_route_split_f16(const void* residual_in, void* residual_out, const void* x_f16,
+                                                  const float* x_slabs, int num_slabs, long slab_stride, int ld_slab,
+                                                  const void* w, float eps, void* norm_out, const void* router_w_tiled,
+                                                  int num_experts, int top_k, int norm_topk_prob, int num_parts,
+                                                  void* cand, float* stats, uint32_t* arrive, int32_t* expert_ids,
+                                                  float* expert_weights, float* logits_out, int tokens, int hidden,
+                                                  void* stream);
 int ferrum_hip_moe_gemm_phase_merge_route_f16(const FerrumHipGptq* stack, const void* input, const void* cand,
                                               const float* stats, void* output, int tokens, int num_parts, int top_k,
                                               int norm_topk_prob, int num_experts, int max_blocks, int fused_silu_mul,

@@ -571,6 +571,49 @@ def test_route_parts_and_merge_equal_single_kernel_route(env, tokens, H, E, K, Q
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("tokens,H,E,K,Q,slabs", [(32, 2048, 128, 8, 4, 8), (64, 2048, 128, 8, 8, 0), (1, 2048, 128, 8, 2, 3),
+                                                     (9, 1024, 64, 4, 2, 2), (5, 512, 16, 2, 1, 0), (33, 2048, 128, 8, 4, 0)])
+def test_route_split_in_launch_merge_equals_route_topk(env, tokens, H, E, K, Q, slabs):
+    """Split router with the merge done by each token's last-arriving part: ids bit-exact and weights 1e-6 against
+    route_topk_softmax on the emitted logits; repeated launches reuse cand/stats/arrive (counter re-arm, stale lines)."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(7 * tokens + H + E + Q)
+    w = f16r(1 + 0.1 * rng.standard_normal(H))
+    rw = f16r(rng.standard_normal((E, H)) * 0.05)
+    rwt = B.dense_repack_f16t(ctx, dev16(torch, rw), E, H)
+    cand = torch.zeros(tokens * Q * 8 * 2, dtype=torch.int32, device="cuda")
+    stats = torch.zeros(tokens * Q * 2, dtype=torch.float32, device="cuda")
+    arrive = torch.zeros(tokens, dtype=torch.int32, device="cuda")
+    wd = dev16(torch, w)
+    for rep in range(4):
+        r = f16r(rng.standard_normal((tokens, H)) * 2)
+        if slabs:
+            parts = [rng.standard_normal((tokens, H)).astype(np.float32) * 0.5 for _ in range(slabs)]
+            xs = torch.from_numpy(np.stack(parts)).cuda()
+            x = f16r(sum(parts[1:], parts[0].copy()))
+            xd = None
+        else:
+            x = f16r(rng.standard_normal((tokens, H)))
+            xs, xd = None, dev16(torch, x)
+        rd, r2 = dev16(torch, r), torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+        nd = torch.empty(tokens, H, dtype=torch.float16, device="cuda")
+        lg = torch.empty(tokens, E, dtype=torch.float32, device="cuda")
+        ids = torch.full((tokens, K), -1, dtype=torch.int32, device="cuda")
+        wts = torch.zeros(tokens, K, dtype=torch.float32, device="cuda")
+        B.fused_add_rms_norm_route_split(ctx, rd, r2, xd, xs, slabs, tokens * H, H, wd, 1e-6, nd, rwt, E, K, rep % 2, Q, cand,
+                                         stats, arrive, ids, wts, lg, tokens, H)
+        ctx.sync()
+        assert int(arrive.abs().sum().item()) == 0                         # counters re-armed
+        r_ref, _ = O.fused_add_rms_norm(r, x, w, 1e-6)
+        assert nmse(r_ref, host(r2)) < NMSE_FP16_TOL
+        assert nmse(O.rms_norm(host(r2), w, 1e-6), host(nd)) < NMSE_FP16_TOL
+        logits = lg.cpu().numpy()
+        assert nmse(O.gemm(host(nd), rw, tokens, E, H), logits) < 1e-10
+        rid, rwt_ref = O.route_topk(logits, E, K, bool(rep % 2))
+        assert np.array_equal(ids.cpu().numpy().astype(np.uint32), rid), f"rep {rep}"
+        assert np.max(np.abs(wts.cpu().numpy() - rwt_ref)) < 1e-6
+
+
 @pytest.mark.parametrize("tokens,H,K,with_norm", [(1, 2048, 8, True), (32, 2048, 8, True), (7, 1024, 2, False)])
 def test_moe_combine_add_rms_norm_equals_op_chain(env, tokens, H, K, with_norm):
     pkg, B, ctx, O, torch = env
