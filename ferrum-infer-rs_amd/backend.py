@@ -301,6 +301,17 @@ class HipBackend:
             "paged_batched_decode_attention")
 
     @staticmethod
+    def paged_decode_attention_fused_qkv(ctx, qkv, q_norm_w, k_norm_w, cos, sin, eps, qk_mode, k_pool, v_pool, out,
+                                         block_tables, valid_kv_lens, num_seqs, max_kv_len, num_heads, num_kv_heads,
+                                         head_dim, block_size, max_num_blocks_per_seq):
+        """split_qkv_norm_rope_into_paged_cache_varlen (one token per sequence) + paged_batched_decode_attention."""
+        _check(ctx.lib.ferrum_hip_paged_decode_attention_fused_qkv_f16(
+            _ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin), C.c_float(eps), qk_mode, _ptr(k_pool),
+            _ptr(v_pool), _ptr(out), _ptr(block_tables), _ptr(valid_kv_lens), num_seqs, max_kv_len, num_heads,
+            num_kv_heads, head_dim, block_size, max_num_blocks_per_seq, ctx.ws, ctx.stream),
+            "paged_decode_attention_fused_qkv")
+
+    @staticmethod
     def paged_kv_read(ctx, cache_k, cache_v, block_table, kv_len, kv_heads, head_dim, block_size=16):
         import torch
         k = torch.empty(kv_len, kv_heads, head_dim, dtype=torch.float16, device=cache_k.device)

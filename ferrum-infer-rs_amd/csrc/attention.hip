@@ -21,6 +21,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "kv_layout.h"
+#include "rope_rows.h"
 
 namespace fh {
 
@@ -36,9 +37,25 @@ struct AttnArgs {
     float* partial;         // [tiles][nsplit][16][hd+2] when nsplit > 1
     int num_seqs, nq, nkv, tiles_per_seq, max_blocks, sliding_window, nsplit;
     float scale;
+    // fused decode form (FUSED_QKV): q / new K / new V come straight from the qkv projection output
+    const __half* qkv;      // [num_seqs, (nq + 2·nkv)·hd]
+    const __half* q_norm_w;
+    const __half* k_norm_w;
+    const float* cos_t;
+    const float* sin_t;
+    __half* k_pool_w;
+    __half* v_pool_w;
+    float eps;
+    int qk_mode;
 };
 
-template <int HD>
+// FUSED_QKV (decode, q_len = 1): the workgroup of (sequence, kv head) first does what
+// split_qkv_norm_rope_into_paged_cache_varlen does for ITS rows of the new token — the G query heads of the
+// group, the kv head's key (both per-head RMSNorm + RoPE per qk_mode) and value — into LDS, with the same
+// float operations in the same order (bit-identical fp16 results).  The split that owns the last KV block
+// writes the new K/V into the paged cache and every wave patches the new token's slot into the fragments it
+// loaded from that block, so nothing depends on the visibility of the cache store inside the launch.
+template <int HD, bool FUSED_QKV>
 __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
     constexpr int DT = HD / 16;      // output d-tiles
     constexpr int KS = HD / 32;      // QKᵀ k-steps (= 1-KiB loads per K tile = per V tile)
@@ -81,8 +98,50 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
 
     half8 qf[KS];
+    __shared__ __attribute__((aligned(16))) __half lds_q[FUSED_QKV ? 16 * HD : 8];
+    __shared__ __attribute__((aligned(16))) __half lds_kv[FUSED_QKV ? 2 * HD : 8];
+    const int last_blk = pos0 / KV_BLOCK, slot_new = pos0 % KV_BLOCK;
+    if (FUSED_QKV) {
+        // 16 quarter-wave rows cover the G query heads, the key (row G), the value (row G + 1); rows ≥ G of lds_q are zero
+        constexpr int HALF = HD / 2;
+        const int q_dim = p.nq * HD, kv_dim = p.nkv * HD;
+        const __half* qrow = p.qkv + (long)seq * (q_dim + 2 * kv_dim);
+        const int r16 = threadIdx.x >> 4, q16 = threadIdx.x & 15;
+        const int rc = r16 < G + 2 ? r16 : G + 1;     // clamped: loads stay unconditional
+        const __half* src = rc < G ? qrow + (kvh * G + rc) * HD
+                                   : rc == G ? qrow + q_dim + kvh * HD : qrow + q_dim + kv_dim + kvh * HD;
+        const RopeRow<HD> rr = rope_row16<HD>(src, rc < G ? p.q_norm_w : p.k_norm_w, p.cos_t + (long)pos0 * HALF,
+                                              p.sin_t + (long)pos0 * HALF, rc <= G ? p.qk_mode : 0, p.qk_mode == 1,
+                                              p.qk_mode != 0, p.eps, q16);
+        using hv = typename RopeRow<HD>::hv;
+        hv z0, z1;
 #pragma unroll
-    for (int s = 0; s < KS; s++) qf[s] = *reinterpret_cast<const half8*>(p.q + q_off + 32 * s + 8 * a);
+        for (int k = 0; k < HD / 32; k++) { z0[k] = (_Float16)0.f; z1[k] = (_Float16)0.f; }
+        _Float16* lq = reinterpret_cast<_Float16*>(lds_q) + r16 * HD;
+        *reinterpret_cast<hv*>(lq + rr.off0) = r16 < G ? rr.out0 : z0;
+        *reinterpret_cast<hv*>(lq + rr.off1) = r16 < G ? rr.out1 : z1;
+        if (r16 == G || r16 == G + 1) {
+            _Float16* lk = reinterpret_cast<_Float16*>(lds_kv) + (r16 - G) * HD;
+            *reinterpret_cast<hv*>(lk + rr.off0) = rr.out0;
+            *reinterpret_cast<hv*>(lk + rr.off1) = rr.out1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < KS; s++) qf[s] = *reinterpret_cast<const half8*>(lds_q + b * HD + 32 * s + 8 * a);
+        // the split that owns the last block stores the new token's K (wave 0) and V (wave 1) into the cache
+        const int last_pair = last_blk >> 1;
+        if (last_pair >= my_lo && last_pair < my_hi && wave < 2) {
+            const long phys = p.block_tables[(long)seq * p.max_blocks + last_blk];
+            const long toff = (phys * p.nkv + kvh) * kv_tile_elems(HD);
+            for (int d = lane; d < HD; d += 64) {
+                if (wave == 0) p.k_pool_w[toff + k_tile_off(slot_new, d)] = lds_kv[d];
+                else p.v_pool_w[toff + v_tile_off(slot_new, d)] = lds_kv[HD + d];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; s++) qf[s] = *reinterpret_cast<const half8*>(p.q + q_off + 32 * s + 8 * a);
+    }
 
     float m_run = -INFINITY, l_run = 0.f;
     float4v o_acc[DT];
@@ -111,6 +170,28 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
         for (int s = 0; s < KS; s++) {
             vf0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v0 + s * 512));
             vf1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v1 + s * 512));
+        }
+        if (FUSED_QKV && (blk0 == last_blk || blk1 == last_blk)) {
+            // patch the new token's slot (key slot_new of block last_blk) into the loaded fragments
+            const bool in1 = blk1 == last_blk;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                const half8 nk = *reinterpret_cast<const half8*>(lds_kv + 32 * s + 8 * a);
+                if (b == slot_new) { if (in1) kf1[s] = nk; else kf0[s] = nk; }
+            }
+            const bool a_hit = a == (slot_new >> 2);
+            const int jn = slot_new & 3;
+#pragma unroll
+            for (int ld = 0; ld < KS; ld++) {
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+                    const _Float16 nv = (_Float16)lds_kv[HD + 32 * ld + 16 * sub + b];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if (a_hit && j == jn) { if (in1) vf1[ld][4 * sub + j] = nv; else vf0[ld][4 * sub + j] = nv; }
+                    }
+                }
+            }
         }
         // Sᵀ[key][row] for the two blocks: lane (a,b) ← keys 4a+r of each block, query row b
         float4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -257,12 +338,17 @@ size_t paged_attention_workspace_bytes(int total_q_tokens, int num_heads, int he
     return (size_t)rows * 32 * (head_dim + 2) * sizeof(float);
 }
 
+struct FusedQkv {
+    const __half* qkv; const __half* q_norm_w; const __half* k_norm_w; const float* cos_t; const float* sin_t;
+    __half* k_pool_w; __half* v_pool_w; float eps; int qk_mode;
+};
+
 static int paged_attention_launch(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
                                const uint32_t* cu_seqlens_q, const uint32_t* pos_offsets, const uint32_t* kv_lens,
                                const int32_t* block_tables, int num_seqs, int total_q_tokens, int max_q_len,
                                int max_kv_len, int num_heads, int num_kv_heads, int head_dim,
                                int sliding_window, int block_size, int max_blocks_per_seq, float* workspace,
-                               size_t workspace_bytes, hipStream_t s) {
+                               size_t workspace_bytes, hipStream_t s, const FusedQkv* fq = nullptr) {
     if (num_seqs <= 0 || total_q_tokens <= 0) return 0;
     FH_REQUIRE(block_size == KV_BLOCK, "paged attention: block_size=%d unsupported (native layout uses 16)", block_size);
     FH_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged attention: nq=%d not a multiple of nkv=%d",
@@ -284,9 +370,14 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     if (nsplit > 1 && (workspace == nullptr || need > workspace_bytes)) nsplit = 1;
     a.nsplit = nsplit;
     a.partial = workspace;
+    if (fq) {
+        a.qkv = fq->qkv; a.q_norm_w = fq->q_norm_w; a.k_norm_w = fq->k_norm_w; a.cos_t = fq->cos_t; a.sin_t = fq->sin_t;
+        a.k_pool_w = fq->k_pool_w; a.v_pool_w = fq->v_pool_w; a.eps = fq->eps; a.qk_mode = fq->qk_mode;
+    }
     dim3 grid(tiles, num_kv_heads, nsplit);
 #define FH_ATTN(HDV)                                                                              \
-    hipLaunchKernelGGL(paged_attn_kernel<HDV>, grid, dim3(256), 0, s, a);                         \
+    if (fq) hipLaunchKernelGGL((paged_attn_kernel<HDV, true>), grid, dim3(256), 0, s, a);         \
+    else hipLaunchKernelGGL((paged_attn_kernel<HDV, false>), grid, dim3(256), 0, s, a);           \
     FH_CHECK_LAUNCH();                                                                            \
     if (nsplit > 1) {                                                                             \
         hipLaunchKernelGGL(paged_attn_reduce_kernel<HDV>, dim3(tiles, num_kv_heads), dim3(16 * HDV / 8), 0, s, a); \
@@ -317,6 +408,23 @@ int paged_batched_decode_attention_f16(const __half* q, const __half* k_pool, co
     return paged_attention_launch(q, k_pool, v_pool, out, nullptr, nullptr, valid_kv_lens, block_tables, num_seqs,
                                   num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, 0, block_size,
                                   max_blocks_per_seq, workspace, workspace_bytes, s);
+}
+
+// Decode step of one layer in ONE launch: split_qkv_norm_rope_into_paged_cache_varlen (q_len = 1 per sequence,
+// position = valid_kv_lens[seq] − 1) + paged_batched_decode_attention.  Same results as the two-op chain.
+int paged_decode_attention_fused_qkv_f16(const __half* qkv, const __half* q_norm_w, const __half* k_norm_w,
+                                         const float* cos_t, const float* sin_t, float eps, int qk_mode, __half* k_pool,
+                                         __half* v_pool, __half* out, const int32_t* block_tables,
+                                         const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len, int num_heads,
+                                         int num_kv_heads, int head_dim, int block_size, int max_blocks_per_seq,
+                                         float* workspace, size_t workspace_bytes, hipStream_t s) {
+    FH_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0 && num_heads / num_kv_heads <= 14,
+               "fused decode attention: GQA group %d/%d must be <= 14", num_heads, num_kv_heads);
+    FH_REQUIRE(qk_mode >= 0 && qk_mode <= 3, "fused decode attention: qk_mode=%d out of range", qk_mode);
+    FusedQkv fq{qkv, q_norm_w, k_norm_w, cos_t, sin_t, k_pool, v_pool, eps, qk_mode};
+    return paged_attention_launch(nullptr, k_pool, v_pool, out, nullptr, nullptr, valid_kv_lens, block_tables, num_seqs,
+                                  num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, 0, block_size,
+                                  max_blocks_per_seq, workspace, workspace_bytes, s, &fq);
 }
 
 }  // namespace fh

@@ -8,19 +8,26 @@
 #include "common.h"
 #include "kernels.h"
 #include "kv_layout.h"
+#include "rope_rows.h"
 
 namespace fh {
 
-// One wave per (token, head).  hd ≤ 256.
+// One quarter wave per (token, head): a 64-thread workgroup covers 4 consecutive heads of one token
+// (q heads, then k heads, then v heads).  Row maths in rope_rows.h.
+template <int HD>
 __global__ __launch_bounds__(64) void split_qkv_norm_rope_paged_kernel(
     const __half* __restrict__ qkv, const __half* __restrict__ q_norm_w, const __half* __restrict__ k_norm_w,
     const float* __restrict__ cos_t, const float* __restrict__ sin_t, __half* __restrict__ q_out,
     __half* __restrict__ cache_k, __half* __restrict__ cache_v, const uint32_t* __restrict__ cu_seqlens_q,
     const uint32_t* __restrict__ pos_offsets, const int32_t* __restrict__ block_tables, int num_seqs,
-    int q_heads, int kv_heads, int hd, float eps, int qk_mode, int max_blocks_per_seq) {
-    const int tok = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
-    const int half_d = hd >> 1;
-    const int q_dim = q_heads * hd, kv_dim = kv_heads * hd;
+    int q_heads, int kv_heads, float eps, int qk_mode, int max_blocks_per_seq) {
+    constexpr int PPL = HD / 32, HALF = HD / 2;
+    const int tok = blockIdx.x, lane = threadIdx.x, q16 = lane & 15;
+    const int heads = q_heads + 2 * kv_heads;
+    const int head_raw = blockIdx.y * 4 + (lane >> 4);
+    const bool act = head_raw < heads;
+    const int head = act ? head_raw : heads - 1;          // clamped: loads stay unconditional
+    const int q_dim = q_heads * HD, kv_dim = kv_heads * HD;
     const __half* row = qkv + (long)tok * (q_dim + 2 * kv_dim);
 
     // locate the sequence (cu_seqlens_q is a short prefix sum; same scan as the reference kernel)
@@ -30,54 +37,32 @@ __global__ __launch_bounds__(64) void split_qkv_norm_rope_paged_kernel(
 
     const bool is_q = head < q_heads;
     const bool is_k = !is_q && head < q_heads + kv_heads;
-    int local_head, mode;
-    const __half* src;
-    const __half* nw = nullptr;
-    if (is_q) { local_head = head; src = row + local_head * hd; mode = qk_mode; nw = q_norm_w; }
-    else if (is_k) { local_head = head - q_heads; src = row + q_dim + local_head * hd; mode = qk_mode; nw = k_norm_w; }
-    else { local_head = head - q_heads - kv_heads; src = row + q_dim + kv_dim + local_head * hd; mode = 0; }
-
-    __half* dst_q = nullptr;
-    __half* tile = nullptr;
-    int slot = 0;
+    const int local_head = is_q ? head : is_k ? head - q_heads : head - q_heads - kv_heads;
+    const __half* src = row + (is_q ? 0 : is_k ? q_dim : q_dim + kv_dim) + local_head * HD;
+    const int mode = (is_q || is_k) ? qk_mode : 0;
+    const RopeRow<HD> rr = rope_row16<HD>(src, is_q ? q_norm_w : k_norm_w, cos_t + (long)pos * HALF, sin_t + (long)pos * HALF,
+                                          mode, qk_mode == 1, qk_mode != 0, eps, q16);
+    if (!act) return;
+    using hv = typename RopeRow<HD>::hv;
     if (is_q) {
-        dst_q = q_out + ((long)tok * q_heads + local_head) * hd;
-    } else {
-        const int logical = pos / KV_BLOCK;
-        slot = pos % KV_BLOCK;
-        const long physical = block_tables[(long)seq * max_blocks_per_seq + logical];
-        tile = (is_k ? cache_k : cache_v) + (physical * kv_heads + local_head) * kv_tile_elems(hd);
-    }
-    auto store = [&](int d, float v) {
-        __half h = __float2half(v);
-        if (is_q) dst_q[d] = h;
-        else if (is_k) tile[k_tile_off(slot, d)] = h;
-        else tile[v_tile_off(slot, d)] = h;
-    };
-
-    if (mode == 0) {
-        for (int i = lane; i < hd; i += 64) store(i, __half2float(src[i]));
+        __half* dst = q_out + ((long)tok * q_heads + local_head) * HD;
+        *reinterpret_cast<hv*>(dst + rr.off0) = rr.out0;
+        *reinterpret_cast<hv*>(dst + rr.off1) = rr.out1;
         return;
     }
-    float scale = 1.0f;
-    if (mode == 1) {
-        float ss = 0.f;
-        for (int i = lane; i < hd; i += 64) { float x = __half2float(src[i]); ss += x * x; }
-        ss = wave_reduce_sum(ss);
-        scale = 1.0f / sqrtf(ss / (float)hd + eps);
-    }
-    const float* cs = cos_t + (long)pos * half_d;
-    const float* sn = sin_t + (long)pos * half_d;
-    for (int i = lane; i < half_d; i += 64) {
-        int i0 = mode == 3 ? 2 * i : i, i1 = mode == 3 ? 2 * i + 1 : i + half_d;
-        float x0 = __half2float(src[i0]), x1 = __half2float(src[i1]);
-        if (mode == 1) {
-            x0 = x0 * scale * __half2float(nw[i0]);
-            x1 = x1 * scale * __half2float(nw[i1]);
+    const int logical = pos / KV_BLOCK, slot = pos % KV_BLOCK;
+    const long physical = block_tables[(long)seq * max_blocks_per_seq + logical];
+    __half* tile = (is_k ? cache_k : cache_v) + (physical * kv_heads + local_head) * kv_tile_elems(HD);
+    _Float16* t16 = reinterpret_cast<_Float16*>(tile);
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        if (is_k) {
+            t16[k_tile_off(slot, rr.off0 + k)] = rr.out0[k];
+            t16[k_tile_off(slot, rr.off1 + k)] = rr.out1[k];
+        } else {
+            t16[v_tile_off(slot, rr.off0 + k)] = rr.out0[k];
+            t16[v_tile_off(slot, rr.off1 + k)] = rr.out1[k];
         }
-        float c = cs[i], s = sn[i];
-        store(i0, x0 * c - x1 * s);
-        store(i1, x1 * c + x0 * s);
     }
 }
 
@@ -88,11 +73,15 @@ int split_qkv_norm_rope_into_paged_cache_varlen_f16(
     int qk_mode, int block_size, int max_blocks_per_seq, hipStream_t s) {
     if (m_total <= 0) return 0;
     FH_REQUIRE(block_size == KV_BLOCK, "paged KV: block_size=%d unsupported (native layout uses 16)", block_size);
-    FH_REQUIRE(head_dim % 32 == 0 && head_dim <= 256, "paged KV: head_dim=%d must be a multiple of 32, <= 256", head_dim);
+    FH_REQUIRE(head_dim == 64 || head_dim == 128 || head_dim == 256, "paged KV: head_dim=%d must be 64, 128 or 256", head_dim);
     FH_REQUIRE(qk_mode >= 0 && qk_mode <= 3, "paged KV: qk_mode=%d out of range", qk_mode);
-    hipLaunchKernelGGL(split_qkv_norm_rope_paged_kernel, dim3(m_total, q_heads + 2 * kv_heads), dim3(64), 0, s, qkv,
-                       q_norm_w, k_norm_w, cos_t, sin_t, q_out, cache_k, cache_v, cu_seqlens_q, pos_offsets,
-                       block_tables, num_seqs, q_heads, kv_heads, head_dim, eps, qk_mode, max_blocks_per_seq);
+    const dim3 grid(m_total, cdiv(q_heads + 2 * kv_heads, 4));
+#define FH_ROPE(HDV)                                                                                                   \
+    hipLaunchKernelGGL(split_qkv_norm_rope_paged_kernel<HDV>, grid, dim3(64), 0, s, qkv, q_norm_w, k_norm_w, cos_t, sin_t, \
+                       q_out, cache_k, cache_v, cu_seqlens_q, pos_offsets, block_tables, num_seqs, q_heads, kv_heads, eps, \
+                       qk_mode, max_blocks_per_seq)
+    if (head_dim == 64) FH_ROPE(64); else if (head_dim == 128) FH_ROPE(128); else FH_ROPE(256);
+#undef FH_ROPE
     FH_CHECK_LAUNCH();
     return 0;
 }

@@ -234,6 +234,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     (void)hipMemcpy(m->sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice);
     m->alloc.reset(new BlockAllocator((uint32_t)cfg->kv_num_blocks));
     if (const char* e = getenv("FERRUM_HIP_ROUTE_PARTS")) m->route_parts = std::max(1, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_FUSE_ROPE")) m->fuse_rope_attn = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_O_SLABS")) m->o_slabs = std::max(0, atoi(e));
     *model = m;
     return 0;
@@ -655,18 +656,26 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         const __half* dummy = L.input_ln;
         const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
         RUN(w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s));
-        RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
-                                                            m->cos_t, m->sin_t, m->q_out, L.k_pool, L.v_pool, cu, pos, bt,
-                                                            sh.num_seqs, T, nq, nkv, hd, c.rms_eps, qk_mode, KV_BLOCK,
-                                                            m->max_blocks_per_seq, s));
-        if (sh.pure_decode) {
-            RUN(paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, bt, kvl, sh.num_seqs,
-                                                   sh.max_kv_len, nq, nkv, hd, KV_BLOCK, m->max_blocks_per_seq,
-                                                   m->workspace, m->workspace_bytes, s));
+        if (sh.pure_decode && m->fuse_rope_attn && nq / nkv <= 14) {
+            // decode: QK-norm + RoPE + KV write happen in the attention kernel's prologue (one launch fewer)
+            RUN(paged_decode_attention_fused_qkv_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
+                                                     m->cos_t, m->sin_t, c.rms_eps, qk_mode, L.k_pool, L.v_pool, m->attn_out,
+                                                     bt, kvl, sh.num_seqs, sh.max_kv_len, nq, nkv, hd, KV_BLOCK,
+                                                     m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
         } else {
-            RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu, pos, bt, sh.num_seqs, T,
-                                           sh.max_q_len, sh.max_kv_len, nq, nkv, hd, c.sliding_window, KV_BLOCK,
-                                           m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
+            RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy,
+                                                                L.k_norm ? L.k_norm : dummy, m->cos_t, m->sin_t, m->q_out,
+                                                                L.k_pool, L.v_pool, cu, pos, bt, sh.num_seqs, T, nq, nkv, hd,
+                                                                c.rms_eps, qk_mode, KV_BLOCK, m->max_blocks_per_seq, s));
+            if (sh.pure_decode) {
+                RUN(paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, bt, kvl, sh.num_seqs,
+                                                       sh.max_kv_len, nq, nkv, hd, KV_BLOCK, m->max_blocks_per_seq,
+                                                       m->workspace, m->workspace_bytes, s));
+            } else {
+                RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu, pos, bt, sh.num_seqs, T,
+                                               sh.max_q_len, sh.max_kv_len, nq, nkv, hd, c.sliding_window, KV_BLOCK,
+                                               m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
+            }
         }
         if (c.num_experts > 0) {
             const int E = c.num_experts, K = c.top_k, P = T * K, sorted_max = P + E * 16;

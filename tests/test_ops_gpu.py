@@ -381,6 +381,49 @@ def test_paged_decode_long_context_split_kv(env):
         assert nmse(ref, got[s:s + 1]) < 1e-5
 
 
+@pytest.mark.parametrize("nq,nkv,hd,kv_lens,qk_mode", [
+    (32, 4, 128, [1, 16, 17, 257, 300, 384, 33, 250], 1), (32, 8, 128, [100, 5], 2), (8, 8, 128, [48], 3),
+    (16, 2, 128, [700, 31], 0), (4, 2, 64, [77, 64, 65], 1), (8, 2, 256, [40, 130], 1), (32, 4, 128, [4096, 1500], 1)])
+def test_paged_decode_attention_fused_qkv_equals_two_op_chain(env, nq, nkv, hd, kv_lens, qk_mode):
+    """One-launch decode (QK-norm + RoPE + KV write in the attention prologue) is bit-identical — attention output
+    AND both cache pools — to split_qkv_norm_rope_into_paged_cache_varlen + paged_batched_decode_attention."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(nq * 3 + nkv + hd + len(kv_lens) + qk_mode)
+    S = len(kv_lens)
+    max_blocks = (max(kv_lens) + 15) // 16 + 1
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 3
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used, K, V = 0, [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))      # the last slot holds stale values the step overwrites
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    ck2, cv2 = ck.clone(), cv.clone()
+    cos, sin = _rope(O, hd, max(kv_lens) + 1)
+    cosd, sind = torch.from_numpy(cos).cuda(), torch.from_numpy(sin).cuda()
+    qkv = dev16(torch, rng.standard_normal((S, (nq + 2 * nkv) * hd)))
+    qn, kn = dev16(torch, 1 + 0.1 * rng.standard_normal(hd)), dev16(torch, 1 + 0.1 * rng.standard_normal(hd))
+    td = torch.from_numpy(tables).cuda()
+    lens = torch.from_numpy(np.array(kv_lens, np.int32)).cuda()
+    q_out = torch.empty(S, nq, hd, dtype=torch.float16, device="cuda")
+    out1 = torch.empty(S, nq, hd, dtype=torch.float16, device="cuda")
+    out2 = torch.zeros_like(out1)
+    B.split_qkv_norm_rope_into_paged_cache_varlen(ctx, qkv, qn, kn, cosd, sind, q_out, ck, cv,
+                                                  torch.arange(S + 1, dtype=torch.int32, device="cuda"), lens - 1, td, S, S,
+                                                  nq, nkv, hd, 1e-6, qk_mode, 16, max_blocks)
+    B.paged_batched_decode_attention(ctx, q_out, ck, cv, out1, td, lens, S, max(kv_lens), nq, nkv, hd, 16, max_blocks)
+    B.paged_decode_attention_fused_qkv(ctx, qkv, qn, kn, cosd, sind, 1e-6, qk_mode, ck2, cv2, out2, td, lens, S, max(kv_lens),
+                                       nq, nkv, hd, 16, max_blocks)
+    ctx.sync()
+    assert torch.equal(ck, ck2) and torch.equal(cv, cv2)
+    assert torch.equal(out1, out2)
+    assert torch.isfinite(out2.float()).all()
+
+
 # ── MoE ──────────────────────────────────────────────────────────────────────
 @pytest.mark.parametrize("batch,ne,k,norm,seed", [(32, 128, 8, True, 0xDEADBEEF), (1, 128, 8, True, 0x1234),
                                                   (64, 128, 8, True, 0x5678), (8, 64, 4, False, 0xC0FFEE),
