@@ -55,13 +55,13 @@ struct AttnArgs {
 // float operations in the same order (bit-identical fp16 results).  The split that owns the last KV block
 // writes the new K/V into the paged cache and every wave patches the new token's slot into the fragments it
 // loaded from that block, so nothing depends on the visibility of the cache store inside the launch.
-template <int HD, bool FUSED_QKV>
-__global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
+template <int HD, bool FUSED_QKV, int NW>
+__global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
     constexpr int DT = HD / 16;      // output d-tiles
     constexpr int KS = HD / 32;      // QKᵀ k-steps (= 1-KiB loads per K tile = per V tile)
     constexpr int OSTRIDE = HD + 4;  // padded LDS row (floats)
-    __shared__ __attribute__((aligned(16))) float lds_o[4 * 16 * OSTRIDE];
-    __shared__ float lds_m[4 * 16], lds_l[4 * 16];
+    __shared__ __attribute__((aligned(16))) float lds_o[NW * 16 * OSTRIDE];
+    __shared__ float lds_m[NW * 16], lds_l[NW * 16];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
@@ -97,6 +97,41 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
     const int my_hi = min(pair_hi, my_lo + per_split);
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
 
+    // Block-table entries of this split are fetched once (64 per wave, re-fetched every 32 pairs) and the K/V
+    // fragments of a wave's NEXT pair are requested before the current pair is consumed, so a wave exposes one
+    // memory round trip, not one (table) + one (tiles) per pair.
+    const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
+    const long tile_elems = kv_tile_elems(HD);
+    int bt_lo = 2 * my_lo;
+    int btv = bt[min(bt_lo + lane, p.max_blocks - 1)];
+    struct Frags { half8 k0[KS], k1[KS], v0[KS], v1[KS]; };
+    auto issue = [&](int pr, Frags& f) {
+        const int blk0 = 2 * pr, blk1 = 2 * pr + 1;
+        const bool has1 = blk1 < nblocks;
+        if (blk1 - bt_lo >= 64) {                        // wave-uniform: next chunk of the table
+            bt_lo = blk0;
+            btv = bt[min(bt_lo + lane, p.max_blocks - 1)];
+        }
+        const long phys0 = __builtin_amdgcn_readlane(btv, blk0 - bt_lo);
+        const long phys1 = has1 ? __builtin_amdgcn_readlane(btv, blk1 - bt_lo) : phys0;
+        const __half* k0 = p.k_pool + (phys0 * p.nkv + kvh) * tile_elems + lane * 8;
+        const __half* k1 = p.k_pool + (phys1 * p.nkv + kvh) * tile_elems + lane * 8;
+        const __half* v0 = p.v_pool + (phys0 * p.nkv + kvh) * tile_elems + lane * 8;
+        const __half* v1 = p.v_pool + (phys1 * p.nkv + kvh) * tile_elems + lane * 8;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            f.k0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(k0 + s * 512));
+            f.k1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(k1 + s * 512));
+        }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            f.v0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v0 + s * 512));
+            f.v1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v1 + s * 512));
+        }
+    };
+    Frags cur, nxt;
+    if (my_lo + wave < my_hi) issue(my_lo + wave, cur);
+
     half8 qf[KS];
     __shared__ __attribute__((aligned(16))) __half lds_q[FUSED_QKV ? 16 * HD : 8];
     __shared__ __attribute__((aligned(16))) __half lds_kv[FUSED_QKV ? 2 * HD : 8];
@@ -107,7 +142,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
         const int q_dim = p.nq * HD, kv_dim = p.nkv * HD;
         const __half* qrow = p.qkv + (long)seq * (q_dim + 2 * kv_dim);
         const int r16 = threadIdx.x >> 4, q16 = threadIdx.x & 15;
-        const int rc = r16 < G + 2 ? r16 : G + 1;     // clamped: loads stay unconditional
+        const int rc = r16 < G + 2 ? r16 : G + 1;     // clamped: loads stay unconditional (r16 < 16·NW/4)
         const __half* src = rc < G ? qrow + (kvh * G + rc) * HD
                                    : rc == G ? qrow + q_dim + kvh * HD : qrow + q_dim + kv_dim + kvh * HD;
         const RopeRow<HD> rr = rope_row16<HD>(src, rc < G ? p.q_norm_w : p.k_norm_w, p.cos_t + (long)pos0 * HALF,
@@ -118,8 +153,10 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
 #pragma unroll
         for (int k = 0; k < HD / 32; k++) { z0[k] = (_Float16)0.f; z1[k] = (_Float16)0.f; }
         _Float16* lq = reinterpret_cast<_Float16*>(lds_q) + r16 * HD;
-        *reinterpret_cast<hv*>(lq + rr.off0) = r16 < G ? rr.out0 : z0;
-        *reinterpret_cast<hv*>(lq + rr.off1) = r16 < G ? rr.out1 : z1;
+        if (r16 < 16) {
+            *reinterpret_cast<hv*>(lq + rr.off0) = r16 < G ? rr.out0 : z0;
+            *reinterpret_cast<hv*>(lq + rr.off1) = r16 < G ? rr.out1 : z1;
+        }
         if (r16 == G || r16 == G + 1) {
             _Float16* lk = reinterpret_cast<_Float16*>(lds_kv) + (r16 - G) * HD;
             *reinterpret_cast<hv*>(lk + rr.off0) = rr.out0;
@@ -148,29 +185,13 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int dt = 0; dt < DT; dt++) o_acc[dt] = (float4v){0.f, 0.f, 0.f, 0.f};
 
-    const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
-    const long tile_elems = kv_tile_elems(HD);
 
-    for (int pr = my_lo + wave; pr < my_hi; pr += 4) {
+    for (int pr = my_lo + wave; pr < my_hi; pr += NW) {
         const int blk0 = 2 * pr, blk1 = 2 * pr + 1;
         const bool has1 = blk1 < nblocks;
-        const long phys0 = bt[blk0];
-        const long phys1 = has1 ? bt[blk1] : phys0;
-        const __half* k0 = p.k_pool + (phys0 * p.nkv + kvh) * tile_elems + lane * 8;
-        const __half* k1 = p.k_pool + (phys1 * p.nkv + kvh) * tile_elems + lane * 8;
-        const __half* v0 = p.v_pool + (phys0 * p.nkv + kvh) * tile_elems + lane * 8;
-        const __half* v1 = p.v_pool + (phys1 * p.nkv + kvh) * tile_elems + lane * 8;
-        half8 kf0[KS], kf1[KS], vf0[KS], vf1[KS];
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            kf0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(k0 + s * 512));
-            kf1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(k1 + s * 512));
-        }
-#pragma unroll
-        for (int s = 0; s < KS; s++) {
-            vf0[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v0 + s * 512));
-            vf1[s] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(v1 + s * 512));
-        }
+        if (pr + NW < my_hi) issue(pr + NW, nxt);
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch ahead of this pair's MFMAs
+        half8 (&kf0)[KS] = cur.k0, (&kf1)[KS] = cur.k1, (&vf0)[KS] = cur.v0, (&vf1)[KS] = cur.v1;
         if (FUSED_QKV && (blk0 == last_blk || blk1 == last_blk)) {
             // patch the new token's slot (key slot_new of block last_blk) into the loaded fragments
             const bool in1 = blk1 == last_blk;
@@ -242,9 +263,10 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
             for (int r = 0; r < 4; r++) o_acc[dt][r] *= alpha;
             o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf, o_acc[dt], 0, 0, 0);
         }
+        cur = nxt;
     }
 
-    // merge the 4 waves' partial states through LDS
+    // merge the NW waves' partial states through LDS
     if (a == 0) {
         lds_m[wave * 16 + b] = m_run;
         lds_l[wave * 16 + b] = l_run;
@@ -254,27 +276,28 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(AttnArgs p) {
         *reinterpret_cast<float4v*>(&lds_o[(wave * 16 + b) * OSTRIDE + dt * 16 + 4 * a]) = o_acc[dt];
     __syncthreads();
 
-    // 256 threads: thread → (row = tid/16, 8·HD/128 dims)
-    const int row = threadIdx.x >> 4, dl = threadIdx.x & 15;
-    float mw[4], M = -INFINITY;
+    // thread → (row = tid / TPR, DPT dims)
+    constexpr int TPR = NW * 4;
+    const int row = threadIdx.x / TPR, dl = threadIdx.x % TPR;
+    float mw[NW], M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { mw[w] = lds_m[w * 16 + row]; M = fmaxf(M, mw[w]); }
+    for (int w = 0; w < NW; w++) { mw[w] = lds_m[w * 16 + row]; M = fmaxf(M, mw[w]); }
     const float Ms = M == -INFINITY ? 0.f : M;
-    float fw[4], L = 0.f;
+    float fw[NW], L = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; w++) { fw[w] = __expf(mw[w] - Ms); L += lds_l[w * 16 + row] * fw[w]; }
+    for (int w = 0; w < NW; w++) { fw[w] = __expf(mw[w] - Ms); L += lds_l[w * 16 + row] * fw[w]; }
 
     const int rho_o = tile * 16 + row;
     const bool ok_o = rho_o < rows_total;
     const int t_o = ok_o ? rho_o / G : 0, g_o = ok_o ? rho_o % G : 0;
-    constexpr int DPT = HD / 16;     // dims per thread
+    constexpr int DPT = HD / TPR;    // dims per thread
     float ov[DPT];
 #pragma unroll
     for (int i = 0; i < DPT; i++) {
         int d = dl * DPT + i;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; w++) acc += lds_o[(w * 16 + row) * OSTRIDE + d] * fw[w];
+        for (int w = 0; w < NW; w++) acc += lds_o[(w * 16 + row) * OSTRIDE + d] * fw[w];
         ov[i] = acc;
     }
     if (p.nsplit > 1) {
@@ -375,9 +398,13 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
         a.k_pool_w = fq->k_pool_w; a.v_pool_w = fq->v_pool_w; a.eps = fq->eps; a.qk_mode = fq->qk_mode;
     }
     dim3 grid(tiles, num_kv_heads, nsplit);
+    // decode with ≥ 8 block pairs per split: 8 waves per workgroup (more loads in flight per CU)
+    const bool wide = max_q_len == 1 && cdiv(cdiv(max_kv_len, KV_BLOCK), 2) / nsplit >= 8 && !(getenv("FERRUM_HIP_ATTN_NARROW") && atoi(getenv("FERRUM_HIP_ATTN_NARROW")));
 #define FH_ATTN(HDV)                                                                              \
-    if (fq) hipLaunchKernelGGL((paged_attn_kernel<HDV, true>), grid, dim3(256), 0, s, a);         \
-    else hipLaunchKernelGGL((paged_attn_kernel<HDV, false>), grid, dim3(256), 0, s, a);           \
+    if (fq && wide) hipLaunchKernelGGL((paged_attn_kernel<HDV, true, 8>), grid, dim3(512), 0, s, a);       \
+    else if (fq) hipLaunchKernelGGL((paged_attn_kernel<HDV, true, 4>), grid, dim3(256), 0, s, a);          \
+    else if (wide) hipLaunchKernelGGL((paged_attn_kernel<HDV, false, 8>), grid, dim3(512), 0, s, a);       \
+    else hipLaunchKernelGGL((paged_attn_kernel<HDV, false, 4>), grid, dim3(256), 0, s, a);                 \
     FH_CHECK_LAUNCH();                                                                            \
     if (nsplit > 1) {                                                                             \
         hipLaunchKernelGGL(paged_attn_reduce_kernel<HDV>, dim3(tiles, num_kv_heads), dim3(16 * HDV / 8), 0, s, a); \
