@@ -231,8 +231,8 @@ class HipBackend:
         """Returns the m token ids on the host (traits.rs:1534); logits fp16 or fp32."""
         import torch
         out = torch.empty(m, dtype=torch.int32, device=logits.device)
-        fn = ctx.lib.ferrum_hip_argmax_rows_f32 if logits.dtype == torch.float32 else ctx.lib.ferrum_hip_argmax_rows_f16
-        _check(fn(_ptr(logits), _ptr(out), None, 0, m, n, ctx.stream), "argmax_rows")
+        fn = ctx.lib.ferrum_hip_argmax_rows_f32_ws if logits.dtype == torch.float32 else ctx.lib.ferrum_hip_argmax_rows_f16_ws
+        _check(fn(_ptr(logits), _ptr(out), None, 0, m, n, ctx.ws, ctx.stream), "argmax_rows")
         ctx.sync()
         return out.cpu().numpy().astype("uint32")
 
@@ -240,8 +240,8 @@ class HipBackend:
     def argmax_rows_f16_masked(ctx, logits, valid_token_mask, mask_len, m, n):
         import torch
         out = torch.empty(m, dtype=torch.int32, device=logits.device)
-        fn = ctx.lib.ferrum_hip_argmax_rows_f32 if logits.dtype == torch.float32 else ctx.lib.ferrum_hip_argmax_rows_f16
-        _check(fn(_ptr(logits), _ptr(out), _ptr(valid_token_mask), mask_len, m, n, ctx.stream), "argmax_rows_masked")
+        fn = ctx.lib.ferrum_hip_argmax_rows_f32_ws if logits.dtype == torch.float32 else ctx.lib.ferrum_hip_argmax_rows_f16_ws
+        _check(fn(_ptr(logits), _ptr(out), _ptr(valid_token_mask), mask_len, m, n, ctx.ws, ctx.stream), "argmax_rows_masked")
         ctx.sync()
         return out.cpu().numpy().astype("uint32")
 

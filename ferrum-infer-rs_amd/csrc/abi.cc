@@ -490,6 +490,14 @@ int ferrum_hip_argmax_rows_f16(const void* logits, uint32_t* out, const uint8_t*
 int ferrum_hip_argmax_rows_f32(const float* logits, uint32_t* out, const uint8_t* mask, int mask_len, int m, int n, void* stream) {
     return argmax_rows_f32(logits, out, mask, mask_len, m, n, ST(stream));
 }
+int ferrum_hip_argmax_rows_f16_ws(const void* logits, uint32_t* out, const uint8_t* mask, int mask_len, int m, int n,
+                                  FerrumHipWorkspace* ws, void* stream) {
+    return argmax_rows_f16_ws(CH(logits), out, mask, mask_len, m, n, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+}
+int ferrum_hip_argmax_rows_f32_ws(const float* logits, uint32_t* out, const uint8_t* mask, int mask_len, int m, int n,
+                                  FerrumHipWorkspace* ws, void* stream) {
+    return argmax_rows_f32_ws(logits, out, mask, mask_len, m, n, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+}
 int ferrum_hip_apply_repetition_penalties_sparse_f16(void* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
                                                      const float* penalties, int m, int n, void* stream) {
     return apply_repetition_penalties_sparse_f16(H(logits), row_offsets, token_ids, penalties, m, n, ST(stream));

@@ -142,6 +142,10 @@ int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residu
                                        hipStream_t s);
 
 // ── sampling (sampling.hip) ──────────────────────────────────────────────────
+int argmax_rows_f16_ws(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                       float* workspace, size_t workspace_bytes, hipStream_t s);
+int argmax_rows_f32_ws(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                       float* workspace, size_t workspace_bytes, hipStream_t s);
 int argmax_rows_f16(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                     hipStream_t s);
 int argmax_rows_f32(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,

@@ -772,7 +772,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         RUN(rms_norm_f16(m->sampled_hidden, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
         RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, c.vocab, H, m->workspace,
                              m->workspace_bytes, s));
-        if (greedy) RUN(argmax_rows_f32(m->logits, m->out_tokens, nullptr, 0, sh.num_sampled, c.vocab, s));
+        if (greedy) RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, nullptr, 0, sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, s));
     }
 #undef RUN
     return 0;

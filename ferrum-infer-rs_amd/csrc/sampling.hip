@@ -39,6 +39,90 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__
     }
 }
 
+// Two-stage form for wide rows (a vocabulary-sized row on ONE workgroup is bound by what one CU can pull, ≈25 GB/s):
+// stage 1 grid (rows, C chunks) → (value, index) partials in the workspace; stage 2 one wave per row.  Same
+// tie-break: first maximum.
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const T* __restrict__ logits, float* __restrict__ pval,
+                                                             int* __restrict__ pidx, const uint8_t* __restrict__ mask,
+                                                             int mask_len, int n, int chunk) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const long row = blockIdx.x;
+    const int c = blockIdx.y, C = gridDim.y;
+    const int lo = c * chunk, hi = min(n, lo + chunk);
+    const T* p = logits + row * n;
+    float best = -INFINITY;
+    int best_idx = 0x7fffffff;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        if (mask && (i >= mask_len || mask[i] == 0)) continue;
+        float v = (float)p[i];
+        if (v > best) { best = v; best_idx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ob = __shfl_xor(best, off, 64);
+        int oi = __shfl_xor(best_idx, off, 64);
+        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_idx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < best_idx)) { best = s_val[w]; best_idx = s_idx[w]; }
+        pval[row * C + c] = best;
+        pidx[row * C + c] = best_idx;
+    }
+}
+
+__global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
+                                                          uint32_t* __restrict__ out, int C) {
+    const long row = blockIdx.x;
+    float best = -INFINITY;
+    int best_idx = 0x7fffffff;
+    for (int c = threadIdx.x; c < C; c += 64) {
+        float v = pval[row * C + c];
+        int i = pidx[row * C + c];
+        if (v > best || (v == best && i < best_idx)) { best = v; best_idx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float ob = __shfl_xor(best, off, 64);
+        int oi = __shfl_xor(best_idx, off, 64);
+        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+    }
+    if (threadIdx.x == 0) out[row] = best_idx == 0x7fffffff ? 0u : (uint32_t)best_idx;
+}
+
+template <typename T>
+static int argmax_rows_ws(const T* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                          float* workspace, size_t workspace_bytes, hipStream_t s) {
+    if (m <= 0) return 0;
+    int C = std::min(128, std::max(1, n / 2048));
+    if (workspace == nullptr || workspace_bytes < (size_t)m * C * 8 || C < 2) {
+        hipLaunchKernelGGL(argmax_rows_kernel<T>, dim3(m), dim3(1024), 0, s, logits, out_ids, valid_mask, mask_len, n);
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
+    const int chunk = cdiv(n, C);
+    float* pval = workspace;
+    int* pidx = reinterpret_cast<int*>(workspace + (size_t)m * C);
+    hipLaunchKernelGGL(argmax_partial_kernel<T>, dim3(m, C), dim3(256), 0, s, logits, pval, pidx, valid_mask, mask_len, n, chunk);
+    FH_CHECK_LAUNCH();
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(m), dim3(64), 0, s, pval, pidx, out_ids, C);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+int argmax_rows_f16_ws(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                       float* workspace, size_t workspace_bytes, hipStream_t s) {
+    return argmax_rows_ws(logits, out_ids, valid_mask, mask_len, m, n, workspace, workspace_bytes, s);
+}
+int argmax_rows_f32_ws(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                       float* workspace, size_t workspace_bytes, hipStream_t s) {
+    return argmax_rows_ws(logits, out_ids, valid_mask, mask_len, m, n, workspace, workspace_bytes, s);
+}
+
 int argmax_rows_f16(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                     hipStream_t s) {
     if (m <= 0) return 0;

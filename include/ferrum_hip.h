@@ -246,6 +246,12 @@ int ferrum_hip_argmax_rows_f16(const void* logits, uint32_t* out_ids_dev, const 
                                int mask_len, int m, int n, void* stream);
 int ferrum_hip_argmax_rows_f32(const float* logits, uint32_t* out_ids_dev, const uint8_t* valid_token_mask,
                                int mask_len, int m, int n, void* stream);
+/* Same result with a workspace (≥ m·1 KiB): vocabulary-wide rows are split over up to 128 workgroups per row and
+ * merged by a second launch (a single workgroup per row is bound by one CU's fetch rate).  ws = NULL → one launch. */
+int ferrum_hip_argmax_rows_f16_ws(const void* logits, uint32_t* out_ids_dev, const uint8_t* valid_token_mask,
+                                  int mask_len, int m, int n, FerrumHipWorkspace* ws, void* stream);
+int ferrum_hip_argmax_rows_f32_ws(const float* logits, uint32_t* out_ids_dev, const uint8_t* valid_token_mask,
+                                  int mask_len, int m, int n, FerrumHipWorkspace* ws, void* stream);
 int ferrum_hip_apply_repetition_penalties_sparse_f16(void* logits, const uint32_t* row_offsets,
                                                      const uint32_t* token_ids, const float* penalties, int m,
                                                      int n, void* stream);

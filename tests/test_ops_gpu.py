@@ -702,6 +702,18 @@ def test_argmax_rows_first_max_and_mask(env):
     masked[:, 777] = -np.inf
     masked[:, mask_len:] = -np.inf
     assert np.array_equal(got, O.argmax_rows(masked))
+    # single-launch entry point (no workspace) and an all -inf row (→ id 0 on both paths)
+    logits[3, :] = -np.inf
+    ld = torch.from_numpy(logits).cuda()
+    out = torch.empty(m, dtype=torch.int32, device="cuda")
+    import ctypes
+    assert ctx.lib.ferrum_hip_argmax_rows_f32(ctypes.c_void_p(ld.data_ptr()), ctypes.c_void_p(out.data_ptr()), None, 0, m, n,
+                                              ctx.stream) == 0
+    ctx.sync()
+    ref = O.argmax_rows(logits)
+    assert ref[3] == 0
+    assert np.array_equal(out.cpu().numpy().astype(np.uint32), ref)
+    assert np.array_equal(B.argmax_rows_f16(ctx, ld, m, n), ref)
 
 
 def test_sparse_repetition_penalty_then_argmax(env):
