@@ -26,6 +26,10 @@ if ROOT not in sys.path:
 QWEN3_30B_A3B = dict(num_layers=48, hidden=2048, num_heads=32, num_kv_heads=4, head_dim=128, intermediate=0,
                      vocab=151936, has_qk_norm=1, activation=0, num_experts=128, top_k=8, expert_inter=768,
                      norm_topk_prob=1, rms_eps=1e-6, rope_theta=1e6)
+LLAMA31_8B = dict(num_layers=32, hidden=4096, num_heads=32, num_kv_heads=8, head_dim=128, intermediate=14336,
+                  vocab=128256, has_qk_norm=0, activation=0, num_experts=0, top_k=0, expert_inter=0, norm_topk_prob=0,
+                  rms_eps=1e-5, rope_theta=5e5)
+MODELS = {"qwen3-30b-a3b": QWEN3_30B_A3B, "llama31-8b": LLAMA31_8B}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -126,6 +130,8 @@ def main():
     ap.add_argument("--concurrency", type=int, default=32)
     ap.add_argument("--prompt-len", type=int, default=256)
     ap.add_argument("--layers", type=int, default=0, help="debug: fewer layers (result is then NOT the metric)")
+    ap.add_argument("--model", default="qwen3-30b-a3b", choices=sorted(MODELS),
+                    help="default = BASELINE.json's metric config; llama31-8b = configs[1] (dense), reported as an extra workload")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -146,7 +152,8 @@ def main():
     import __graft_entry__ as ge
     pkg = ge.load_package()
     pkg.load_library()
-    cfg = dict(QWEN3_30B_A3B)
+    cfg = dict(MODELS[args.model])
+    moe = cfg["num_experts"] > 0
     c, K, W, PL = args.concurrency, args.steps, args.warmup, args.prompt_len
     max_seq_len = ((PL + W + K + 8 + 15) // 16) * 16
     chunk = 2048
@@ -189,7 +196,8 @@ def main():
     if rank == 0:
         # dominant kernel: MoE gate_up grouped INT4 GEMM — live HIP-event timing on the runner's stream
         kernels = {}
-        for name in ("moe_gate_up", "moe_down", "attention", "qkv", "o", "lm_head"):
+        mlp_names = ("moe_gate_up", "moe_down") if moe else ("gate_up", "down")
+        for name in mlp_names + ("attention", "qkv", "o", "lm_head"):
             us, blocks = model.time_kernel(name, c, kv_end, reps=3)
             entry = {"avg_us": round(us, 2)}
             if name.startswith("moe"):
@@ -199,24 +207,27 @@ def main():
                 mean_kv = kv_end - 0.5
                 b = int(c * mean_kv * cfg["num_kv_heads"] * cfg["head_dim"] * 2 * 2 + 2 * c * cfg["num_heads"] * cfg["head_dim"] * 2)
                 entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
-            elif name in ("qkv", "o"):
-                kk, nn = (cfg["hidden"], (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * cfg["head_dim"]) if name == "qkv" \
-                    else (cfg["num_heads"] * cfg["head_dim"], cfg["hidden"])
+            elif name in ("qkv", "o", "gate_up", "down"):
+                kk, nn = {"qkv": (cfg["hidden"], (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * cfg["head_dim"]),
+                          "o": (cfg["num_heads"] * cfg["head_dim"], cfg["hidden"]),
+                          "gate_up": (cfg["hidden"], 2 * cfg["intermediate"]),
+                          "down": (cfg["intermediate"], cfg["hidden"])}[name]
                 b = kk * nn // 2 + (kk // 128) * nn * 2 + c * (kk + nn) * 2
                 entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
             else:
                 b = cfg["vocab"] * cfg["hidden"] * 2 + c * cfg["vocab"] * 4
                 entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
             kernels[name] = entry
-        dom = kernels["moe_gate_up"]
-        extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_kernel<1,false,2> (MoE gate_up INT4 grouped GEMM + silu*mul)",
+        dom = kernels[mlp_names[0]]
+        extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_kernel<1,false,2> (MoE gate_up INT4 grouped GEMM + silu*mul)" if moe
+                             else "w4_gemm dense gate_up INT4 GEMM",
                              "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
                              "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"]}
         extra["kernels"] = kernels
         # whole-step roofline: weights touched + KV + lm_head per step
         L = model.cfg.num_layers
-        step_bytes = L * (kernels["moe_gate_up"]["bytes"] + kernels["moe_down"]["bytes"] + kernels["attention"]["bytes"] +
+        step_bytes = L * (kernels[mlp_names[0]]["bytes"] + kernels[mlp_names[1]]["bytes"] + kernels["attention"]["bytes"] +
                           kernels["qkv"]["bytes"] + kernels["o"]["bytes"]) + kernels["lm_head"]["bytes"]
         extra["step_roofline"] = {"bytes_per_step": int(step_bytes), "achieved_gbs": round(step_bytes / (t_max / K) / 1e9, 1),
                                   "frac": round(step_bytes / (t_max / K) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -248,20 +259,26 @@ def main():
         # BASELINE.md's published c=32 number for this model (RTX 4090, ferrum 0.7.7 gate, `ferrum bench-serve`: output
         # tokens over the whole 256-in/128-out run, i.e. prefill included).  `value` is the decode-loop rate BASELINE.md
         # line 52 defines; `e2e_tok_s` is the serve-like form (prefill of all prompts + 128 decode steps) for a like-for-like ratio.
-        ref_c32 = 706.0
+        ref_c32 = 706.0 if moe else 745.6
         if c in prefill_ms:
             e2e = world * c * 128 / (prefill_ms[c] / 1e3 + 128 * t_max / K)
             extra["e2e_tok_s"] = round(e2e, 1)
             extra["e2e_vs_baseline"] = round(e2e / ref_c32, 2)
-        extra["baseline"] = {"value": ref_c32, "unit": "tok/s", "hardware": "1x RTX 4090 (reference CUDA lane)",
-                             "source": "BASELINE.md table row 'Qwen3-30B-A3B-GPTQ-Int4 output tok/s (0.7.7 gate)', c=32"}
-        line = {"metric": "output tok/s at c=32, Qwen3-30B-A3B GPTQ-INT4 (256-in/128-out decode)", "value": round(value, 1),
+        if moe:
+            extra["baseline"] = {"value": ref_c32, "unit": "tok/s", "hardware": "1x RTX 4090 (reference CUDA lane)",
+                                 "source": "BASELINE.md table row 'Qwen3-30B-A3B-GPTQ-Int4 output tok/s (0.7.7 gate)', c=32"}
+        is_metric = args.model == "qwen3-30b-a3b" and c == 32 and model.cfg.num_layers == cfg["num_layers"]
+        mname = {"qwen3-30b-a3b": "Qwen3-30B-A3B", "llama31-8b": "Llama-3.1-8B"}[args.model]
+        if args.model == "llama31-8b":
+            extra["baseline"] = {"value": 745.6, "unit": "tok/s", "hardware": "1x RTX 4090 (reference CUDA lane)",
+                                 "source": "BASELINE.md row 'Llama-3.1-8B-Instruct-GPTQ-INT4 output tok/s', c=32"}
+        line = {"metric": f"output tok/s at c={c}, {mname} GPTQ-INT4 (256-in/128-out decode)", "value": round(value, 1),
                 "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(t_max / K * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": round(value / ref_c32, 2) if c == 32 and model.cfg.num_layers == cfg["num_layers"] else None,
+                "vs_baseline": round(value / ref_c32, 2) if is_metric else None,
                 "dtype": "int4-weights/f16-activations/f32-accumulate",
                 "data": "synthetic",
-                "config": {"workload": "Qwen3-30B-A3B GPTQ-INT4 (BASELINE configs[2]), TP=1 per GPU, replicas across GPUs",
+                "config": {"workload": f"{mname} GPTQ-INT4 (BASELINE configs[{2 if moe else 1}]), TP=1 per GPU, replicas across GPUs",
                            "concurrency": c, "prompt_len": PL, "kv_len_range": [PL + W, PL + W + K], "kv_block": 16,
                            "layers": model.cfg.num_layers, "parallelism": f"replica x{world}"}}
         line.update(extra)

@@ -982,12 +982,15 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
                                                           c.head_dim, KV_BLOCK, m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s);
         case 3: return w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s);
         case 4: return w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s);
+        case 6: return w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s);
+        case 7: return w4_gemm_dense(L.down, m->act_out, m->mlp_out, T, m->workspace, m->workspace_bytes, s);
         case 5: return f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, T, c.vocab, H, m->workspace, m->workspace_bytes, s);
         }
         fh::set_error("time_kernel: which=%d", which);
         return FERRUM_HIP_INVALID;
     };
     FH_REQUIRE(which >= 2 || E > 0, "time_kernel: MoE kernel on a dense model");
+    FH_REQUIRE(which < 6 || E == 0, "time_kernel: dense MLP kernel on a MoE model");
     // warm-up round (code objects, TLBs), then the timed rounds
     for (int li = 0; li < c.num_layers && !rc; li++) rc = one(li);
     if (rc) return rc;

@@ -599,6 +599,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, OutT* __
     out[(long)row * ldo + col] = (OutT)s;
 }
 
+__global__ void splitk_reduce_bias_kernel(const float* __restrict__ partial, __half* __restrict__ out,
+                                          const __half* __restrict__ bias, int S, int M, int N, int rows_pad, int n_pad,
+                                          int ldo) {
+    int col = blockIdx.x * blockDim.x + threadIdx.x;
+    int row = blockIdx.y;
+    if (col >= N || row >= M) return;
+    float s = 0.f;
+    for (int z = 0; z < S; z++) s += partial[((long)z * rows_pad + row) * n_pad + col];
+    if (bias) s += __half2float(bias[col]);
+    out[(long)row * ldo + col] = __float2half(s);
+}
 
 // ── dense skinny GEMM, K split ACROSS THE WAVES of one workgroup ─────────────────────────────────
 // The small projections of the decode layer (qkv, o) are latency-bound: a slab split-K needs a second
@@ -697,6 +708,158 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) 
     }
 }
 
+// ── dense GEMM for 17–64 rows: activations staged ONCE per workgroup in LDS ───────────────────────
+// With MT ≥ 2 row tiles a wave that fetches its own A fragments pulls 2–4× more activation bytes (from L2)
+// than weight bytes (from HBM) and the kernel runs at the activation rate (gate_up 4096→28672: 12.6 µs at
+// m = 1, 25.7 µs at m = 32).  Here the NW waves of a workgroup own NW neighbouring 64-column supertiles over
+// the SAME K range: each 128-k group's activations (MT·4 KiB, fragment-major) are loaded cooperatively into
+// a double-buffered LDS tile and every wave reads its MFMA A fragments with conflict-free ds_read_b128.
+// One barrier per group.  K may be split over grid.z into fp32 slabs (reduced by the consumer kernel).
+template <int MT, int NW, bool HAS_ZP>
+__global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][MT·4][64] half8
+    constexpr int FR = MT * 256;                                // 16-byte fragments per group
+    constexpr int NT_ = NW * 64;
+    constexpr int ALD = (FR + NT_ - 1) / NT_;                   // fragment loads per thread per group
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int st_raw = blockIdx.x * NW + wave;
+    const bool st_ok = st_raw < p.n64;
+    const int st = st_ok ? st_raw : p.n64 - 1;
+    const int rb = blockIdx.y, z = blockIdx.z;
+    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+
+    // cooperative A loads: fragment idx ↔ (mt, k-step s, lane l): row mt·16 + (l & 15), k = 32 s + 8 (l >> 4)
+    const __half* asrc[ALD];
+#pragma unroll
+    for (int i = 0; i < ALD; i++) {
+        const int idx = min(threadIdx.x + i * NT_, FR - 1);
+        const int mt = idx >> 8, s = (idx >> 6) & 3, l = idx & 63;
+        const int r = rb * 16 * MT + mt * 16 + (l & 15);
+        asrc[i] = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + 32 * s + 8 * (l >> 4);
+    }
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp) + ((long)st * p.G) * 16 + b : nullptr;
+
+    float4v acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    // Rings of depth 4 (static slots through a 4× unrolled loop): weights of group g+3 and activations of
+    // group g+3 are requested while group g is consumed, so one workgroup alone keeps ≈3 groups × NW × 4 KiB
+    // in flight (a CU needs ≈48 KB in flight to hold its share of HBM at ≈2 µs latency).
+    constexpr int D = 4;
+    u32x4g wq[D][4];
+    uint2 scv[D], zpv[D];
+    half8 areg[D][ALD];
+    auto issue_w = [&](int slot, int g) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[slot] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[slot] = zp_lane[(long)g * 16];
+    };
+    auto issue_a = [&](int slot, int g) {
+#pragma unroll
+        for (int i = 0; i < ALD; i++) areg[slot][i] = *reinterpret_cast<const half8*>(asrc[i] + (long)g * 128);
+    };
+    auto store_a = [&](int slot, int buf) {
+#pragma unroll
+        for (int i = 0; i < ALD; i++) {
+            const int idx = threadIdx.x + i * NT_;
+            if (idx < FR) lds_a[buf * FR + idx] = areg[slot][i];
+        }
+    };
+    auto consume = [&](int slot, int abuf) {
+        half8 af[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) af[mt][s] = lds_a[abuf * FR + (mt * 4 + s) * 64 + lane];
+        const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
+        w4_consume_group<MT, 4, HAS_ZP>(wq[slot], sb, zb, 0, af, acc);
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    // No load sits under a runtime condition in the steady loop (a conditional load makes hipcc wait vmcnt(0) at
+    // the join and every group then pays the full memory latency): prefetch indices are CLAMPED to the last group
+    // instead — the few repeated requests at the tail hit L2.
+    if (g0 < g1) {
+        const int gl = g1 - 1;
+#pragma unroll
+        for (int d = 0; d < D - 1; d++) { issue_w(d, min(g0 + d, gl)); issue_a(d, min(g0 + d, gl)); }
+        FH_PIN();
+        store_a(0, 0);                                  // A(g0) → LDS buffer 0
+        __syncthreads();
+        int gb = g0;
+        for (; gb + D <= g1; gb += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int g = gb + d;
+                issue_w((d + D - 1) % D, min(g + D - 1, gl));
+                issue_a((d + D - 1) % D, min(g + D - 1, gl));
+                store_a((d + 1) % D, (d + 1) & 1);      // A(g+1), requested two groups ago
+                FH_PIN();
+                consume(d, d & 1);
+                FH_PIN();
+                __syncthreads();
+            }
+        }
+        // tail: ≤ 3 groups, already requested (slots 0..2 relative to gb)
+#pragma unroll
+        for (int d = 0; d < D - 1; d++) {
+            if (gb + d < g1) {
+                if (d + 1 < D - 1) store_a(d + 1, (d + 1) & 1);
+                consume(d, d & 1);
+                __syncthreads();
+            }
+        }
+    }
+#undef FH_PIN
+    if (!st_ok) return;
+    if (p.partial) {
+        float* slab = p.partial + (long)z * p.rows_pad * p.n_pad;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) slab[(long)row * p.n_pad + st * 64 + nt * 16 + b] = acc[mt][nt][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int col = st * 64 + nt * 16 + b;
+                if (col < p.N) {
+                    float v = acc[mt][nt][r];
+                    if (p.bias) v += __half2float(p.bias[col]);
+                    p.out[(long)row * p.ldo + col] = __float2half(v);
+                }
+            }
+        }
+}
+
+template <int MT, int NW>
+static int launch_ldsa(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)2 * MT * 256 * 16;
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_ldsa_kernel<MT, NW, true>), grid, dim3(NW * 64), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_ldsa_kernel<MT, NW, false>), grid, dim3(NW * 64), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int MT, int NT>
 static int launch_wgsplit(const W4Args& a, bool has_zp, dim3 grid, int W, hipStream_t stream) {
     size_t lds = (size_t)W * MT * NT * 4 * 64 * sizeof(float);
@@ -731,13 +894,40 @@ static int launch_w4_slabs(const W4Args& a, int mt, bool has_zp, dim3 grid, hipS
 // Dense y[M,N] = x[M,K]·Wᵀ (+bias).  One launch: K is split across the waves of each workgroup.
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
-    (void)workspace; (void)workspace_bytes;
     if (m <= 0) return 0;
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp; a.bias = w.bias;
     a.x = x; a.out = out; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n; a.S = 1;
     const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
     const int row_blocks = cdiv(m, 16 * mt);
+    // LDS-shared activations (w4_gemm_ldsa_kernel) + fp32 split-K slabs + one reduce launch.  Measured at m = 32 against
+    // the one-launch intra-workgroup split below (tools/exp_dense.py): down 14336→4096 31.3 → 18.4 µs (S = 8),
+    // gate_up 4096→28672 25.7 → 23.2 µs (S = 2); the small projections (qkv, o) tie, so they keep the single launch.
+    static const int lds_mode = getenv("FERRUM_HIP_W4_LDSA") ? atoi(getenv("FERRUM_HIP_W4_LDSA")) : 1;
+    const bool lds_shape = (w.G >= 64 && w.n64 >= 32) || w.n64 >= 256;
+    if (mt >= 2 && w.perm == nullptr && (lds_mode == 2 || (lds_mode == 1 && lds_shape && mt == 2))) {
+        int nw = 4;
+        if (const char* e = getenv("FERRUM_HIP_W4_LDSA_NW")) nw = atoi(e) == 8 && mt == 2 ? 8 : 4;
+        const int cols = cdiv(w.n64, nw);
+        int S = 1;
+        while ((long)cols * row_blocks * S < 128 && w.G / (S * 2) >= 8) S *= 2;
+        if (const char* e = getenv("FERRUM_HIP_W4_LDSA_S")) S = std::max(1, std::min(atoi(e), w.G));
+        const int rows_pad = row_blocks * 16 * mt, n_pad = w.n64 * 64;
+        if (S > 1 && (workspace == nullptr || (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes)) S = 1;
+        a.S = S;
+        a.rows_pad = rows_pad; a.n_pad = n_pad;
+        a.partial = S > 1 ? workspace : nullptr;
+        dim3 grid(cols, row_blocks, S);
+        const bool zp = w.zp != nullptr;
+        int rc;
+        if (mt == 2) rc = nw == 8 ? launch_ldsa<2, 8>(a, zp, grid, stream) : launch_ldsa<2, 4>(a, zp, grid, stream);
+        else rc = launch_ldsa<4, 4>(a, zp, grid, stream);      // MT = 4 with 8 waves would exceed 256 VGPRs per lane
+        if (rc || S == 1) return rc;
+        hipLaunchKernelGGL(splitk_reduce_bias_kernel, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, w.bias, S, m,
+                           w.n, rows_pad, n_pad, w.n);
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
     const int n16 = w.n64 * 4;
     // column tiles per workgroup: as wide as possible (A-fragment reuse) while ≥ ~384 workgroups exist
     int nt = 4;
