@@ -219,10 +219,14 @@ def main():
                 entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
             kernels[name] = entry
         dom = kernels[mlp_names[0]]
+        traffic = None                                          # HBM bytes per launch from the committed PMC passes
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic_gate_up.json")
+        if moe and c == 32 and os.path.exists(tp):
+            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
         extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_kernel<1,false,2> (MoE gate_up INT4 grouped GEMM + silu*mul)" if moe
                              else "w4_gemm dense gate_up INT4 GEMM",
                              "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                              "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"]}
         extra["kernels"] = kernels
         # whole-step roofline: weights touched + KV + lm_head per step
