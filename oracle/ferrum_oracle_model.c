@@ -95,6 +95,9 @@ typedef struct {
     /* debug taps: last call's hidden state after each layer [L][T][H] (optional) */
     float *tap_hidden;
     int tap_tokens;
+    /* test aid: smallest k-th / (k+1)-th router-logit gap over the layers and tokens of the last call — lets a
+     * parity test tell a routing near-tie (a legitimately different expert pick) from an arithmetic error */
+    float last_route_gap;
 } fo_model;
 
 static float *fo_dup(const float *src, long n) {
@@ -222,6 +225,21 @@ FO_API void fo_model_enable_taps(fo_model *m, int max_tokens) {
     m->tap_tokens = max_tokens;
 }
 FO_API const float *fo_model_taps(fo_model *m) { return m->tap_hidden; }
+FO_API float fo_model_last_route_gap(const fo_model *m) { return m->last_route_gap; }
+
+/* gap between the k-th and (k+1)-th largest of n logits (n > k) */
+static float fo_topk_gap(const float *l, int n, int k) {
+    float *tmp = (float *)malloc(sizeof(float) * n);
+    memcpy(tmp, l, sizeof(float) * n);
+    for (int i = 0; i <= k && i < n; i++) {           /* partial selection sort, descending */
+        int best = i;
+        for (int j = i + 1; j < n; j++) if (tmp[j] > tmp[best]) best = j;
+        float t = tmp[i]; tmp[i] = tmp[best]; tmp[best] = t;
+    }
+    float gap = k < n ? tmp[k - 1] - tmp[k] : INFINITY;
+    free(tmp);
+    return gap;
+}
 
 /* One forward over `tokens` for sequence `cache_id` starting at pos_offset
  * (must equal the cache length).  logits_out [vocab] receives the logits of
@@ -232,6 +250,7 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
     fo_kv *cache = fo_get_cache(m, cache_id);
     if (cache->len != pos_offset) return -2;
     if (pos_offset + n_tokens > g->max_seq_len) return -3;
+    m->last_route_gap = INFINITY;
     int T = n_tokens, H = g->hidden, nh = g->num_heads, nkv = g->num_kv_heads, hd = g->head_dim;
     int q_dim = nh * hd, kv_dim = nkv * hd, qkv_dim = q_dim + 2 * kv_dim;
     int I = g->intermediate;
@@ -294,6 +313,10 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
         if (g->num_experts > 0) {
             fo_gemm(norm_out, L->router_w, router_logits, T, g->num_experts, H);
             fo_route_topk(router_logits, T, g->num_experts, g->top_k, g->norm_topk_prob, eids, ew);
+            for (int t = 0; t < T; t++) {
+                float gap = fo_topk_gap(router_logits + (long)t * g->num_experts, g->num_experts, g->top_k);
+                if (gap < m->last_route_gap) m->last_route_gap = gap;
+            }
             fo_moe_forward_cpu(norm_out, T, H, g->expert_inter, g->top_k, eids, ew,
                                L->exp_gate_up_w, L->exp_down_w, mlp_out);
         } else {

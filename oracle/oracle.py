@@ -117,6 +117,8 @@ def _declare(l):
     l.fo_model_enable_taps.argtypes = [C.c_void_p, C.c_int]
     l.fo_model_taps.restype = C.POINTER(C.c_float)
     l.fo_model_taps.argtypes = [C.c_void_p]
+    l.fo_model_last_route_gap.restype = C.c_float
+    l.fo_model_last_route_gap.argtypes = [C.c_void_p]
     l.fo_model_forward.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int,
                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
 
@@ -515,6 +517,10 @@ class OracleModel:
         out = np.zeros((n, self.cfg.num_kv_heads, self.cfg.head_dim), np.float32)
         lib().fo_model_read_kv(self._h, cache_id, layer, int(is_v), _f(out))
         return out
+
+    def last_route_gap(self):
+        """Smallest k-th/(k+1)-th router-logit gap over the last forward's layers and tokens (inf for dense models)."""
+        return float(lib().fo_model_last_route_gap(self._h))
 
     def enable_taps(self, max_tokens):
         self._tap_tokens = max_tokens

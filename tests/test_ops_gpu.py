@@ -477,7 +477,8 @@ def test_moe_align_block_size_bit_exact(env, tokens, ne, k):
     assert np.array_equal(bd.cpu().numpy()[:len(rb)], rb)
 
 
-@pytest.mark.parametrize("tokens,E,K,H,I", [(1, 8, 2, 256, 128), (9, 8, 2, 256, 128), (32, 16, 4, 512, 256)])
+@pytest.mark.parametrize("tokens,E,K,H,I", [(1, 8, 2, 256, 128), (9, 8, 2, 256, 128), (32, 16, 4, 512, 256),
+                                            (32, 128, 8, 2048, 768), (96, 128, 8, 2048, 768)])   # Qwen3-30B-A3B expert dims
 def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
     # whole expert MLP path vs moe_forward_cpu (dispatch.rs:2208-2288), plain and fused-silu stacks
     pkg, B, ctx, O, torch = env
