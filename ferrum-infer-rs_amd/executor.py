@@ -54,7 +54,91 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class Checkpoint:
+    """Checkpoint directory reader over `ferrum_hip_checkpoint_*` (the C++ mirror of NativeSafetensorsLoader,
+    ferrum-quantization/src/native_safetensors.rs:130-330,887-1000, and of the config.json mapping)."""
+
+    def __init__(self, model_dir):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        _check(self.lib.ferrum_hip_checkpoint_open(C.byref(self.h), str(model_dir).encode()), "checkpoint_open")
+
+    def close(self):
+        if self.h:
+            self.lib.ferrum_hip_checkpoint_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def num_tensors(self):
+        return int(self.lib.ferrum_hip_checkpoint_num_tensors(self.h))
+
+    def tensor_info(self, name):
+        dt, nd = C.c_int(), C.c_int()
+        shape = (C.c_int64 * 4)()
+        _check(self.lib.ferrum_hip_checkpoint_tensor_info(self.h, name.encode(), C.byref(dt), C.byref(nd), shape), "tensor_info")
+        return ("F32", "F16", "BF16", "I32", "I64", "other")[dt.value], tuple(shape[:nd.value])
+
+    def read_f32(self, name):
+        _, shape = self.tensor_info(name)
+        out = np.empty(shape, np.float32)
+        _check(self.lib.ferrum_hip_checkpoint_read_f32(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_float)),
+                                                       C.c_size_t(out.size)), "read_f32")
+        return out
+
+    def read_i32(self, name):
+        _, shape = self.tensor_info(name)
+        out = np.empty(shape, np.int32)
+        _check(self.lib.ferrum_hip_checkpoint_read_i32(self.h, name.encode(), out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                       C.c_size_t(out.size)), "read_i32")
+        return out
+
+    def quant_config(self):
+        v = [C.c_int() for _ in range(5)]
+        _check(self.lib.ferrum_hip_checkpoint_quant_config(self.h, *[C.byref(x) for x in v]), "quant_config")
+        return dict(zip(("is_gptq", "bits", "group_size", "desc_act", "sym"), (x.value for x in v)))
+
+    def read_gptq_fused(self, parts):
+        arr = (C.c_char_p * len(parts))(*[p.encode() for p in parts])
+        k, n, hg = C.c_int(), C.c_int(), C.c_int()
+        fn = self.lib.ferrum_hip_checkpoint_read_gptq_fused
+        _check(fn(self.h, arr, len(parts), None, None, None, None, C.byref(k), C.byref(n), C.byref(hg)), "read_gptq_fused")
+        g = self.quant_config()["group_size"]
+        K, N = k.value, n.value
+        qw, sc = np.empty((K // 8, N), np.int32), np.empty((K // g, N), np.float32)
+        qz, gi = np.empty((K // g, N // 8), np.int32), np.empty(K, np.int32)
+        p = C.POINTER(C.c_int32)
+        _check(fn(self.h, arr, len(parts), qw.ctypes.data_as(p), sc.ctypes.data_as(C.POINTER(C.c_float)), qz.ctypes.data_as(p),
+                  gi.ctypes.data_as(p), None, None, None), "read_gptq_fused")
+        return qw, sc, qz, (gi if hg.value else None), K, N
+
+    def model_config(self, max_seq_len_cap=0):
+        cfg = ModelConfig()
+        arch = C.create_string_buffer(128)
+        tied = C.c_int()
+        _check(self.lib.ferrum_hip_checkpoint_model_config(self.h, max_seq_len_cap, C.byref(cfg), arch, C.c_size_t(128),
+                                                           C.byref(tied)), "checkpoint_model_config")
+        d = {f: getattr(cfg, f) for f, _ in ModelConfig._fields_ if f != "_pad"}
+        return d, arch.value.decode(), bool(tied.value)
+
+
 class HipModel:
+    @classmethod
+    def from_checkpoint(cls, model_dir, kv_num_blocks, max_seqs, max_tokens, max_seq_len=0):
+        """Create → load every tensor with the reference's names and fusions → finalize."""
+        ck = Checkpoint(model_dir)
+        d, _, _ = ck.model_config(max_seq_len)
+        d.update(kv_num_blocks=kv_num_blocks, max_seqs=max_seqs, max_tokens=max_tokens)
+        m = cls(**d)
+        _check(m.lib.ferrum_hip_model_load_checkpoint(m.h, ck.h), "model_load_checkpoint")
+        m.finalize()
+        ck.close()
+        return m
+
     def __init__(self, **kw):
         self.lib = load_library()
         self.cfg = ModelConfig()

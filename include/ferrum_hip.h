@@ -336,6 +336,35 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* model, int layer, int which, int e
 int ferrum_hip_model_init_synthetic(FerrumHipModel* model, uint64_t seed);
 int ferrum_hip_model_finalize(FerrumHipModel* model);
 
+/* ── checkpoint reader (host only): safetensors shards + HF config.json + GPTQ quantize config, with the reference
+ *    loader's semantics — shard index (ferrum-quantization/src/native_safetensors.rs:142-195), f32/f16/bf16 → f32 and raw
+ *    i32 reads (:197-330), fused GPTQ linears q|k|v → qkv and gate|up → gate_up (:887-1000) with symmetric-4-bit qzeros
+ *    canonicalised to 0x77777777 (:1242-1246) and g_idx validation (:1288-1324), quantize_config.json or config.json
+ *    "quantization_config" (:1475-1530), config.json mapping (ferrum-models/src/definition.rs:225-375,
+ *    models/llama_family.rs:596-680,733-810, moe_config.rs:91-130), tensor names (llama_family.rs:900-945,
+ *    qwen3_moe/load.rs:178-260).  Architectures: Llama, Mistral, Qwen3, Qwen3-MoE; others → FERRUM_HIP_UNSUPPORTED. ── */
+typedef struct FerrumHipCheckpoint FerrumHipCheckpoint;
+int ferrum_hip_checkpoint_open(FerrumHipCheckpoint** ck, const char* model_dir);
+int ferrum_hip_checkpoint_close(FerrumHipCheckpoint* ck);
+int ferrum_hip_checkpoint_num_tensors(const FerrumHipCheckpoint* ck);
+/* dtype: 0 F32, 1 F16, 2 BF16, 3 I32, 4 I64, 5 other; shape4 padded with 1 */
+int ferrum_hip_checkpoint_tensor_info(const FerrumHipCheckpoint* ck, const char* name, int* dtype, int* ndim, int64_t* shape4);
+int ferrum_hip_checkpoint_read_f32(const FerrumHipCheckpoint* ck, const char* name, float* out, size_t capacity);
+int ferrum_hip_checkpoint_read_i32(const FerrumHipCheckpoint* ck, const char* name, int32_t* out, size_t capacity);
+int ferrum_hip_checkpoint_quant_config(const FerrumHipCheckpoint* ck, int* is_gptq, int* bits, int* group_size, int* desc_act,
+                                       int* sym);
+/* Fused GPTQ read of tensor-name stems (e.g. "model.layers.0.self_attn.q_proj", "…k_proj", "…v_proj").  Call with null
+ * buffers for k / n / has_g_idx, then with qweight [k/8·n], scales [k/group·n], qzeros [k/group·n/8], g_idx [k]. */
+int ferrum_hip_checkpoint_read_gptq_fused(const FerrumHipCheckpoint* ck, const char* const* parts, int num_parts,
+                                          int32_t* qweight, float* scales, int32_t* qzeros, int32_t* g_idx, int* k, int* n,
+                                          int* has_g_idx);
+/* config.json → architecture fields of the runner config (kv_num_blocks / max_seqs / max_tokens stay 0 for the caller);
+ * max_seq_len = min(max_position_embeddings, cap) (cap 0 = none); tied_lm_head = no lm_head.weight tensor. */
+int ferrum_hip_checkpoint_model_config(const FerrumHipCheckpoint* ck, int max_seq_len_cap, FerrumHipModelConfig* cfg,
+                                       char* arch_out, size_t arch_cap, int* tied_lm_head);
+/* Hand every weight to a created, not yet finalized model (dimensions from ferrum_hip_checkpoint_model_config). */
+int ferrum_hip_model_load_checkpoint(FerrumHipModel* model, const FerrumHipCheckpoint* ck);
+
 /* ModelExecutor::reserve_kv_slots (model_executor.rs:484): allocate physical blocks so every
  * requested sequence can hold target_len tokens; atomic — on exhaustion nothing is taken and
  * FERRUM_HIP_INVALID is returned. */

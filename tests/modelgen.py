@@ -90,6 +90,136 @@ class TinyModel:
         return m
 
 
+def write_checkpoint(tm, out_dir, arch, shards=1, fused_names=False, dense_dtype="F16", embedded_quant_config=False,
+                     qzeros_noise=False):
+    """Write a TinyModel as an HF-style GPTQ checkpoint directory: config.json, quantize_config.json (or the embedded
+    "quantization_config"), model.safetensors or an index + shards.  qkv / gate_up are split into q|k|v and gate|up parts
+    like real checkpoints unless fused_names.  Tensor names as the reference reads them (llama_family.rs:900-945,
+    qwen3_moe/load.rs:178-260)."""
+    import json
+    import os
+    from safetensors.numpy import save_file
+    c = tm.cfg
+    H, nq, nkv, hd = c["hidden"], c["num_heads"], c["num_kv_heads"], c["head_dim"]
+    tensors = {}
+
+    def dense(name, a):
+        a = np.asarray(a, np.float32)
+        if dense_dtype == "F16":
+            tensors[name] = a.astype(np.float16)
+        elif dense_dtype == "BF16":                       # safetensors.numpy has no bf16: store raw via a uint16 view later
+            tensors[name] = ("BF16", (a.view(np.uint32) >> 16).astype(np.uint16))
+        else:
+            tensors[name] = a
+
+    def gptq(stem, qw, sc, qz):
+        if qzeros_noise:                                   # sym=true checkpoints may carry arbitrary qzeros: loader canonicalises
+            qz = (qz ^ 0x11111111).astype(np.int32)
+        tensors[stem + ".qweight"] = np.ascontiguousarray(qw, np.int32)
+        tensors[stem + ".scales"] = np.ascontiguousarray(sc, np.float16)
+        tensors[stem + ".qzeros"] = np.ascontiguousarray(qz, np.int32)
+
+    def split_cols(k, n, qw, sc, qz, widths):
+        qw, sc, qz = qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8)
+        off, out = 0, []
+        for w in widths:
+            out.append((qw[:, off:off + w], sc[:, off:off + w], qz[:, off // 8:(off + w) // 8]))
+            off += w
+        return out
+
+    dense("model.embed_tokens.weight", tm.glob["embed"])
+    dense("model.norm.weight", tm.glob["final_norm"])
+    if "lm_head" in tm.glob:
+        dense("lm_head.weight", tm.glob["lm_head"])
+    names = {"input_ln": "input_layernorm.weight", "post_ln": "post_attention_layernorm.weight",
+             "q_norm": "self_attn.q_norm.weight", "k_norm": "self_attn.k_norm.weight", "router": "mlp.gate.weight"}
+    for li, L in enumerate(tm.layers):
+        p = f"model.layers.{li}."
+        for key, a in L["dense"].items():
+            dense(p + names[key], a)
+        k, n, qw, sc, qz = L["gptq"]["qkv"]
+        if fused_names:
+            gptq(p + "self_attn.qkv_proj", qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8))
+        else:
+            for stem, part in zip(("q_proj", "k_proj", "v_proj"), split_cols(k, n, qw, sc, qz, (nq * hd, nkv * hd, nkv * hd))):
+                gptq(p + "self_attn." + stem, *part)
+        k, n, qw, sc, qz = L["gptq"]["o"]
+        gptq(p + "self_attn.o_proj", qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8))
+
+        def mlp(prefix, gu, dn):
+            k, n, qw, sc, qz = gu
+            if fused_names:
+                gptq(prefix + "gate_up_proj", qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8))
+            else:
+                for stem, part in zip(("gate_proj", "up_proj"), split_cols(k, n, qw, sc, qz, (n // 2, n // 2))):
+                    gptq(prefix + stem, *part)
+            k, n, qw, sc, qz = dn
+            gptq(prefix + "down_proj", qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8))
+
+        if L["experts"]:
+            for e, d in L["experts"].items():
+                mlp(p + f"mlp.experts.{e}.", d["expert_gate_up"], d["expert_down"])
+        else:
+            mlp(p + "mlp.", L["gptq"]["gate_up"], L["gptq"]["down"])
+
+    os.makedirs(out_dir, exist_ok=True)
+    cfgj = {"architectures": [arch], "hidden_size": H, "intermediate_size": c["intermediate"] or 4 * H, "vocab_size": c["vocab"],
+            "num_hidden_layers": c["num_layers"], "num_attention_heads": nq, "num_key_value_heads": nkv, "head_dim": hd,
+            "max_position_embeddings": c["max_seq_len"], "rms_norm_eps": c["rms_eps"], "rope_theta": c["rope_theta"],
+            "hidden_act": "gelu_pytorch_tanh" if c["activation"] == 1 else "silu", "tie_word_embeddings": "lm_head" not in tm.glob}
+    if c["num_experts"]:
+        cfgj.update(num_experts=c["num_experts"], num_experts_per_tok=c["top_k"], moe_intermediate_size=c["expert_inter"],
+                    norm_topk_prob=bool(c["norm_topk_prob"]))
+    if c["rope_scaling_kind"] == 2:
+        cfgj["rope_scaling"] = {"rope_type": "llama3", "factor": c["rope_p0"], "low_freq_factor": c["rope_p1"],
+                                "high_freq_factor": c["rope_p2"], "original_max_position_embeddings": int(c["rope_p3"])}
+    elif c["rope_scaling_kind"] == 1:
+        cfgj["rope_scaling"] = {"type": "linear", "factor": c["rope_p0"]}
+    if c["sliding_window"]:
+        cfgj["sliding_window"] = c["sliding_window"]
+    qc = {"quant_method": "gptq", "bits": 4, "group_size": 128, "desc_act": False, "sym": True}
+    if embedded_quant_config:
+        cfgj["quantization_config"] = qc
+    else:
+        json.dump(qc, open(os.path.join(out_dir, "quantize_config.json"), "w"))
+    json.dump(cfgj, open(os.path.join(out_dir, "config.json"), "w"))
+
+    def save(path, items):
+        plain = {k: v for k, v in items.items() if not isinstance(v, tuple)}
+        bf = {k: v[1] for k, v in items.items() if isinstance(v, tuple)}
+        if not bf:
+            save_file(plain, path)
+            return
+        # hand-written safetensors container so BF16 tensors keep their dtype tag
+        import struct
+        hdr, blobs, off = {}, [], 0
+        for k, v in list(plain.items()) + list(bf.items()):
+            raw = np.ascontiguousarray(v).tobytes()
+            dt = "BF16" if k in bf else {"float16": "F16", "float32": "F32", "int32": "I32"}[str(v.dtype)]
+            hdr[k] = {"dtype": dt, "shape": list(v.shape), "data_offsets": [off, off + len(raw)]}
+            blobs.append(raw)
+            off += len(raw)
+        hj = json.dumps(hdr).encode()
+        with open(path, "wb") as f:
+            f.write(struct.pack("<Q", len(hj)))
+            f.write(hj)
+            for b in blobs:
+                f.write(b)
+
+    keys = sorted(tensors)
+    if shards <= 1:
+        save(os.path.join(out_dir, "model.safetensors"), tensors)
+    else:
+        wm = {}
+        for s in range(shards):
+            fn = f"model-{s + 1:05d}-of-{shards:05d}.safetensors"
+            part = {k: tensors[k] for k in keys[s::shards]}
+            save(os.path.join(out_dir, fn), part)
+            wm.update({k: fn for k in part})
+        json.dump({"metadata": {}, "weight_map": wm}, open(os.path.join(out_dir, "model.safetensors.index.json"), "w"))
+    return tensors
+
+
 def cosine(a, b):
     a, b = a.astype(np.float64).ravel(), b.astype(np.float64).ravel()
     return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
