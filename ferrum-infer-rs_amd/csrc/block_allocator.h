@@ -12,6 +12,56 @@
 
 namespace fh {
 
+// SipHash-c-d (Aumasson & Bernstein), little-endian message words, 64-bit output.
+inline uint64_t siphash(int c_rounds, int d_rounds, uint64_t k0, uint64_t k1, const uint8_t* data, size_t len) {
+    uint64_t v0 = k0 ^ 0x736f6d6570736575ull, v1 = k1 ^ 0x646f72616e646f6dull;
+    uint64_t v2 = k0 ^ 0x6c7967656e657261ull, v3 = k1 ^ 0x7465646279746573ull;
+    auto rotl = [](uint64_t x, int b) { return (x << b) | (x >> (64 - b)); };
+    auto round = [&]() {
+        v0 += v1; v1 = rotl(v1, 13); v1 ^= v0; v0 = rotl(v0, 32);
+        v2 += v3; v3 = rotl(v3, 16); v3 ^= v2;
+        v0 += v3; v3 = rotl(v3, 21); v3 ^= v0;
+        v2 += v1; v1 = rotl(v1, 17); v1 ^= v2; v2 = rotl(v2, 32);
+    };
+    const size_t full = len / 8;
+    for (size_t i = 0; i < full; i++) {
+        uint64_t m = 0;
+        for (int j = 0; j < 8; j++) m |= (uint64_t)data[8 * i + j] << (8 * j);
+        v3 ^= m;
+        for (int r = 0; r < c_rounds; r++) round();
+        v0 ^= m;
+    }
+    uint64_t b = (uint64_t)(len & 0xff) << 56;
+    for (size_t j = 0; j < (len & 7); j++) b |= (uint64_t)data[8 * full + j] << (8 * j);
+    v3 ^= b;
+    for (int r = 0; r < c_rounds; r++) round();
+    v0 ^= b;
+    v2 ^= 0xff;
+    for (int r = 0; r < d_rounds; r++) round();
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+
+// Content hash of one KV block chained from its parent (paged_pool.rs:76-84): Rust's `DefaultHasher::new()` is
+// SipHash-1-3 with a zero key; `parent.hash()` feeds the u64 and each `TokenId` its u32, native (little) endian.
+inline uint64_t block_hash(uint64_t parent, const uint32_t* tokens, int n) {
+    std::vector<uint8_t> msg(8 + 4 * (size_t)n);
+    for (int j = 0; j < 8; j++) msg[j] = (uint8_t)(parent >> (8 * j));
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 4; j++) msg[8 + 4 * i + j] = (uint8_t)(tokens[i] >> (8 * j));
+    return siphash(1, 3, 0, 0, msg.data(), msg.size());
+}
+
+// block_hash_chain (paged_pool.rs:89-98): one hash per FULL block; a trailing partial block is dropped.
+inline std::vector<uint64_t> block_hash_chain(const uint32_t* tokens, int n, int block_size) {
+    std::vector<uint64_t> out;
+    uint64_t parent = 0;
+    for (int i = 0; i + block_size <= n; i += block_size) {
+        parent = block_hash(parent, tokens + i, block_size);
+        out.push_back(parent);
+    }
+    return out;
+}
+
 class BlockAllocator {
 public:
     explicit BlockAllocator(uint32_t num_blocks)

@@ -55,6 +55,7 @@ struct FerrumHipModel {
     // KV
     std::unique_ptr<fh::BlockAllocator> alloc;
     std::unordered_map<uint64_t, fh::SeqState> seqs;
+    uint64_t prefix_hits = 0, prefix_misses = 0, prefix_saved_tokens = 0;   // block-level prefix cache probes
 
     // scratch
     __half *residual = nullptr, *norm_out = nullptr, *qkv_out = nullptr, *q_out = nullptr, *attn_out = nullptr,

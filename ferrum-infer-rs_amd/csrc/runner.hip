@@ -560,6 +560,76 @@ int ferrum_hip_model_release(FerrumHipModel* m, uint64_t seq_id) {
     return 0;
 }
 
+// ── block-level prefix cache (ferrum-models/src/models/qwen3_moe/prefix_cache.rs:66-235, prefill_decode.rs:10-70) ──
+int ferrum_hip_block_hash_chain(const uint32_t* tokens, int n, int block_size, uint64_t* out, int capacity, int* count) {
+    FH_REQUIRE((tokens || n == 0) && block_size > 0 && count, "block_hash_chain: bad argument");
+    std::vector<uint64_t> h = fh::block_hash_chain(tokens, n, block_size);
+    *count = (int)h.size();
+    for (int i = 0; i < (int)h.size() && i < capacity; i++) out[i] = h[i];
+    return 0;
+}
+uint64_t ferrum_hip_siphash(int c_rounds, int d_rounds, uint64_t k0, uint64_t k1, const uint8_t* data, size_t len) {
+    return fh::siphash(c_rounds, d_rounds, k0, k1, data, len);
+}
+
+int ferrum_hip_model_prefix_cache_acquire(FerrumHipModel* m, uint64_t seq_id, const uint32_t* tokens, int n, int* cached_tokens) {
+    FH_REQUIRE(m && tokens && n > 0 && cached_tokens, "prefix_cache_acquire: bad argument");
+    *cached_tokens = 0;
+    auto it = m->seqs.find(seq_id);
+    FH_REQUIRE(it != m->seqs.end(), "prefix_cache_acquire: reserve KV slots for sequence %llu first", (unsigned long long)seq_id);
+    SeqState& st = it->second;
+    FH_REQUIRE(st.len == 0, "prefix_cache_acquire: sequence %llu already holds %d tokens", (unsigned long long)seq_id, st.len);
+    const std::vector<uint64_t> hashes = fh::block_hash_chain(tokens, n, KV_BLOCK);
+    // longest contiguous prefix: stop at the first miss
+    std::vector<uint32_t> matched;
+    for (uint64_t h : hashes) {
+        if (matched.size() >= st.blocks.size()) break;
+        int64_t b = m->alloc->try_acquire_by_hash(h);
+        if (b < 0) break;
+        matched.push_back((uint32_t)b);
+    }
+    if (matched.empty()) {
+        m->prefix_misses++;
+        return 0;
+    }
+    // the freshly reserved blocks in the matched slots go back to the pool; the cached ids take their place
+    m->alloc->free(st.blocks.data(), (uint32_t)matched.size());
+    for (size_t i = 0; i < matched.size(); i++) st.blocks[i] = matched[i];
+    int cached = (int)matched.size() * KV_BLOCK;
+    // a full hit keeps one block's worth to re-run so the forward still yields final logits (prefill_decode.rs:34-48);
+    // the suffix then rewrites the shared block with identical content
+    if (cached >= n) cached = std::min(std::max(cached - KV_BLOCK, 0), n - 1);
+    st.len = cached;
+    if (cached > 0) { m->prefix_hits++; m->prefix_saved_tokens += (uint64_t)cached; } else { m->prefix_misses++; }
+    *cached_tokens = cached;
+    return 0;
+}
+
+int ferrum_hip_model_prefix_cache_register(FerrumHipModel* m, uint64_t seq_id, const uint32_t* all_tokens, int n,
+                                           int prior_cached_tokens) {
+    FH_REQUIRE(m && all_tokens && n >= 0 && prior_cached_tokens >= 0, "prefix_cache_register: bad argument");
+    auto it = m->seqs.find(seq_id);
+    FH_REQUIRE(it != m->seqs.end(), "prefix_cache_register: unknown sequence %llu", (unsigned long long)seq_id);
+    const SeqState& st = it->second;
+    const std::vector<uint64_t> hashes = fh::block_hash_chain(all_tokens, n, KV_BLOCK);
+    // only blocks whose 16 slots were all written: (i + 1)·16 ≤ kv length
+    for (size_t i = (size_t)prior_cached_tokens / KV_BLOCK; i < hashes.size() && i < st.blocks.size(); i++) {
+        if ((int)(i + 1) * KV_BLOCK > st.len) break;
+        m->alloc->register_block_hash(st.blocks[i], hashes[i]);
+    }
+    return 0;
+}
+
+int ferrum_hip_model_prefix_cache_stats(const FerrumHipModel* m, uint64_t* hits, uint64_t* misses, uint64_t* saved_prefill_tokens,
+                                        uint64_t* entries) {
+    FH_REQUIRE(m, "prefix_cache_stats: null");
+    if (hits) *hits = m->prefix_hits;
+    if (misses) *misses = m->prefix_misses;
+    if (saved_prefill_tokens) *saved_prefill_tokens = m->prefix_saved_tokens;
+    if (entries) *entries = m->alloc ? m->alloc->hash_table_size() : 0;
+    return 0;
+}
+
 int ferrum_hip_model_block_table(const FerrumHipModel* m, uint64_t seq_id, uint32_t* blocks, int capacity,
                                  int* num_blocks, int* kv_len) {
     FH_REQUIRE(m, "model_block_table: null");

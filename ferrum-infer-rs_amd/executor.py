@@ -182,6 +182,25 @@ class HipModel:
     def finalize(self):
         _check(self.lib.ferrum_hip_model_finalize(self.h), "finalize")
 
+    # ── block-level prefix cache (models/qwen3_moe/prefix_cache.rs) ───────────
+    def prefix_cache_acquire(self, seq_id, tokens):
+        """After reserve_kv_slots: splice cached prefix blocks in; returns the number of prompt tokens already cached."""
+        t = np.ascontiguousarray(tokens, np.uint32)
+        cached = C.c_int()
+        _check(self.lib.ferrum_hip_model_prefix_cache_acquire(self.h, C.c_uint64(seq_id), t.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                              len(t), C.byref(cached)), "prefix_cache_acquire")
+        return cached.value
+
+    def prefix_cache_register(self, seq_id, all_tokens, prior_cached_tokens):
+        t = np.ascontiguousarray(all_tokens, np.uint32)
+        _check(self.lib.ferrum_hip_model_prefix_cache_register(self.h, C.c_uint64(seq_id), t.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                               len(t), prior_cached_tokens), "prefix_cache_register")
+
+    def prefix_cache_stats(self):
+        v = [C.c_uint64() for _ in range(4)]
+        _check(self.lib.ferrum_hip_model_prefix_cache_stats(self.h, *[C.byref(x) for x in v]), "prefix_cache_stats")
+        return dict(zip(("hits", "misses", "saved_prefill_tokens", "entries"), (int(x.value) for x in v)))
+
     # ── KV admission ─────────────────────────────────────────────────────────
     def reserve_kv_slots(self, requests):
         """requests: [(seq_id, target_len)] → KvSlotReservation dict; raises when the pool is exhausted."""

@@ -336,6 +336,21 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* model, int layer, int which, int e
 int ferrum_hip_model_init_synthetic(FerrumHipModel* model, uint64_t seed);
 int ferrum_hip_model_finalize(FerrumHipModel* model);
 
+/* ── block-level prefix cache (paged_pool.rs:60-98, models/qwen3_moe/prefix_cache.rs:66-235, prefill_decode.rs:10-70).
+ *    block_hash = SipHash-1-3, zero key (Rust `DefaultHasher::new()`), over parent u64 ‖ token u32s, little endian; one hash
+ *    per full 16-token block, chained.  acquire: after reserve_kv_slots, before the first forward of a sequence — splices
+ *    the longest cached block prefix into the sequence (fresh blocks in those slots are freed), sets its kv length and
+ *    returns the number of prompt tokens that need no prefill; a full hit is rolled back by one block so the forward still
+ *    yields logits.  The caller then forwards tokens[cached:] at pos_offset = cached and calls register with the FULL prompt. */
+uint64_t ferrum_hip_siphash(int c_rounds, int d_rounds, uint64_t k0, uint64_t k1, const uint8_t* data, size_t len);
+int ferrum_hip_block_hash_chain(const uint32_t* tokens, int n, int block_size, uint64_t* out, int capacity, int* count);
+int ferrum_hip_model_prefix_cache_acquire(FerrumHipModel* model, uint64_t seq_id, const uint32_t* tokens, int n,
+                                          int* cached_tokens);
+int ferrum_hip_model_prefix_cache_register(FerrumHipModel* model, uint64_t seq_id, const uint32_t* all_tokens, int n,
+                                           int prior_cached_tokens);
+int ferrum_hip_model_prefix_cache_stats(const FerrumHipModel* model, uint64_t* hits, uint64_t* misses,
+                                        uint64_t* saved_prefill_tokens, uint64_t* entries);
+
 /* ── checkpoint reader (host only): safetensors shards + HF config.json + GPTQ quantize config, with the reference
  *    loader's semantics — shard index (ferrum-quantization/src/native_safetensors.rs:142-195), f32/f16/bf16 → f32 and raw
  *    i32 reads (:197-330), fused GPTQ linears q|k|v → qkv and gate|up → gate_up (:887-1000) with symmetric-4-bit qzeros

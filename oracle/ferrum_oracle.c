@@ -705,6 +705,53 @@ typedef struct {
     uint32_t peak_in_use;
 } fo_allocator;
 
+/* ── KV block content hashes (ferrum-models/src/common/paged_pool.rs:60-98) ──────────────────────────
+ * `block_hash` feeds Rust's `DefaultHasher::new()` — SipHash-1-3 with a zero key (a third-party algorithm as far as
+ * /root/reference is concerned: it lives in Rust's std, version pinned by the toolchain, not vendored) — the parent
+ * hash as a u64 and every token id as a u32, native endian.  The routine below is the published SipHash-c-d
+ * (Aumasson & Bernstein 2012), pinned by the paper's SipHash-2-4 vectors in tests/test_oracle_golden.py; the 1-3
+ * VALUES have no golden in the reference (its tests check chain properties only) → value parity with Rust unpinned. */
+#define FO_ROTL64(x, b) (((x) << (b)) | ((x) >> (64 - (b))))
+#define FO_SIPROUND do { \
+    v0 += v1; v1 = FO_ROTL64(v1, 13); v1 ^= v0; v0 = FO_ROTL64(v0, 32); \
+    v2 += v3; v3 = FO_ROTL64(v3, 16); v3 ^= v2; \
+    v0 += v3; v3 = FO_ROTL64(v3, 21); v3 ^= v0; \
+    v2 += v1; v1 = FO_ROTL64(v1, 17); v1 ^= v2; v2 = FO_ROTL64(v2, 32); } while (0)
+FO_API uint64_t fo_siphash(int c, int d, uint64_t k0, uint64_t k1, const uint8_t *in, size_t len) {
+    uint64_t v0 = 0x736f6d6570736575ULL ^ k0, v1 = 0x646f72616e646f6dULL ^ k1;
+    uint64_t v2 = 0x6c7967656e657261ULL ^ k0, v3 = 0x7465646279746573ULL ^ k1;
+    const uint8_t *end = in + (len - (len % 8));
+    for (; in != end; in += 8) {
+        uint64_t m = 0;
+        for (int j = 7; j >= 0; j--) m = (m << 8) | in[j];
+        v3 ^= m;
+        for (int i = 0; i < c; i++) FO_SIPROUND;
+        v0 ^= m;
+    }
+    uint64_t b = ((uint64_t)len) << 56;
+    for (int j = (int)(len % 8) - 1; j >= 0; j--) b |= ((uint64_t)in[j]) << (8 * j);
+    v3 ^= b;
+    for (int i = 0; i < c; i++) FO_SIPROUND;
+    v0 ^= b;
+    v2 ^= 0xff;
+    for (int i = 0; i < d; i++) FO_SIPROUND;
+    return v0 ^ v1 ^ v2 ^ v3;
+}
+/* block_hash_chain (paged_pool.rs:89-98): out gets one hash per full block; returns the count. */
+FO_API int fo_block_hash_chain(const uint32_t *tokens, int n, int block_size, uint64_t *out) {
+    uint64_t parent = 0;
+    int count = 0;
+    uint8_t *msg = (uint8_t *)malloc(8 + 4 * (size_t)block_size);
+    for (int i = 0; i + block_size <= n; i += block_size) {
+        memcpy(msg, &parent, 8);                                   /* little-endian host, like the reference's targets */
+        memcpy(msg + 8, tokens + i, 4 * (size_t)block_size);
+        parent = fo_siphash(1, 3, 0, 0, msg, 8 + 4 * (size_t)block_size);
+        out[count++] = parent;
+    }
+    free(msg);
+    return count;
+}
+
 FO_API fo_allocator *fo_alloc_new(uint32_t num_blocks) {
     fo_allocator *a = (fo_allocator *)calloc(1, sizeof(fo_allocator));
     a->capacity = num_blocks;

@@ -117,6 +117,10 @@ def _declare(l):
     l.fo_model_enable_taps.argtypes = [C.c_void_p, C.c_int]
     l.fo_model_taps.restype = C.POINTER(C.c_float)
     l.fo_model_taps.argtypes = [C.c_void_p]
+    l.fo_siphash.restype = C.c_uint64
+    l.fo_siphash.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.c_size_t]
+    l.fo_block_hash_chain.restype = C.c_int
+    l.fo_block_hash_chain.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     l.fo_model_last_route_gap.restype = C.c_float
     l.fo_model_last_route_gap.argtypes = [C.c_void_p]
     l.fo_model_forward.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int,
@@ -451,6 +455,19 @@ class ModelCfg(C.Structure):
         "norm_topk_prob", "rope_scaling_kind", "sliding_window")] + [
         ("rms_eps", C.c_float), ("_pad", C.c_float), ("rope_theta", C.c_double),
         ("rope_p0", C.c_double), ("rope_p1", C.c_double), ("rope_p2", C.c_double), ("rope_p3", C.c_double)]
+
+
+def siphash(c, d, k0, k1, data):
+    """SipHash-c-d of `data` (bytes) with key (k0, k1)."""
+    return int(lib().fo_siphash(c, d, k0, k1, bytes(data), len(data)))
+
+
+def block_hash_chain(tokens, block_size=16):
+    """paged_pool.rs:89-98: chained content hash per full block of `tokens`."""
+    t = np.ascontiguousarray(tokens, np.uint32)
+    out = np.zeros(max(len(t) // block_size, 1), np.uint64)
+    n = lib().fo_block_hash_chain(t.ctypes.data, len(t), block_size, out.ctypes.data)
+    return out[:n].copy()
 
 
 class OracleModel:

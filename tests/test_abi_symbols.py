@@ -122,3 +122,24 @@ def test_model_create_validates_config(pkg):
         HipModel(num_layers=1, hidden=100, num_heads=2, num_kv_heads=1, head_dim=128, intermediate=128, vocab=64)
     with pytest.raises(RuntimeError):
         HipModel(num_layers=1, hidden=128, num_heads=3, num_kv_heads=2, head_dim=128, intermediate=128, vocab=64)
+
+
+def test_block_hash_chain_matches_restatement_and_published_siphash(pkg, oracle):
+    """paged_pool.rs:60-98 through the product's C ABI: same chain as the independent restatement on random prompts,
+    SipHash-2-4 paper vectors through the product's own routine."""
+    import struct
+    lib = pkg.load_library()
+    lib.ferrum_hip_siphash.restype = C.c_uint64
+    lib.ferrum_hip_siphash.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.c_size_t]
+    k0, k1 = struct.unpack("<QQ", bytes(range(16)))
+    assert lib.ferrum_hip_siphash(2, 4, k0, k1, b"", 0) == 0x726FDB47DD0E0E31
+    assert lib.ferrum_hip_siphash(2, 4, k0, k1, bytes(range(15)), 15) == 0xA129CA6149BE45E5
+    rng = np.random.default_rng(5)
+    for n in (0, 15, 16, 17, 100, 256, 1000):
+        toks = rng.integers(0, 2**32 - 1, size=n, dtype=np.uint64).astype(np.uint32)
+        out = np.zeros(n // 16 + 1, np.uint64)
+        cnt = C.c_int()
+        assert lib.ferrum_hip_block_hash_chain(toks.ctypes.data_as(C.POINTER(C.c_uint32)), n, 16,
+                                               out.ctypes.data_as(C.POINTER(C.c_uint64)), len(out), C.byref(cnt)) == 0
+        ref = oracle.block_hash_chain(toks, 16)
+        assert cnt.value == n // 16 == len(ref) and np.array_equal(out[:cnt.value], ref)

@@ -189,6 +189,50 @@ def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     assert [hm.block_table(i)[0] for i in range(c)] == [[i] for i in range(c)]   # one block each, ids in arrival order
 
 
+def test_block_level_prefix_cache_reuses_kv_and_matches_full_prefill(pkg):
+    """models/qwen3_moe/prefix_cache.rs + prefill_decode.rs:10-70: a second request sharing a 40-token prefix splices the
+    two cached blocks (ids of the first request's blocks, resurrected from the soft-free list), prefills only the suffix,
+    and produces the logits of a full prefill; a full-hit prompt is rolled back by one block."""
+    from tests import modelgen
+    tm = modelgen.TinyModel(True, layers=2, seed=51)
+    hm = tm.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=128)
+    rng = np.random.default_rng(52)
+    V = tm.cfg["vocab"]
+    shared = rng.integers(0, V, size=40).astype(np.uint32)
+    pa = np.concatenate([shared, rng.integers(0, V, size=9).astype(np.uint32)])       # 49 tokens: 3 full blocks
+    pb = np.concatenate([shared, rng.integers(0, V, size=23).astype(np.uint32)])      # shares blocks 0,1 (32 tokens)
+
+    def run(seq_id, prompt, use_cache):
+        hm.reserve_kv_slots([(seq_id, len(prompt))])
+        cached = hm.prefix_cache_acquire(seq_id, prompt) if use_cache else 0
+        toks, lg = hm.unified_forward([(seq_id, prompt[cached:], cached, True)], greedy=True, want_logits=True)
+        hm.prefix_cache_register(seq_id, prompt, cached)
+        return cached, int(toks[0]), lg[0].copy(), hm.block_table(seq_id)[0]
+
+    ca, ta, la, blocks_a = run(1, pa, True)
+    assert ca == 0 and blocks_a == [0, 1, 2, 3] and hm.prefix_cache_stats()["entries"] == 3
+    hm.release(1)                                               # soft-free: hashes stay resolvable
+    cb, tb, lb, blocks_b = run(2, pb, True)
+    assert cb == 32 and blocks_b[:2] == [0, 1]                  # first request's blocks resurrected
+    st = hm.prefix_cache_stats()
+    assert (st["hits"], st["misses"], st["saved_prefill_tokens"]) == (1, 1, 32)
+    # reference: the same prompt prefilled in full on a fresh model
+    hm2 = tm.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=128)
+    _, lfull = hm2.unified_forward([(9, pb, 0, True)], greedy=True, want_logits=True)
+    assert modelgen.cosine(lfull[0], lb) > 0.99999 and np.max(np.abs(lfull[0] - lb)) < 2e-3 * np.max(np.abs(lfull[0]))
+    om = tm.oracle_model()
+    assert modelgen.cosine(om.forward(0, pb, 0), lb) > 0.999
+    for is_v in (0, 1):
+        assert modelgen.nmse(om.read_kv(0, 1, is_v), hm.read_kv(2, 1, is_v)) < 3e-3
+    # full hit: identical 48-token prompt (3 full blocks, all cached) → rolled back to 32 so a suffix remains
+    hm.release(2)
+    p48 = pa[:48]
+    c3, _, l3, _ = run(3, p48, True)
+    assert c3 == 32
+    _, l48 = hm2.unified_forward([(10, p48, 0, True)], greedy=True, want_logits=True)
+    assert modelgen.cosine(l48[0], l3) > 0.99999
+
+
 def test_kv_admission_contract(pkg):
     """reserve_kv_slots is atomic and release returns blocks LIFO (model_executor.rs:484, paged_pool.rs:333-345)."""
     from tests import modelgen

@@ -455,3 +455,26 @@ def test_qk_norm_rope_modes(oracle):
     for t in range(T):
         c, s = cos[5 + t], sin[5 + t]
         assert np.allclose(o3[:, t, 0::2], x[t, :, 0::2] * c - x[t, :, 1::2] * s, atol=1e-6)
+
+
+# ── KV block content hashes (paged_pool.rs:60-98) ────────────────────────────
+def test_siphash_published_vectors_and_block_hash_chain_properties(oracle):
+    O = oracle
+    """SipHash-c-d pinned by the paper's SipHash-2-4 vectors (key 00..0f: empty message and 00..0e); the block chain is
+    the 1-3 variant with a zero key (Rust DefaultHasher) and must satisfy the reference's chain tests
+    (paged_pool.rs:578-606): chained, prefix-stable, trailing partial block dropped."""
+    import struct
+    k0, k1 = struct.unpack("<QQ", bytes(range(16)))
+    assert O.siphash(2, 4, k0, k1, b"") == 0x726FDB47DD0E0E31
+    assert O.siphash(2, 4, k0, k1, bytes(range(15))) == 0xA129CA6149BE45E5
+    chain = O.block_hash_chain([1, 2, 3, 4, 5, 6, 7, 8], 4)
+    assert len(chain) == 2 and chain[0] != chain[1]
+    ca = O.block_hash_chain([10, 20, 30, 40, 50, 60, 70, 80], 4)
+    cb = O.block_hash_chain([10, 20, 30, 40, 99, 99, 99, 99], 4)
+    assert ca[0] == cb[0] and ca[1] != cb[1]
+    assert len(O.block_hash_chain([1, 2, 3, 4, 5, 6, 7], 4)) == 1
+    # chaining: hash[1] depends on hash[0] — the same second block under a different first block hashes differently
+    assert O.block_hash_chain([9, 9, 9, 9, 5, 6, 7, 8], 4)[1] != chain[1]
+    # explicit construction: parent u64 LE ‖ token u32 LE, SipHash-1-3, zero key
+    msg = struct.pack("<Q4I", 0, 1, 2, 3, 4)
+    assert O.siphash(1, 3, 0, 0, msg) == int(chain[0])
