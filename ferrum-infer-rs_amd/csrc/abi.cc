@@ -334,6 +334,18 @@ int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const
                                     top_k, fused_silu_mul, nullptr, nullptr, nullptr, ST(stream));
 }
 
+int ferrum_hip_sandwich_add_rms_norm_f32(const void* branch_f16, const void* w_branch, float* residual_f32, const void* w_next,
+                                         float eps, void* norm_out_f16, int tokens, int dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (branch_f16 && w_branch && residual_f32 && (!w_next || norm_out_f16)), "sandwich_add_rms_norm_f32: null buffer");
+    return sandwich_add_rms_norm_f32(CH(branch_f16), CH(w_branch), residual_f32, CH(w_next), eps, H(norm_out_f16), tokens, dim,
+                                     ST(stream));
+}
+int ferrum_hip_rms_norm_f32_to_f16(const float* x_f32, const int32_t* row_idx, const void* w, float eps, void* out_f16, int n_rows,
+                                   int dim, void* stream) {
+    FH_REQUIRE(n_rows == 0 || (x_f32 && w && out_f16), "rms_norm_f32_to_f16: null buffer");
+    return rms_norm_f32_to_f16(x_f32, row_idx, CH(w), eps, H(out_f16), n_rows, dim, ST(stream));
+}
+
 // ── paged KV ────────────────────────────────────────────────────────────────
 size_t ferrum_hip_paged_pool_bytes(int num_blocks, int kv_heads, int head_dim) {
     return (size_t)num_blocks * kv_heads * 16 * head_dim * 2;

@@ -68,6 +68,10 @@ int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, 
 int fused_silu_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s);
 int fused_gelu_tanh_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s);
 int add_inplace_f16(__half* residual, const __half* x, long len, hipStream_t s);
+int sandwich_add_rms_norm_f32(const __half* branch, const __half* w_branch, float* residual, const __half* w_next, float eps,
+                              __half* norm_out, int tokens, int dim, hipStream_t s);
+int rms_norm_f32_to_f16(const float* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int n_rows, int dim,
+                        hipStream_t s);
 int scale_inplace_f16(__half* buf, float scale, long len, hipStream_t s);
 int add_bias_f16(__half* data, const __half* bias, int rows, int cols, hipStream_t s);
 int gather_columns_f16(const __half* in, const int32_t* perm, __half* out, int rows, int cols, hipStream_t s);

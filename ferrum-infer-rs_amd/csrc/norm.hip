@@ -111,6 +111,127 @@ int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, 
     return 0;
 }
 
+// ── fp32 residual stream (Gemma-3 sandwich norms) ────────────────────────────────────────────────
+// residual += rms_norm(branch)·w_branch (all f32, branch read as fp16);  norm_out = f16(rms_norm(residual)·w_next).
+// One 256-thread workgroup per token, the row held in registers between the two reductions (H ≤ 8192).
+__global__ __launch_bounds__(256) void sandwich_add_norm_f32_kernel(const __half* __restrict__ branch,
+                                                                     const __half* __restrict__ w_branch,
+                                                                     float* __restrict__ residual,
+                                                                     const __half* __restrict__ w_next, float eps,
+                                                                     __half* __restrict__ norm_out, int H) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int nvec = H >> 3;
+    constexpr int CH = 4;
+    float x[CH][8], r[CH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            const half8 v = *reinterpret_cast<const half8*>(branch + row * H + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { x[c][j] = (float)v[j]; ss += x[c][j] * x[c][j]; }
+        }
+    }
+    auto block_sum = [&](float v) {
+        v = wave_reduce_sum(v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        const float t = (red[0] + red[1]) + (red[2] + red[3]);
+        __syncthreads();
+        return t;
+    };
+    const float inv1 = 1.0f / sqrtf(block_sum(ss) / (float)H + eps);
+    float ss2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            const half8 wv = *reinterpret_cast<const half8*>(w_branch + i * 8);
+            float4v* rp = reinterpret_cast<float4v*>(residual + row * H + i * 8);
+            float4v r0 = rp[0], r1 = rp[1];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float b = x[c][j] * inv1 * (float)wv[j];
+                r[c][j] = (j < 4 ? r0[j] : r1[j - 4]) + b;
+                ss2 += r[c][j] * r[c][j];
+            }
+            rp[0] = (float4v){r[c][0], r[c][1], r[c][2], r[c][3]};
+            rp[1] = (float4v){r[c][4], r[c][5], r[c][6], r[c][7]};
+        }
+    }
+    if (w_next == nullptr) return;
+    const float inv2 = 1.0f / sqrtf(block_sum(ss2) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            const half8 wv = *reinterpret_cast<const half8*>(w_next + i * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)(r[c][j] * inv2 * (float)wv[j]);
+            *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+        }
+    }
+}
+
+int sandwich_add_rms_norm_f32(const __half* branch, const __half* w_branch, float* residual, const __half* w_next, float eps,
+                              __half* norm_out, int tokens, int dim, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0 && dim <= 8192, "sandwich_add_rms_norm_f32: dim=%d must be a multiple of 8, <= 8192", dim);
+    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel, dim3(tokens), dim3(256), 0, s, branch, w_branch, residual, w_next, eps,
+                       norm_out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void rms_norm_f32_to_f16_kernel(const float* __restrict__ x, const int32_t* __restrict__ row_idx,
+                                                                   const __half* __restrict__ w, float eps,
+                                                                   __half* __restrict__ out, int H) {
+    __shared__ float red[4];
+    const long src = row_idx ? row_idx[blockIdx.x] : blockIdx.x;
+    const long dst = blockIdx.x;
+    const int nvec = H >> 3;
+    constexpr int CH = 4;
+    float v[CH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            const float4v* p = reinterpret_cast<const float4v*>(x + src * H + i * 8);
+            const float4v a = p[0], b = p[1];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { v[c][j] = j < 4 ? a[j] : b[j - 4]; ss += v[c][j] * v[c][j]; }
+        }
+    }
+    ss = wave_reduce_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf(((red[0] + red[1]) + (red[2] + red[3])) / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            const half8 wv = *reinterpret_cast<const half8*>(w + i * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)(v[c][j] * inv * (float)wv[j]);
+            *reinterpret_cast<half8*>(out + dst * H + i * 8) = o;
+        }
+    }
+}
+
+int rms_norm_f32_to_f16(const float* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int n_rows, int dim,
+                        hipStream_t s) {
+    if (n_rows <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0 && dim <= 8192, "rms_norm_f32_to_f16: dim=%d must be a multiple of 8, <= 8192", dim);
+    hipLaunchKernelGGL(rms_norm_f32_to_f16_kernel, dim3(n_rows), dim3(256), 0, s, x, row_idx, w, eps, out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 int gather_rows_f16(const __half* in, const int32_t* row_idx, __half* out, int n_rows, int dim, hipStream_t s) {
     if (n_rows <= 0) return 0;
     FH_REQUIRE(dim % 8 == 0, "gather_rows: dim=%d must be a multiple of 8", dim);

@@ -18,6 +18,8 @@ struct LayerWeights {
     __half* q_norm = nullptr;
     __half* k_norm = nullptr;
     __half* router = nullptr;      // [E, H] fp16
+    __half* post_attn_ln = nullptr;   // sandwich norms (Gemma 3); post_ln is then the pre-MLP norm
+    __half* post_ffn_ln = nullptr;
     W4Device qkv, o, gate_up, down;
     W4Device exp_gate_up, exp_down;   // stacked experts
     std::vector<uint8_t> exp_loaded;   // per expert: bit0 gate_up, bit1 down
@@ -50,6 +52,9 @@ struct FerrumHipModel {
     __half* final_norm = nullptr;
     float* cos_t = nullptr;
     float* sin_t = nullptr;
+    float* cos_local = nullptr;    // RoPE table of the local-attention layers (rope_local_theta), else null
+    float* sin_local = nullptr;
+    float* residual_f32 = nullptr; // fp32 residual stream of sandwich-norm models
     std::vector<fh::LayerWeights> layers;
 
     // KV

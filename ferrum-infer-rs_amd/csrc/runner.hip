@@ -207,6 +207,8 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     } else {
         FH_REQUIRE(cfg->intermediate > 0 && cfg->intermediate % 128 == 0, "model_create: intermediate=%d must be a multiple of 128", cfg->intermediate);
     }
+    FH_REQUIRE(!cfg->sandwich_norms || cfg->num_experts == 0, "model_create: sandwich norms are implemented for dense MLP models");
+    FH_REQUIRE(cfg->sliding_window_pattern >= 0 && cfg->rope_local_theta >= 0.0, "model_create: bad local-attention schedule");
     auto* m = new FerrumHipModel();
     m->cfg = *cfg;
     if (m->cfg.tp_world < 1) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
@@ -214,24 +216,29 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     m->max_blocks_per_seq = cdiv(cfg->max_seq_len, KV_BLOCK);
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete m; fh::set_error("model_create: hipStreamCreate: %s", hipGetErrorString(e)); return 1; }
-    // RoPE tables
+    // RoPE tables: the main one (θ, optional scaling) and, for Gemma-3 style models, the unscaled local-layer table
     const int half = cfg->head_dim / 2;
-    std::vector<float> cs((size_t)cfg->max_seq_len * half), sn((size_t)cfg->max_seq_len * half);
-    std::vector<double> freq(half);
-    for (int i = 0; i < half; i++) freq[i] = rope_freq(*cfg, i);
-    for (int pos = 0; pos < cfg->max_seq_len; pos++)
-        for (int i = 0; i < half; i++) {
-            double ang = (double)pos * freq[i];
-            cs[(size_t)pos * half + i] = (float)cos(ang);
-            sn[(size_t)pos * half + i] = (float)sin(ang);
-        }
-    if (hipMalloc((void**)&m->cos_t, cs.size() * 4) != hipSuccess || hipMalloc((void**)&m->sin_t, sn.size() * 4) != hipSuccess) {
+    auto build_table = [&](bool local, float** cos_d, float** sin_d) -> bool {
+        std::vector<float> cs((size_t)cfg->max_seq_len * half), sn((size_t)cfg->max_seq_len * half);
+        std::vector<double> freq(half);
+        for (int i = 0; i < half; i++)
+            freq[i] = local ? 1.0 / pow(cfg->rope_local_theta, (double)(2 * i) / (double)cfg->head_dim) : rope_freq(*cfg, i);
+        for (int pos = 0; pos < cfg->max_seq_len; pos++)
+            for (int i = 0; i < half; i++) {
+                double ang = (double)pos * freq[i];
+                cs[(size_t)pos * half + i] = (float)cos(ang);
+                sn[(size_t)pos * half + i] = (float)sin(ang);
+            }
+        if (hipMalloc((void**)cos_d, cs.size() * 4) != hipSuccess || hipMalloc((void**)sin_d, sn.size() * 4) != hipSuccess) return false;
+        (void)hipMemcpy(*cos_d, cs.data(), cs.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(*sin_d, sn.data(), sn.size() * 4, hipMemcpyHostToDevice);
+        return true;
+    };
+    if (!build_table(false, &m->cos_t, &m->sin_t) || (cfg->rope_local_theta > 0.0 && !build_table(true, &m->cos_local, &m->sin_local))) {
         fh::set_error("model_create: rope table allocation failed");
         ferrum_hip_model_destroy(m);
         return 1;
     }
-    (void)hipMemcpy(m->cos_t, cs.data(), cs.size() * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(m->sin_t, sn.data(), sn.size() * 4, hipMemcpyHostToDevice);
     m->alloc.reset(new BlockAllocator((uint32_t)cfg->kv_num_blocks));
     if (const char* e = getenv("FERRUM_HIP_ROUTE_PARTS")) m->route_parts = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_FUSE_ROPE")) m->fuse_rope_attn = atoi(e) != 0;
@@ -245,7 +252,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     for (auto& L : m->layers) {
-        for (__half* p : {L.input_ln, L.post_ln, L.q_norm, L.k_norm, L.router, L.k_pool, L.v_pool})
+        for (__half* p : {L.input_ln, L.post_ln, L.q_norm, L.k_norm, L.router, L.k_pool, L.v_pool, L.post_attn_ln, L.post_ffn_ln})
             if (p) (void)hipFree(p);
         free_w4(L.qkv); free_w4(L.o); free_w4(L.gate_up); free_w4(L.down); free_w4(L.exp_gate_up); free_w4(L.exp_down);
     }
@@ -256,7 +263,8 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
-                    (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive})
+                    (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
+                    (void*)m->sin_local, (void*)m->residual_f32})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -287,6 +295,8 @@ int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* m, int layer, int which
     case 4:
         FH_REQUIRE(m->cfg.num_experts > 0, "model_set_layer_dense: router on a dense model");
         return upload_f32_as_f16(data, (size_t)m->cfg.num_experts * m->cfg.hidden, &L.router);
+    case 5: return upload_f32_as_f16(data, m->cfg.hidden, &L.post_attn_ln);
+    case 6: return upload_f32_as_f16(data, m->cfg.hidden, &L.post_ffn_ln);
     }
     fh::set_error("model_set_layer_dense: which=%d", which);
     return FERRUM_HIP_INVALID;
@@ -412,6 +422,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         const LayerWeights& L = m->layers[li];
         FH_REQUIRE(L.input_ln && L.post_ln && L.qkv.qw && L.o.qw, "model_finalize: layer %d attention weights missing", li);
         FH_REQUIRE(!c.has_qk_norm || (L.q_norm && L.k_norm), "model_finalize: layer %d q/k norm missing", li);
+        FH_REQUIRE(!c.sandwich_norms || (L.post_attn_ln && L.post_ffn_ln), "model_finalize: layer %d sandwich norms missing", li);
         if (c.num_experts > 0) {
             FH_REQUIRE(L.router && L.exp_gate_up.qw && L.exp_down.qw, "model_finalize: layer %d MoE weights missing", li);
             for (int e = 0; e < c.num_experts; e++)
@@ -449,6 +460,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     }
     int rc = 0;
     rc |= dev_alloc(&m->residual, T * H);
+    if (c.sandwich_norms) rc |= dev_alloc(&m->residual_f32, T * H);
     rc |= dev_alloc(&m->norm_out, T * H);
     rc |= dev_alloc(&m->qkv_out, T * qkv_dim(c));
     rc |= dev_alloc(&m->q_out, T * q_dim(c));
@@ -719,31 +731,46 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
     int rc;
 #define RUN(x) if ((rc = (x))) return rc
     RUN(embedding_lookup_f16(m->embed, tokens, m->residual, T, H, s));
+    if (c.embed_scale != 0.0f) RUN(scale_inplace_f16(m->residual, c.embed_scale, (long)T * H, s));   // llama_family.rs:3656
+    const bool sandwich = c.sandwich_norms != 0;
     // the input norm of layer 0; later layers get theirs fused into the previous layer's tail
-    RUN(rms_norm_f16(m->residual, m->layers[0].input_ln, c.rms_eps, m->norm_out, T, H, s));
+    if (sandwich) {
+        // fp32 residual stream (the reference's device F32 shadow, llama_family.rs:3664-3674): fp16 only feeds the GEMMs
+        hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)T * H, 256)), dim3(256), 0, s, m->residual, m->residual_f32, (long)T * H);
+        RUN(rms_norm_f32_to_f16(m->residual_f32, nullptr, m->layers[0].input_ln, c.rms_eps, m->norm_out, T, H, s));
+    } else {
+        RUN(rms_norm_f16(m->residual, m->layers[0].input_ln, c.rms_eps, m->norm_out, T, H, s));
+    }
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
         const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
         RUN(w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s));
-        if (sh.pure_decode && m->fuse_rope_attn && nq / nkv <= 14) {
+        // per-layer attention schedule (llama_layer_attention_schedule, llama_family.rs:1028-1045)
+        const int pattern = c.sliding_window_pattern;
+        const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
+        const int layer_window = pattern == 0 ? c.sliding_window : (is_global ? 0 : c.sliding_window);
+        const float* cos_l = (!is_global && m->cos_local) ? m->cos_local : m->cos_t;
+        const float* sin_l = (!is_global && m->sin_local) ? m->sin_local : m->sin_t;
+        const bool layer_decode = sh.pure_decode && layer_window == 0;
+        if (layer_decode && m->fuse_rope_attn && nq / nkv <= 14) {
             // decode: QK-norm + RoPE + KV write happen in the attention kernel's prologue (one launch fewer)
             RUN(paged_decode_attention_fused_qkv_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
-                                                     m->cos_t, m->sin_t, c.rms_eps, qk_mode, L.k_pool, L.v_pool, m->attn_out,
+                                                     cos_l, sin_l, c.rms_eps, qk_mode, L.k_pool, L.v_pool, m->attn_out,
                                                      bt, kvl, sh.num_seqs, sh.max_kv_len, nq, nkv, hd, KV_BLOCK,
                                                      m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
         } else {
             RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy,
-                                                                L.k_norm ? L.k_norm : dummy, m->cos_t, m->sin_t, m->q_out,
+                                                                L.k_norm ? L.k_norm : dummy, cos_l, sin_l, m->q_out,
                                                                 L.k_pool, L.v_pool, cu, pos, bt, sh.num_seqs, T, nq, nkv, hd,
                                                                 c.rms_eps, qk_mode, KV_BLOCK, m->max_blocks_per_seq, s));
-            if (sh.pure_decode) {
+            if (layer_decode) {
                 RUN(paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, bt, kvl, sh.num_seqs,
                                                        sh.max_kv_len, nq, nkv, hd, KV_BLOCK, m->max_blocks_per_seq,
                                                        m->workspace, m->workspace_bytes, s));
             } else {
                 RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu, pos, bt, sh.num_seqs, T,
-                                               sh.max_q_len, sh.max_kv_len, nq, nkv, hd, c.sliding_window, KV_BLOCK,
+                                               sh.max_q_len, sh.max_kv_len, nq, nkv, hd, layer_window, KV_BLOCK,
                                                m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
             }
         }
@@ -814,7 +841,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             const int I = c.intermediate;
             RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
             RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
-            RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+            if (sandwich) {
+                // Gemma 3 (llama_family.rs:3357-3421): residual += norm(o, post_attention_layernorm); pre-MLP norm
+                RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+            } else {
+                RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+            }
             RUN(w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s));
             if (c.activation == 1) {
                 RUN(fused_gelu_tanh_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
@@ -823,23 +855,34 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             }
             RUN(w4_gemm_dense(L.down, m->act_out, m->mlp_out, T, m->workspace, m->workspace_bytes, s));
             RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
-            if (next_ln) {
+            if (sandwich) {
+                // residual += norm(mlp_out, post_feedforward_layernorm); next layer's input norm rides along
+                RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s));
+            } else if (next_ln) {
                 RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s));
             } else {
                 RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
             }
         }
         if (m->taps_enabled && m->taps) {
-            hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)T * H, 256)), dim3(256), 0, s, m->residual,
-                               m->taps + (size_t)li * c.max_tokens * H, (long)T * H);
+            if (sandwich)
+                FH_CHECK_HIP(hipMemcpyAsync(m->taps + (size_t)li * c.max_tokens * H, m->residual_f32, (size_t)T * H * 4,
+                                            hipMemcpyDeviceToDevice, s));
+            else
+                hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)T * H, 256)), dim3(256), 0, s, m->residual,
+                                   m->taps + (size_t)li * c.max_tokens * H, (long)T * H);
         }
     }
     m->taps_tokens = T;
     if (sh.num_sampled > 0) {
         // final norm + lm_head on the sampled rows only (same rows the reference packs,
         // qwen3_moe_forward_unified.rs:365-392)
-        RUN(gather_rows_f16(m->residual, sampled_idx, m->sampled_hidden, sh.num_sampled, H, s));
-        RUN(rms_norm_f16(m->sampled_hidden, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
+        if (sandwich) {
+            RUN(rms_norm_f32_to_f16(m->residual_f32, sampled_idx, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
+        } else {
+            RUN(gather_rows_f16(m->residual, sampled_idx, m->sampled_hidden, sh.num_sampled, H, s));
+            RUN(rms_norm_f16(m->sampled_hidden, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
+        }
         RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, c.vocab, H, m->workspace,
                              m->workspace_bytes, s));
         if (greedy) RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, nullptr, 0, sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, s));
@@ -881,7 +924,7 @@ int ferrum_hip_model_unified_forward(FerrumHipModel* m, const FerrumHipBatchItem
         reqs[i] = {it.seq_id, it.pos_offset + it.num_q_tokens, 0};
     }
     FH_REQUIRE(sh.m_total <= c.max_tokens, "unified_forward: %d tokens > max_tokens %d", sh.m_total, c.max_tokens);
-    if (c.sliding_window > 0) sh.pure_decode = false;
+    if (c.sliding_window > 0 && c.sliding_window_pattern == 0) sh.pure_decode = false;   // uniform window: varlen path on every layer
     if (int rc = reserve(m, reqs.data(), num_items, nullptr)) return rc;
 
     // index block

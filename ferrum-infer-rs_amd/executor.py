@@ -19,7 +19,8 @@ class ModelConfig(C.Structure):
         "sliding_window", "group_size", "kv_num_blocks", "max_seqs", "max_tokens")] + [
         ("rms_eps", C.c_float), ("_pad", C.c_float), ("rope_theta", C.c_double), ("rope_p0", C.c_double),
         ("rope_p1", C.c_double), ("rope_p2", C.c_double), ("rope_p3", C.c_double), ("tp_rank", C.c_int32),
-        ("tp_world", C.c_int32)]
+        ("tp_world", C.c_int32), ("sliding_window_pattern", C.c_int32), ("sandwich_norms", C.c_int32),
+        ("embed_scale", C.c_float), ("_pad2", C.c_float), ("rope_local_theta", C.c_double)]
 
 
 class BatchItem(C.Structure):
@@ -42,7 +43,7 @@ _DEFAULTS = dict(max_seq_len=512, has_qk_norm=0, activation=0, num_experts=0, to
                  max_seqs=32, max_tokens=512, rms_eps=1e-6, rope_theta=1e6, intermediate=0, tp_rank=0, tp_world=1)
 
 GLOBAL = {"embed": 0, "lm_head": 1, "final_norm": 2}
-LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4}
+LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4, "post_attn_ln": 5, "post_ffn_ln": 6}
 GPTQ = {"qkv": 0, "o": 1, "gate_up": 2, "down": 3, "expert_gate_up": 4, "expert_down": 5}
 
 
@@ -122,7 +123,7 @@ class Checkpoint:
         tied = C.c_int()
         _check(self.lib.ferrum_hip_checkpoint_model_config(self.h, max_seq_len_cap, C.byref(cfg), arch, C.c_size_t(128),
                                                            C.byref(tied)), "checkpoint_model_config")
-        d = {f: getattr(cfg, f) for f, _ in ModelConfig._fields_ if f != "_pad"}
+        d = {f: getattr(cfg, f) for f, _ in ModelConfig._fields_ if not f.startswith("_pad")}
         return d, arch.value.decode(), bool(tied.value)
 
 

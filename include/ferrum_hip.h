@@ -139,6 +139,15 @@ int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const
                                                int num_experts, int top_k, int max_blocks, int fused_silu_mul,
                                                void* stream);
 
+/* Sandwich-norm residual update on an fp32 residual stream (Gemma 3): `rms_norm_activation_add_to_f32` +
+ * `rms_norm_f32_to_activation` of the reference's device path (llama_family.rs:3381-3421) in one launch:
+ * residual_f32 += rms_norm(branch, w_branch);  norm_out = f16(rms_norm(residual_f32, w_next))  (w_next NULL → skipped). */
+int ferrum_hip_sandwich_add_rms_norm_f32(const void* branch_f16, const void* w_branch, float* residual_f32,
+                                         const void* w_next, float eps, void* norm_out_f16, int tokens, int dim, void* stream);
+/* out_f16[i] = rms_norm(residual_f32[row_idx ? row_idx[i] : i], w) — final norm / first input norm of the fp32 stream */
+int ferrum_hip_rms_norm_f32_to_f16(const float* x_f32, const int32_t* row_idx, const void* w, float eps, void* out_f16,
+                                   int n_rows, int dim, void* stream);
+
 /* ── paged KV: BackendPagedKv (traits.rs:1622-1904).  Block tables and block ids are the
  *    reference's (ferrum-models/src/common/paged_pool.rs); the bytes inside a block use the native
  *    MFMA-shaped tile layout (csrc/kv_layout.h).  Pools: [num_blocks][kv_heads][16·head_dim] fp16,
@@ -300,6 +309,15 @@ typedef struct {
     double rope_theta;
     double rope_p0, rope_p1, rope_p2, rope_p3;
     int32_t tp_rank, tp_world;    /* tensor-parallel shard of this process (world 1 = none) */
+    /* Gemma-3 layer semantics (llama_family.rs:520-552).  The load-time folds stay with the loader: RMSNorm `x̂·(1+w)`
+     * (+1 on every norm weight) and 1/√query_pre_attn_scalar (× √(head_dim/scalar) on q_norm), llama_family.rs:891-967. */
+    int32_t sliding_window_pattern; /* N > 0: layer (idx+1) % N == 0 is global (full attention, main RoPE table); the others
+                                       are local (sliding_window, local RoPE table).  0 = every layer uses sliding_window */
+    int32_t sandwich_norms;       /* post_attn / post_ffn norms applied to the branch BEFORE its residual add; the residual
+                                     stream is then kept in fp32 on the device (the reference's F32 residual shadow) */
+    float embed_scale;            /* 0 = none; else embedding rows × this (Gemma: bf16-rounded √hidden) */
+    float _pad2;
+    double rope_local_theta;      /* 0 = one table; else θ of the unscaled table the local layers use */
 } FerrumHipModelConfig;
 
 /* One item of a UnifiedBatch (model_executor.rs:354-386). */
@@ -326,7 +344,8 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
 int ferrum_hip_model_destroy(FerrumHipModel* model);
 /* Weight hand-over (host slices, copied/repacked to device).  which:
  *   global dense: 0 embed [V,H], 1 lm_head [V,H] (omit → tied to embed), 2 final_norm [H]
- *   layer dense : 0 input_ln [H], 1 post_ln [H], 2 q_norm [hd], 3 k_norm [hd], 4 router [E,H]
+ *   layer dense : 0 input_ln [H], 1 post_ln [H] (sandwich: pre_feedforward_layernorm), 2 q_norm [hd], 3 k_norm [hd],
+ *                 4 router [E,H], 5 post_attn_ln [H], 6 post_ffn_ln [H] (sandwich norms)
  *   gptq        : 0 qkv, 1 o, 2 gate_up, 3 down, 4 expert gate_up, 5 expert down               */
 int ferrum_hip_model_set_global_f32(FerrumHipModel* model, int which, const float* data);
 int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* model, int layer, int which, const float* data);

@@ -37,6 +37,7 @@ void fo_split_qkv(const float *, float *, float *, float *, int, int, int);
 void fo_fused_silu_mul_split(const float *, float *, int, int);
 void fo_fused_gelu_tanh_mul_split(const float *, float *, int, int);
 void fo_add_inplace(float *, const float *, long);
+void fo_scale_inplace(float *, float, long);
 void fo_qk_norm_rope(const float *, const float *, const float *, const float *, float *, int,
                      int, int, int, float, int);
 void fo_kv_cache_append_head_major(float *, float *, int, int, const float *, const float *,
@@ -65,10 +66,18 @@ typedef struct {
     float _pad;
     double rope_theta;
     double rope_p0, rope_p1, rope_p2, rope_p3;
+    /* Gemma-3 layer semantics (llama_family.rs:520-552): */
+    int32_t sliding_window_pattern; /* N > 0: layer (idx+1) % N == 0 is global (full attention, main rope table), the rest
+                                       are local (sliding_window, local rope table); 0 = uniform */
+    int32_t sandwich_norms;         /* post_attn_ln / post_ffn_ln applied to the branch BEFORE the residual add */
+    float embed_scale;              /* 0 = none; else embedding output × this */
+    float _pad2;
+    double rope_local_theta;        /* 0 = one table; else θ of the unscaled table local layers use */
 } fo_model_cfg;
 
 typedef struct {
     float *input_ln, *post_ln, *q_norm, *k_norm;
+    float *post_attn_ln, *post_ffn_ln;   /* sandwich norms (Gemma 3); post_ln is then pre_feedforward_layernorm */
     float *qkv_w, *o_w;          /* [n,k] f32 */
     float *gate_up_w, *down_w;   /* dense MLP */
     float *router_w;             /* [E,H] */
@@ -91,6 +100,7 @@ typedef struct {
     float *final_norm;
     fo_layer *layers;
     float *cos_t, *sin_t;
+    float *cos_local, *sin_local;   /* second rope table (local layers), NULL when rope_local_theta == 0 */
     fo_kv caches[FO_MAX_CACHES];
     /* debug taps: last call's hidden state after each layer [L][T][H] (optional) */
     float *tap_hidden;
@@ -116,6 +126,11 @@ FO_API fo_model *fo_model_new(const fo_model_cfg *cfg) {
     fo_build_rope_cache(cfg->rope_theta, cfg->head_dim, cfg->max_seq_len,
                         cfg->rope_scaling_kind, cfg->rope_p0, cfg->rope_p1, cfg->rope_p2,
                         cfg->rope_p3, m->cos_t, m->sin_t);
+    if (cfg->rope_local_theta > 0.0) {   /* llama_family.rs:1843: own θ, never rope-scaled */
+        m->cos_local = (float *)malloc(sizeof(float) * (long)cfg->max_seq_len * half);
+        m->sin_local = (float *)malloc(sizeof(float) * (long)cfg->max_seq_len * half);
+        fo_build_rope_cache(cfg->rope_local_theta, cfg->head_dim, cfg->max_seq_len, 0, 0, 0, 0, 0, m->cos_local, m->sin_local);
+    }
     return m;
 }
 
@@ -123,12 +138,13 @@ FO_API void fo_model_free(fo_model *m) {
     for (int l = 0; l < m->cfg.num_layers; l++) {
         fo_layer *L = &m->layers[l];
         free(L->input_ln); free(L->post_ln); free(L->q_norm); free(L->k_norm);
+        free(L->post_attn_ln); free(L->post_ffn_ln);
         free(L->qkv_w); free(L->o_w); free(L->gate_up_w); free(L->down_w);
         free(L->router_w); free(L->exp_gate_up_w); free(L->exp_down_w);
     }
     for (int c = 0; c < FO_MAX_CACHES; c++) { free(m->caches[c].k); free(m->caches[c].v); }
     free(m->layers); free(m->embed); free(m->lm_head); free(m->final_norm);
-    free(m->cos_t); free(m->sin_t); free(m->tap_hidden);
+    free(m->cos_t); free(m->sin_t); free(m->cos_local); free(m->sin_local); free(m->tap_hidden);
     free(m);
 }
 
@@ -140,7 +156,8 @@ FO_API void fo_model_set_global(fo_model *m, int which, const float *data) {
     else { free(m->final_norm); m->final_norm = fo_dup(data, m->cfg.hidden); }
 }
 
-/* which: 0 input_ln [H], 1 post_ln [H], 2 q_norm [hd], 3 k_norm [hd], 4 router [E,H] */
+/* which: 0 input_ln [H], 1 post_ln [H] (sandwich: pre_feedforward_layernorm), 2 q_norm [hd], 3 k_norm [hd], 4 router [E,H],
+ *        5 post_attn_ln [H], 6 post_ffn_ln [H] (sandwich norms) */
 FO_API void fo_model_set_layer_dense(fo_model *m, int layer, int which, const float *data) {
     fo_layer *L = &m->layers[layer];
     int H = m->cfg.hidden, hd = m->cfg.head_dim;
@@ -150,6 +167,8 @@ FO_API void fo_model_set_layer_dense(fo_model *m, int layer, int which, const fl
     case 2: free(L->q_norm); L->q_norm = fo_dup(data, hd); break;
     case 3: free(L->k_norm); L->k_norm = fo_dup(data, hd); break;
     case 4: free(L->router_w); L->router_w = fo_dup(data, (long)m->cfg.num_experts * H); break;
+    case 5: free(L->post_attn_ln); L->post_attn_ln = fo_dup(data, H); break;
+    case 6: free(L->post_ffn_ln); L->post_ffn_ln = fo_dup(data, H); break;
     }
 }
 
@@ -281,6 +300,8 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
     }
 
     fo_embedding_lookup(m->embed, tokens, T, residual, H);
+    if (g->embed_scale != 0.0f) fo_scale_inplace(residual, g->embed_scale, (long)T * H);   /* llama_family.rs:3656 */
+    float *branch = g->sandwich_norms ? (float *)malloc(sizeof(float) * (long)T * H) : NULL;
 
     for (int li = 0; li < g->num_layers; li++) {
         fo_layer *L = &m->layers[li];
@@ -289,26 +310,40 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
         const float *qn = L->q_norm ? L->q_norm : dummy;
         const float *kn = L->k_norm ? L->k_norm : dummy;
 
+        /* per-layer attention schedule (llama_layer_attention_schedule, llama_family.rs:1028-1045) */
+        const int pattern = g->sliding_window_pattern;
+        const int is_global = pattern == 0 || (li + 1) % pattern == 0;
+        const int layer_window = pattern == 0 ? g->sliding_window : (is_global ? 0 : g->sliding_window);
+        const float *cos_l = (!is_global && m->cos_local) ? m->cos_local : m->cos_t;
+        const float *sin_l = (!is_global && m->sin_local) ? m->sin_local : m->sin_t;
+
         fo_rms_norm(residual, L->input_ln, g->rms_eps, norm_out, T, H);
         fo_gemm(norm_out, L->qkv_w, qkv, T, qkv_dim, H);
         /* kv_layer.rs:437-495 unfused contig_write chain */
         fo_split_qkv(qkv, q_buf, k_buf, v_buf, T, q_dim, kv_dim);
-        fo_qk_norm_rope(q_buf, qn, m->cos_t, m->sin_t, q_hm, T, nh, hd, pos_offset, g->rms_eps, qk_mode);
-        fo_qk_norm_rope(k_buf, kn, m->cos_t, m->sin_t, k_hm, T, nkv, hd, pos_offset, g->rms_eps, qk_mode);
-        fo_qk_norm_rope(v_buf, qn, m->cos_t, m->sin_t, v_hm, T, nkv, hd, pos_offset, g->rms_eps, 0);
+        fo_qk_norm_rope(q_buf, qn, cos_l, sin_l, q_hm, T, nh, hd, pos_offset, g->rms_eps, qk_mode);
+        fo_qk_norm_rope(k_buf, kn, cos_l, sin_l, k_hm, T, nkv, hd, pos_offset, g->rms_eps, qk_mode);
+        fo_qk_norm_rope(v_buf, qn, cos_l, sin_l, v_hm, T, nkv, hd, pos_offset, g->rms_eps, 0);
         fo_kv_cache_append_head_major(cache->k + layer_kv, cache->v + layer_kv, cache->len,
                                       g->max_seq_len, k_hm, v_hm, T, nkv, hd);
         int new_len = cache->len + T;
         memset(attn_hm, 0, sizeof(float) * (long)T * q_dim);
         fo_cpu_attention(q_hm, cache->k + layer_kv, cache->v + layer_kv, attn_hm, T, new_len,
-                         1, pos_offset, nh, nkv, hd, scale, g->max_seq_len, g->sliding_window);
+                         1, pos_offset, nh, nkv, hd, scale, g->max_seq_len, layer_window);
         const float *attn_in = attn_hm;
         if (T > 1) {
             fo_transpose_head_to_token(attn_hm, attn_tm, T, nh, hd);
             attn_in = attn_tm;
         }
         fo_gemm(attn_in, L->o_w, o_out, T, H, q_dim);
-        fo_fused_add_rms_norm(residual, o_out, L->post_ln, g->rms_eps, norm_out, T, H);
+        if (g->sandwich_norms) {
+            /* llama_family.rs:3357-3436 (host path): norm the attention output FIRST, add, then the pre-MLP norm */
+            fo_rms_norm(o_out, L->post_attn_ln, g->rms_eps, branch, T, H);
+            fo_add_inplace(residual, branch, (long)T * H);
+            fo_rms_norm(residual, L->post_ln, g->rms_eps, norm_out, T, H);
+        } else {
+            fo_fused_add_rms_norm(residual, o_out, L->post_ln, g->rms_eps, norm_out, T, H);
+        }
 
         if (g->num_experts > 0) {
             fo_gemm(norm_out, L->router_w, router_logits, T, g->num_experts, H);
@@ -325,7 +360,12 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
             else fo_fused_silu_mul_split(gate_up, act, T, I);
             fo_gemm(act, L->down_w, mlp_out, T, H, I);
         }
-        fo_add_inplace(residual, mlp_out, (long)T * H);
+        if (g->sandwich_norms) {   /* post_feedforward_layernorm wraps the MLP output before its residual add */
+            fo_rms_norm(mlp_out, L->post_ffn_ln, g->rms_eps, branch, T, H);
+            fo_add_inplace(residual, branch, (long)T * H);
+        } else {
+            fo_add_inplace(residual, mlp_out, (long)T * H);
+        }
         if (m->tap_hidden && T <= m->tap_tokens)
             memcpy(m->tap_hidden + (long)li * m->tap_tokens * H, residual, sizeof(float) * (long)T * H);
     }
@@ -338,6 +378,6 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
 
     free(residual); free(norm_out); free(qkv); free(q_buf); free(k_buf); free(v_buf);
     free(q_hm); free(k_hm); free(v_hm); free(attn_hm); free(attn_tm); free(o_out);
-    free(mlp_out); free(gate_up); free(act); free(router_logits); free(eids); free(ew);
+    free(mlp_out); free(gate_up); free(act); free(router_logits); free(eids); free(ew); free(branch);
     return 0;
 }

@@ -454,7 +454,9 @@ class ModelCfg(C.Structure):
         "max_seq_len", "has_qk_norm", "activation", "num_experts", "top_k", "expert_inter",
         "norm_topk_prob", "rope_scaling_kind", "sliding_window")] + [
         ("rms_eps", C.c_float), ("_pad", C.c_float), ("rope_theta", C.c_double),
-        ("rope_p0", C.c_double), ("rope_p1", C.c_double), ("rope_p2", C.c_double), ("rope_p3", C.c_double)]
+        ("rope_p0", C.c_double), ("rope_p1", C.c_double), ("rope_p2", C.c_double), ("rope_p3", C.c_double),
+        ("sliding_window_pattern", C.c_int32), ("sandwich_norms", C.c_int32), ("embed_scale", C.c_float), ("_pad2", C.c_float),
+        ("rope_local_theta", C.c_double)]
 
 
 def siphash(c, d, k0, k1, data):
@@ -474,7 +476,7 @@ class OracleModel:
     """CPU restatement of LlamaFamilyModel<CpuBackend> / Qwen3-MoE (see ferrum_oracle_model.c)."""
 
     GLOBAL = {"embed": 0, "lm_head": 1, "final_norm": 2}
-    LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4}
+    LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4, "post_attn_ln": 5, "post_ffn_ln": 6}
     GPTQ = {"qkv": 0, "o": 1, "gate_up": 2, "down": 3, "expert_gate_up": 4, "expert_down": 5}
 
     def __init__(self, **kw):

@@ -24,13 +24,16 @@ def synth_gptq(k, n, seed, symmetric=True, group=128):
 class TinyModel:
     def __init__(self, moe, layers=2, hidden=256, nq=4, nkv=2, hd=128, inter=256, vocab=512, experts=8, top_k=2,
                  expert_inter=128, qk_norm=True, seed=0, max_seq_len=256, activation=0, sliding_window=0,
-                 rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False):
+                 rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False, sandwich=False,
+                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0):
         self.cfg = dict(num_layers=layers, hidden=hidden, num_heads=nq, num_kv_heads=nkv, head_dim=hd,
                         intermediate=0 if moe else inter, vocab=vocab, max_seq_len=max_seq_len, has_qk_norm=int(qk_norm),
                         activation=activation, num_experts=experts if moe else 0, top_k=top_k if moe else 0,
                         expert_inter=expert_inter if moe else 0, norm_topk_prob=1, rope_scaling_kind=rope_scaling_kind,
                         sliding_window=sliding_window, rms_eps=1e-6, rope_theta=rope_theta, rope_p0=rope_p[0],
-                        rope_p1=rope_p[1], rope_p2=rope_p[2], rope_p3=rope_p[3])
+                        rope_p1=rope_p[1], rope_p2=rope_p[2], rope_p3=rope_p[3], sandwich_norms=int(sandwich),
+                        sliding_window_pattern=sliding_window_pattern, rope_local_theta=rope_local_theta,
+                        embed_scale=embed_scale)
         rng = np.random.default_rng(seed)
         H, V = hidden, vocab
         qd, kvd = nq * hd, nkv * hd
@@ -42,6 +45,9 @@ class TinyModel:
         for li in range(layers):
             L = {"dense": {"input_ln": f16r(1.0 + 0.1 * rng.standard_normal(H)),
                            "post_ln": f16r(1.0 + 0.1 * rng.standard_normal(H))}, "gptq": {}, "experts": {}}
+            if sandwich:
+                L["dense"]["post_attn_ln"] = f16r(1.0 + 0.1 * rng.standard_normal(H))
+                L["dense"]["post_ffn_ln"] = f16r(1.0 + 0.1 * rng.standard_normal(H))
             if qk_norm:
                 L["dense"]["q_norm"] = f16r(1.0 + 0.1 * rng.standard_normal(hd))
                 L["dense"]["k_norm"] = f16r(1.0 + 0.1 * rng.standard_normal(hd))

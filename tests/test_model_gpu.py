@@ -52,6 +52,26 @@ def test_gelu_activation_model(pkg):
     _assert_parity(res)
 
 
+def test_gemma3_layer_semantics(pkg):
+    """Gemma-3 family switches (llama_family.rs:520-552,683-703): sandwich norms on an fp32 residual stream, 2:1 local/global
+    layer schedule (window 8 on local layers, own unscaled RoPE table), linear-scaled global RoPE, GeGLU, scaled embeddings.
+    The 37-token prompt exceeds the local window, so the schedule and both tables matter."""
+    from tests import modelgen
+    res = modelgen.run_parity_case(pkg, moe=False, layers=4, prompt_len=37, decode_steps=5, seed=61, activation=1,
+                                   sandwich=True, sliding_window=8, sliding_window_pattern=2, rope_local_theta=10000.0,
+                                   rope_theta=1e6, rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=16.0)
+    _assert_parity(res)
+    # the schedule is observable: the same model with every layer global gives different logits
+    res2 = modelgen.run_parity_case(pkg, moe=False, layers=4, prompt_len=37, decode_steps=0, seed=61, activation=1,
+                                    sandwich=True, sliding_window=0, sliding_window_pattern=0, rope_local_theta=0.0,
+                                    rope_theta=1e6, rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=16.0)
+    _assert_parity(res2)
+    assert res["steps"][0][3] >= 0 and abs(res["steps"][0][2] - 1.0) < 1e-3
+    a = res["model"].unified_forward([(7, np.arange(37, dtype=np.uint32), 0, True)], greedy=True, want_logits=True)[1][0]
+    b = res2["model"].unified_forward([(7, np.arange(37, dtype=np.uint32), 0, True)], greedy=True, want_logits=True)[1][0]
+    assert modelgen.cosine(a, b) < 0.9999
+
+
 def test_mixed_batch_chunked_prefill_matches_per_sequence_oracle(pkg):
     """unified_decode contract (model_executor.rs:354-418): decode rows and prefill chunks in one batch;
     only final-chunk items return logits, in item order."""
