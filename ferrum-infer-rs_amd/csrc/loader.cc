@@ -588,13 +588,14 @@ int ferrum_hip_checkpoint_model_config(const FerrumHipCheckpoint* ck, int max_se
     memset(cfg, 0, sizeof(*cfg));
     const std::string arch = architecture(ck);
     if (arch_out && arch_cap) snprintf(arch_out, arch_cap, "%s", arch.c_str());
-    enum { Llama, Qwen3, Qwen3Moe, Mistral } fam;
+    enum { Llama, Qwen3, Qwen3Moe, Mistral, Gemma3 } fam;
     if (arch == "LlamaForCausalLM" || arch == "llama") fam = Llama;
+    else if (arch == "Gemma3ForCausalLM" || arch == "Gemma3ForConditionalGeneration" || arch == "gemma3_text" || arch == "gemma3") fam = Gemma3;
     else if (arch == "Qwen3ForCausalLM" || arch == "qwen3") fam = Qwen3;
     else if (arch == "Qwen3MoeForCausalLM" || arch == "qwen3_moe") fam = Qwen3Moe;
     else if (arch == "MistralForCausalLM" || arch == "mistral") fam = Mistral;
     else {
-        set_error("checkpoint: architecture '%s' is not supported by the HIP runner (Llama, Qwen3, Qwen3-MoE, Mistral)", arch.c_str());
+        set_error("checkpoint: architecture '%s' is not supported by the HIP runner (Llama, Mistral, Qwen3, Qwen3-MoE, Gemma-3)", arch.c_str());
         return FERRUM_HIP_UNSUPPORTED;
     }
     auto u = [&](const char* key, const char* alt, double dflt) {
@@ -618,7 +619,7 @@ int ferrum_hip_checkpoint_model_config(const FerrumHipCheckpoint* ck, int max_se
     const Value* act = cfg_get(ck, "hidden_act");
     if (!act) act = cfg_get(ck, "hidden_activation");
     cfg->activation = act && act->kind == Value::Str && act->str == "gelu_pytorch_tanh" ? 1 : 0;
-    cfg->has_qk_norm = fam == Qwen3 || fam == Qwen3Moe;
+    cfg->has_qk_norm = fam == Qwen3 || fam == Qwen3Moe || fam == Gemma3;
     // rope theta: checkpoint value, else the family default (llama_family.rs:654-680)
     const Value* th = cfg_get(ck, "rope_theta");
     if (!(th && th->is_num())) th = cfg_get(ck, "rotary_emb_base");
@@ -657,6 +658,19 @@ int ferrum_hip_checkpoint_model_config(const FerrumHipCheckpoint* ck, int max_se
         cfg->norm_topk_prob = nt && nt->kind == Value::Bool ? nt->b : 1;
         cfg->intermediate = 0;
     }
+    if (fam == Gemma3) {
+        // gemma3_from_def (llama_family.rs:683-703): 5:1 local/global schedule, own local θ, sandwich norms, √hidden embeddings
+        // rounded through bf16 like HF; the norm-weight folds (+1, q_norm × √(head_dim/query_pre_attn_scalar)) happen at load.
+        cfg->sliding_window_pattern = (int)num_or(cfg_get(ck, "sliding_window_pattern"), 6.0);
+        cfg->rope_local_theta = num_or(cfg_get(ck, "rope_local_base_freq"), 10000.0);
+        cfg->sandwich_norms = 1;
+        float es = (float)std::sqrt((double)cfg->hidden);
+        uint32_t bits;
+        memcpy(&bits, &es, 4);
+        bits = (bits + 0x7FFFu + ((bits >> 16) & 1u)) & 0xFFFF0000u;     // bf16 round-to-nearest-even (finite input)
+        memcpy(&es, &bits, 4);
+        cfg->embed_scale = es;
+    }
     cfg->group_size = ck->group_size > 0 ? ck->group_size : 128;
     cfg->tp_world = 1;
     if (tied_lm_head) *tied_lm_head = find(ck, "lm_head.weight") == nullptr;
@@ -674,14 +688,25 @@ int ferrum_hip_model_load_checkpoint(FerrumHipModel* model, const FerrumHipCheck
                "model_load_checkpoint: the HIP runner loads GPTQ INT4 checkpoints (quant_method=%s bits=%d)",
                ck->has_quant ? ck->quant_method.c_str() : "none", ck->bits);
     std::vector<float> buf;
-    auto dense_global = [&](int which, const std::string& name) -> int {
+    // fold_norm_weight (llama_family.rs:949-967): Gemma RMSNorm is x̂·(1+w) → w' = (w + 1)·scale at load time
+    const bool unit_offset = c.sandwich_norms != 0;
+    double q_scale = 1.0;
+    if (unit_offset)
+        if (const Value* s = cfg_get(ck, "query_pre_attn_scalar"); s && s->is_num() && s->num > 0.0)
+            q_scale = std::sqrt((double)c.head_dim / s->num);
+    auto fold = [&](float scale) {
+        if (!unit_offset && scale == 1.0f) return;
+        for (float& x : buf) x = (x + (unit_offset ? 1.0f : 0.0f)) * scale;
+    };
+    auto dense_global = [&](int which, const std::string& name, bool is_norm) -> int {
         if (int rc = read_f32(ck, name, buf, nullptr)) return rc;
+        if (is_norm) fold(1.0f);
         return ferrum_hip_model_set_global_f32(model, which, buf.data());
     };
-    if (int rc = dense_global(0, "model.embed_tokens.weight")) return rc;
+    if (int rc = dense_global(0, "model.embed_tokens.weight", false)) return rc;
     if (!tied)
-        if (int rc = dense_global(1, "lm_head.weight")) return rc;
-    if (int rc = dense_global(2, "model.norm.weight")) return rc;
+        if (int rc = dense_global(1, "lm_head.weight", false)) return rc;
+    if (int rc = dense_global(2, "model.norm.weight", true)) return rc;
     FusedGptq f;
     auto gptq = [&](int layer, int which, int expert, const std::vector<std::string>& parts) -> int {
         if (int rc = read_gptq_fused(ck, parts, &f)) return rc;
@@ -690,22 +715,29 @@ int ferrum_hip_model_load_checkpoint(FerrumHipModel* model, const FerrumHipCheck
     };
     for (int li = 0; li < c.num_layers; li++) {
         const std::string p = "model.layers." + std::to_string(li) + ".";
-        auto dense_layer = [&](int which, const std::string& name) -> int {
+        auto dense_layer = [&](int which, const std::string& name, float norm_scale = 0.0f) -> int {
             if (int rc = read_f32(ck, p + name, buf, nullptr)) return rc;
+            if (norm_scale != 0.0f) fold(norm_scale);
             return ferrum_hip_model_set_layer_dense_f32(model, li, which, buf.data());
         };
-        if (int rc = dense_layer(0, "input_layernorm.weight")) return rc;
-        if (int rc = dense_layer(1, "post_attention_layernorm.weight")) return rc;
+        if (int rc = dense_layer(0, "input_layernorm.weight", 1.0f)) return rc;
+        if (c.sandwich_norms) {   // llama_family.rs:913-921: Gemma naming
+            if (int rc = dense_layer(1, "pre_feedforward_layernorm.weight", 1.0f)) return rc;
+            if (int rc = dense_layer(5, "post_attention_layernorm.weight", 1.0f)) return rc;
+            if (int rc = dense_layer(6, "post_feedforward_layernorm.weight", 1.0f)) return rc;
+        } else {
+            if (int rc = dense_layer(1, "post_attention_layernorm.weight", 1.0f)) return rc;
+        }
         if (c.has_qk_norm && find(ck, p + "self_attn.q_norm.weight") && find(ck, p + "self_attn.k_norm.weight")) {
-            if (int rc = dense_layer(2, "self_attn.q_norm.weight")) return rc;
-            if (int rc = dense_layer(3, "self_attn.k_norm.weight")) return rc;
+            if (int rc = dense_layer(2, "self_attn.q_norm.weight", (float)q_scale)) return rc;
+            if (int rc = dense_layer(3, "self_attn.k_norm.weight", 1.0f)) return rc;
         }
         FH_REQUIRE(!find(ck, p + "self_attn.q_proj.bias") && !find(ck, p + "self_attn.qkv_proj.bias"),
                    "model_load_checkpoint: attention biases are not supported by the runner (layer %d)", li);
         if (int rc = gptq(li, 0, 0, linear_parts(ck, p + "self_attn.", "qkv_proj", {"q_proj", "k_proj", "v_proj"}))) return rc;
         if (int rc = gptq(li, 1, 0, {p + "self_attn.o_proj"})) return rc;
         if (c.num_experts > 0) {
-            if (int rc = dense_layer(4, "mlp.gate.weight")) return rc;
+            if (int rc = dense_layer(4, "mlp.gate.weight")) return rc;   // router: not a norm, no fold
             for (int e = 0; e < c.num_experts; e++) {
                 const std::string ep = p + "mlp.experts." + std::to_string(e) + ".";
                 if (int rc = gptq(li, 4, e, linear_parts(ck, ep, "gate_up_proj", {"gate_proj", "up_proj"}))) return rc;

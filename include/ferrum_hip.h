@@ -376,7 +376,8 @@ int ferrum_hip_model_prefix_cache_stats(const FerrumHipModel* model, uint64_t* h
  *    canonicalised to 0x77777777 (:1242-1246) and g_idx validation (:1288-1324), quantize_config.json or config.json
  *    "quantization_config" (:1475-1530), config.json mapping (ferrum-models/src/definition.rs:225-375,
  *    models/llama_family.rs:596-680,733-810, moe_config.rs:91-130), tensor names (llama_family.rs:900-945,
- *    qwen3_moe/load.rs:178-260).  Architectures: Llama, Mistral, Qwen3, Qwen3-MoE; others → FERRUM_HIP_UNSUPPORTED. ── */
+ *    qwen3_moe/load.rs:178-260).  Architectures: Llama, Mistral, Qwen3, Qwen3-MoE, Gemma-3 (norm folds of
+ *    llama_family.rs:891-967 applied at load); others → FERRUM_HIP_UNSUPPORTED. ── */
 typedef struct FerrumHipCheckpoint FerrumHipCheckpoint;
 int ferrum_hip_checkpoint_open(FerrumHipCheckpoint** ck, const char* model_dir);
 int ferrum_hip_checkpoint_close(FerrumHipCheckpoint* ck);

@@ -97,7 +97,7 @@ class TinyModel:
 
 
 def write_checkpoint(tm, out_dir, arch, shards=1, fused_names=False, dense_dtype="F16", embedded_quant_config=False,
-                     qzeros_noise=False):
+                     qzeros_noise=False, gemma=None):
     """Write a TinyModel as an HF-style GPTQ checkpoint directory: config.json, quantize_config.json (or the embedded
     "quantization_config"), model.safetensors or an index + shards.  qkv / gate_up are split into q|k|v and gate|up parts
     like real checkpoints unless fused_names.  Tensor names as the reference reads them (llama_family.rs:900-945,
@@ -139,6 +139,9 @@ def write_checkpoint(tm, out_dir, arch, shards=1, fused_names=False, dense_dtype
         dense("lm_head.weight", tm.glob["lm_head"])
     names = {"input_ln": "input_layernorm.weight", "post_ln": "post_attention_layernorm.weight",
              "q_norm": "self_attn.q_norm.weight", "k_norm": "self_attn.k_norm.weight", "router": "mlp.gate.weight"}
+    if gemma:   # Gemma naming (llama_family.rs:913-921): the pre-MLP norm is pre_feedforward_layernorm
+        names.update(post_ln="pre_feedforward_layernorm.weight", post_attn_ln="post_attention_layernorm.weight",
+                     post_ffn_ln="post_feedforward_layernorm.weight")
     for li, L in enumerate(tm.layers):
         p = f"model.layers.{li}."
         for key, a in L["dense"].items():
@@ -183,6 +186,16 @@ def write_checkpoint(tm, out_dir, arch, shards=1, fused_names=False, dense_dtype
         cfgj["rope_scaling"] = {"type": "linear", "factor": c["rope_p0"]}
     if c["sliding_window"]:
         cfgj["sliding_window"] = c["sliding_window"]
+    if gemma:
+        cfgj.pop("hidden_act")
+        cfgj.update(hidden_activation="gelu_pytorch_tanh", sliding_window_pattern=c["sliding_window_pattern"],
+                    rope_local_base_freq=c["rope_local_theta"], query_pre_attn_scalar=gemma["query_pre_attn_scalar"])
+        if gemma.get("nested"):                            # Gemma3ForConditionalGeneration nests the text model's fields
+            keep = {"architectures": cfgj.pop("architectures")}
+            qc_embedded = cfgj.pop("quantization_config", None)
+            cfgj = {**keep, "model_type": "gemma3", "text_config": cfgj, "vision_config": {"hidden_size": 1152}}
+            if qc_embedded:
+                cfgj["quantization_config"] = qc_embedded
     qc = {"quant_method": "gptq", "bits": 4, "group_size": 128, "desc_act": False, "sym": True}
     if embedded_quant_config:
         cfgj["quantization_config"] = qc

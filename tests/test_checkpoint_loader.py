@@ -93,7 +93,17 @@ def test_config_mapping_defaults_and_rope_scaling(pkg, tmp_path):
     with pytest.raises(RuntimeError, match="missing num_experts"):
         cfg({"architectures": ["Qwen3MoeForCausalLM"], "moe_intermediate_size": 768})
     with pytest.raises(RuntimeError, match="not supported"):
-        cfg({"architectures": ["Gemma3ForCausalLM"]})
+        cfg({"architectures": ["GPT2LMHeadModel"]})
+    # Gemma 3 (gemma3_from_def, llama_family.rs:683-703), nested text_config flattened over the root
+    d, arch, _ = cfg({"architectures": ["Gemma3ForConditionalGeneration"], "model_type": "gemma3",
+                      "text_config": {"hidden_size": 1152, "num_attention_heads": 4, "num_key_value_heads": 1, "head_dim": 256,
+                                      "num_hidden_layers": 26, "intermediate_size": 6912, "vocab_size": 262144,
+                                      "hidden_activation": "gelu_pytorch_tanh", "sliding_window": 512,
+                                      "query_pre_attn_scalar": 256, "rope_scaling": {"rope_type": "linear", "factor": 8.0}}})
+    assert (d["sandwich_norms"], d["sliding_window_pattern"], d["rope_local_theta"], d["activation"]) == (1, 6, 10000.0, 1)
+    assert (d["has_qk_norm"], d["sliding_window"], d["rope_theta"], d["rope_scaling_kind"], d["head_dim"]) == (1, 512, 1e6, 1, 256)
+    es = np.float32(np.sqrt(1152.0))                        # bf16_round(√hidden): low mantissa bits cleared (llama_family.rs:5951)
+    assert np.float32(d["embed_scale"]).view(np.uint32) & 0xFFFF == 0 and abs(d["embed_scale"] - es) < 0.25
     with pytest.raises(RuntimeError, match="no safetensors"):
         pkg.Checkpoint(str(tmp_path / "missing"))
 
@@ -152,3 +162,34 @@ def test_model_loaded_from_checkpoint_equals_direct_load(pkg, tmp_path, moe, arc
     assert np.array_equal(l1, l2) and np.array_equal(t1, t2)
     om = tm.oracle_model()
     assert modelgen.cosine(om.forward(0, prompt, 0), l2[0]) > 0.999
+
+
+@pytest.mark.gpu
+def test_gemma3_checkpoint_folds_norm_weights(pkg, tmp_path):
+    """Gemma-3 checkpoints store RMSNorm weights as w − 1 and expect q_norm × √(head_dim/query_pre_attn_scalar)
+    (fold_norm_weight, llama_family.rs:891-967).  A model loaded from such a checkpoint equals a model handed the folded
+    arrays directly, and both match the oracle."""
+    from tests import modelgen
+    kw = dict(activation=1, sandwich=True, sliding_window=8, sliding_window_pattern=2, rope_local_theta=10000.0,
+              rope_theta=1e6, rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0))
+    stored = modelgen.TinyModel(False, layers=2, seed=71, **kw)           # what the files hold (norms = w − 1 convention)
+    qpas = 256.0
+    q_scale = np.float32(np.sqrt(stored.cfg["head_dim"] / qpas))
+    es = np.float32(np.sqrt(stored.cfg["hidden"])).view(np.uint32)
+    es = np.uint32((int(es) + 0x7FFF + ((int(es) >> 16) & 1)) & 0xFFFF0000).view(np.float32)
+    eff = modelgen.TinyModel(False, layers=2, seed=71, embed_scale=float(es), **kw)   # what the runner must end up with
+    fold = lambda w, s=np.float32(1.0): ((w.astype(np.float32) + np.float32(1.0)) * s).astype(np.float32)
+    eff.glob["final_norm"] = fold(stored.glob["final_norm"])
+    for Ls, Le in zip(stored.layers, eff.layers):
+        for key in Ls["dense"]:
+            Le["dense"][key] = fold(Ls["dense"][key], q_scale if key == "q_norm" else np.float32(1.0))
+    modelgen.write_checkpoint(stored, str(tmp_path), "Gemma3ForConditionalGeneration",
+                              gemma=dict(query_pre_attn_scalar=qpas, nested=True))
+    loaded = pkg.HipModel.from_checkpoint(str(tmp_path), kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    direct = eff.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    rng = np.random.default_rng(4)
+    prompt = rng.integers(0, stored.cfg["vocab"], size=29).astype(np.uint32)
+    _, l1 = direct.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
+    _, l2 = loaded.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
+    assert np.array_equal(l1, l2)
+    assert modelgen.cosine(eff.oracle_model().forward(0, prompt, 0), l2[0]) > 0.999
