@@ -154,6 +154,11 @@ FULL_DIMS = {
     "qwen3-30b-a3b": dict(moe=True, hidden=2048, nq=32, nkv=4, hd=128, experts=128, top_k=8, expert_inter=768, c=32),
     "llama31-8b": dict(moe=False, hidden=4096, nq=32, nkv=8, hd=128, inter=14336, qk_norm=False, rope_theta=500000.0,
                        rope_scaling_kind=2, rope_p=(8.0, 1.0, 4.0, 8192.0), c=20),
+    # Gemma-3 27B (configs[3]) layer at TP=1 dims: sandwich norms / fp32 residual, GeGLU, hidden 5376 = 42 quant groups;
+    # two layers so that one is local (window 1024, θ 10k) and one global (linear-scaled θ 1M)
+    "gemma3-27b": dict(moe=False, hidden=5376, nq=32, nkv=16, hd=128, inter=21504, activation=1, sandwich=True,
+                       sliding_window=1024, sliding_window_pattern=2, rope_local_theta=10000.0, rope_theta=1e6,
+                       rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=73.5, layers=2, c=18, plen=2, steps=1),
 }
 
 
@@ -162,11 +167,11 @@ def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     from tests import modelgen
     kw = dict(FULL_DIMS[name])
     c, moe = kw.pop("c"), kw.pop("moe")
-    tm = modelgen.TinyModel(moe, layers=1, vocab=2048, seed=41, max_seq_len=64, **kw)
+    layers, plen, steps = kw.pop("layers", 1), kw.pop("plen", 3), kw.pop("steps", 2)
+    tm = modelgen.TinyModel(moe, layers=layers, vocab=2048, seed=41, max_seq_len=64, **kw)
     om = tm.oracle_model()
     hm = tm.hip_model(pkg, kv_num_blocks=c + 4, max_seqs=c, max_tokens=4 * c)
     rng = np.random.default_rng(42)
-    plen, steps = 3, 2
     prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
     toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
     cur = np.zeros(c, np.uint32)
@@ -205,7 +210,7 @@ def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     assert near <= c and route_ties <= c // 4                    # near-ties are rare; most rows must be decided
     for i in (0, c - 1):
         for is_v in (0, 1):
-            assert modelgen.nmse(om.read_kv(i, 0, is_v), hm.read_kv(i, 0, is_v)) < 3e-3
+            assert modelgen.nmse(om.read_kv(i, layers - 1, is_v), hm.read_kv(i, layers - 1, is_v)) < 3e-3
     assert [hm.block_table(i)[0] for i in range(c)] == [[i] for i in range(c)]   # one block each, ids in arrival order
 
 
