@@ -35,6 +35,9 @@ int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* q
                    W4HostPacked* out);
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream);
+int w4_gemm_dense_lds_splits(const W4Device& w, int m);
+int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_inout,
+                            int* rows_pad_out, int* n_pad_out, hipStream_t stream);
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
                 const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs,
                 int max_blocks, int top_k, int fused_silu, hipStream_t stream);
@@ -70,6 +73,11 @@ int fused_gelu_tanh_mul_split_f16(const __half* gate_up, __half* out, int tokens
 int add_inplace_f16(__half* residual, const __half* x, long len, hipStream_t s);
 int sandwich_add_rms_norm_f32(const __half* branch, const __half* w_branch, float* residual, const __half* w_next, float eps,
                               __half* norm_out, int tokens, int dim, hipStream_t s);
+int sandwich_add_rms_norm_f32_slabs(const float* slabs, int S, long slab_stride, int ld_slab, const __half* w_branch,
+                                    float* residual, const __half* w_next, float eps, __half* norm_out, int tokens, int dim,
+                                    hipStream_t s);
+int fused_gated_act_slabs_f16(const float* slabs, int S, long slab_stride, int ld, __half* out, int tokens, int im, int gelu,
+                              hipStream_t s);
 int rms_norm_f32_to_f16(const float* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int n_rows, int dim,
                         hipStream_t s);
 int scale_inplace_f16(__half* buf, float scale, long len, hipStream_t s);

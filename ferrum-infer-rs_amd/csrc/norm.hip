@@ -114,8 +114,10 @@ int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, 
 // ── fp32 residual stream (Gemma-3 sandwich norms) ────────────────────────────────────────────────
 // residual += rms_norm(branch)·w_branch (all f32, branch read as fp16);  norm_out = f16(rms_norm(residual)·w_next).
 // One 256-thread workgroup per token, the row held in registers between the two reductions (H ≤ 8192).
+template <bool SLABS>
 __global__ __launch_bounds__(256) void sandwich_add_norm_f32_kernel(const __half* __restrict__ branch,
-                                                                     const __half* __restrict__ w_branch,
+                                                                     const float* __restrict__ slabs, int S, long slab_stride,
+                                                                     int ld_slab, const __half* __restrict__ w_branch,
                                                                      float* __restrict__ residual,
                                                                      const __half* __restrict__ w_next, float eps,
                                                                      __half* __restrict__ norm_out, int H) {
@@ -129,9 +131,21 @@ __global__ __launch_bounds__(256) void sandwich_add_norm_f32_kernel(const __half
     for (int c = 0; c < CH; c++) {
         const int i = threadIdx.x + c * 256;
         if (i < nvec) {
-            const half8 v = *reinterpret_cast<const half8*>(branch + row * H + i * 8);
+            if (SLABS) {   // branch = S fp32 split-K slabs, summed in slab order and rounded like the fp16 GEMM output
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int z = 0; z < S; z++) {
+                    const float4v* sp = reinterpret_cast<const float4v*>(slabs + z * slab_stride + row * ld_slab + i * 8);
+                    const float4v a0 = sp[0], a1 = sp[1];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { x[c][j] = (float)v[j]; ss += x[c][j] * x[c][j]; }
+                    for (int j = 0; j < 4; j++) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { x[c][j] = (float)(_Float16)acc[j]; ss += x[c][j] * x[c][j]; }
+            } else {
+                const half8 v = *reinterpret_cast<const half8*>(branch + row * H + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) { x[c][j] = (float)v[j]; ss += x[c][j] * x[c][j]; }
+            }
         }
     }
     auto block_sum = [&](float v) {
@@ -180,8 +194,18 @@ int sandwich_add_rms_norm_f32(const __half* branch, const __half* w_branch, floa
                               __half* norm_out, int tokens, int dim, hipStream_t s) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(dim % 8 == 0 && dim <= 8192, "sandwich_add_rms_norm_f32: dim=%d must be a multiple of 8, <= 8192", dim);
-    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel, dim3(tokens), dim3(256), 0, s, branch, w_branch, residual, w_next, eps,
-                       norm_out, dim);
+    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel<false>, dim3(tokens), dim3(256), 0, s, branch, nullptr, 0, 0L, 0, w_branch,
+                       residual, w_next, eps, norm_out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+int sandwich_add_rms_norm_f32_slabs(const float* slabs, int S, long slab_stride, int ld_slab, const __half* w_branch,
+                                    float* residual, const __half* w_next, float eps, __half* norm_out, int tokens, int dim,
+                                    hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0 && dim <= 8192 && S >= 1, "sandwich_add_rms_norm_f32_slabs: dim=%d S=%d", dim, S);
+    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel<true>, dim3(tokens), dim3(256), 0, s, nullptr, slabs, S, slab_stride, ld_slab,
+                       w_branch, residual, w_next, eps, norm_out, dim);
     FH_CHECK_LAUNCH();
     return 0;
 }
@@ -261,6 +285,51 @@ __global__ void gated_act_kernel(const __half* __restrict__ gate_up, __half* __r
         o[j] = (_Float16)(a * uf);
     }
     *reinterpret_cast<half8*>(out + t * im + i * 8) = o;
+}
+
+// Same, with the gate_up projection arriving as S fp32 split-K slabs [S][rows_pad][ld]: summed in slab order and rounded
+// to fp16 first, so the result is bit-identical to reduce → fused_*_mul_split (one launch instead of two).
+template <bool GELU>
+__global__ void gated_act_slabs_kernel(const float* __restrict__ slabs, int S, long slab_stride, int ld,
+                                       __half* __restrict__ out, int im) {
+    const long t = blockIdx.y;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (im >> 3)) return;
+    float g[8], u[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { g[j] = 0.f; u[j] = 0.f; }
+    for (int z = 0; z < S; z++) {
+        const float4v* gp = reinterpret_cast<const float4v*>(slabs + z * slab_stride + t * ld + i * 8);
+        const float4v* up = reinterpret_cast<const float4v*>(slabs + z * slab_stride + t * ld + im + i * 8);
+        const float4v g0 = gp[0], g1 = gp[1], u0 = up[0], u1 = up[1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { g[j] += g0[j]; g[4 + j] += g1[j]; u[j] += u0[j]; u[4 + j] += u1[j]; }
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float gf = (float)(_Float16)g[j], uf = (float)(_Float16)u[j];
+        float a;
+        if (GELU) {
+            float inner = 0.79788456f * (gf + 0.044715f * gf * gf * gf);
+            a = 0.5f * gf * (1.0f + tanhf(inner));
+        } else {
+            a = gf / (1.0f + __expf(-gf));
+        }
+        o[j] = (_Float16)(a * uf);
+    }
+    *reinterpret_cast<half8*>(out + t * im + i * 8) = o;
+}
+
+int fused_gated_act_slabs_f16(const float* slabs, int S, long slab_stride, int ld, __half* out, int tokens, int im, int gelu,
+                              hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(im % 8 == 0 && S >= 1 && ld >= 2 * im, "fused_gated_act_slabs: intermediate=%d S=%d ld=%d", im, S, ld);
+    dim3 grid(cdiv(im / 8, 256), tokens);
+    if (gelu) hipLaunchKernelGGL(gated_act_slabs_kernel<true>, grid, dim3(256), 0, s, slabs, S, slab_stride, ld, out, im);
+    else hipLaunchKernelGGL(gated_act_slabs_kernel<false>, grid, dim3(256), 0, s, slabs, S, slab_stride, ld, out, im);
+    FH_CHECK_LAUNCH();
+    return 0;
 }
 
 int fused_silu_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s) {

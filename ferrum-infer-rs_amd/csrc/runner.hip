@@ -243,6 +243,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_ROUTE_PARTS")) m->route_parts = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_FUSE_ROPE")) m->fuse_rope_attn = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_O_SLABS")) m->o_slabs = std::max(0, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_DENSE_SLABS")) m->dense_slabs = atoi(e) != 0;
     *model = m;
     return 0;
 }
@@ -839,6 +840,34 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             }
         } else {
             const int I = c.intermediate;
+            // 17–32 rows, one GPU: every projection of the MLP block writes fp32 split-K slabs (LDS-shared activations) and
+            // the consumer that exists anyway — add+norm, gated activation — sums them: no reduce launches.
+            const bool slab_chain = m->dense_slabs && c.tp_world == 1 && T > 16 && T <= 32;
+            int S = 0, rows_pad = 0, n_pad = 0;
+            if (slab_chain) {
+                RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+                if (sandwich) {
+                    RUN(sandwich_add_rms_norm_f32_slabs(m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_attn_ln, m->residual_f32,
+                                                        L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                } else {
+                    RUN(fused_add_rms_norm_route_slabs_f16(m->residual, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
+                                                           c.rms_eps, m->norm_out, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, T, H, s));
+                }
+                S = 0;
+                RUN(w4_gemm_dense_slabs_lds(L.gate_up, m->norm_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+                RUN(fused_gated_act_slabs_f16(m->workspace, S, (long)rows_pad * n_pad, n_pad, m->act_out, T, I, c.activation == 1, s));
+                S = 0;
+                RUN(w4_gemm_dense_slabs_lds(L.down, m->act_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+                if (sandwich) {
+                    RUN(sandwich_add_rms_norm_f32_slabs(m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ffn_ln, m->residual_f32,
+                                                        next_ln, c.rms_eps, m->norm_out, T, H, s));
+                } else {
+                    // last layer: the norm output is unused (the final norm runs on the sampled rows)
+                    RUN(fused_add_rms_norm_route_slabs_f16(m->residual, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad,
+                                                           next_ln ? next_ln : L.input_ln, c.rms_eps, m->norm_out, nullptr, 0, 0, 0,
+                                                           nullptr, nullptr, nullptr, T, H, s));
+                }
+            } else {
             RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
             RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
             if (sandwich) {
@@ -862,6 +891,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                 RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s));
             } else {
                 RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
+            }
             }
         }
         if (m->taps_enabled && m->taps) {

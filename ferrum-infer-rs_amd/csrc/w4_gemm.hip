@@ -173,7 +173,7 @@ __device__ __forceinline__ half8 splat_half8(float v) {
 // zero point: −zero·(S_lo+S_hi)) is removed with NO per-weight work: four extra MFMAs per group against a
 // constant B operand produce −(1024+zero)·S_lo − (64+zero)·S_hi per token row, and that is used as the
 // starting accumulator of every tile's MFMA chain.  The group scale multiplies the fp32 chain result.
-template <int MT, int NT, bool HAS_ZP, typename WQ>
+template <int MT, int NT, bool HAS_ZP, bool ILV = true, typename WQ>
 __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned long long sbits,
                                                  unsigned long long zbits, int nt0, half8 (&af)[MT][4],
                                                  float4v (&acc)[MT][NT]) {
@@ -208,32 +208,75 @@ __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned lo
             s_sum[mt] = u;
         }
     }
+    // All NT×MT accumulator chains advance together (k-step by k-step) so that consecutive MFMAs are independent:
+    // with one tile at a time the chain tmp ← mfma(·,·,tmp) serialises on the MFMA latency whenever a SIMD holds a
+    // single wave (the dense LDS kernel) — same operations per chain, same order, same bits.
+    // (ILV = false: one tile at a time — fewer live registers, for the 1024-thread intra-workgroup split kernel.)
+    if constexpr (!ILV) {
 #pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        float4v tmp[MT];
+        for (int nt = 0; nt < NT; nt++) {
+            float4v t1[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) tmp[mt] = neg_off[mt];
+            for (int mt = 0; mt < MT; mt++) t1[mt] = neg_off[mt];
 #pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
+            for (int pr = 0; pr < 2; pr++) {
+                const uint32_t d0 = wq[nt][2 * pr], d1 = wq[nt][2 * pr + 1];
+                const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
+                const half8 lo = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic),
+                                            and_or(d1s, m_lo, magic));
+                const half8 hi = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic),
+                                            and_or(d1s, m_hi, magic));
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    t1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr], lo, t1[mt], 0, 0, 0);
+                    t1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr + 1], hi, t1[mt], 0, 0, 0);
+                }
+            }
+            const float s_f = (float)half_at(sbits, nt0 + nt);
+            const float z_f = HAS_ZP ? (float)half_at(zbits, nt0 + nt) : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = HAS_ZP ? t1[mt][r] - z_f * s_sum[mt][r] : t1[mt][r];
+                    acc[mt][nt][r] += s_f * v;
+                }
+        }
+        return;
+    }
+    float4v tmp[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) tmp[mt][nt] = neg_off[mt];
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        half8 lo[NT], hi[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) {
             const uint32_t d0 = wq[nt][2 * pr], d1 = wq[nt][2 * pr + 1];
             const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
-            const half8 lo = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic),
-                                        and_or(d1s, m_lo, magic));
-            const half8 hi = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic),
-                                        and_or(d1s, m_hi, magic));
-#pragma unroll
-            for (int mt = 0; mt < MT; mt++) {
-                tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr], lo, tmp[mt], 0, 0, 0);
-                tmp[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr + 1], hi, tmp[mt], 0, 0, 0);
-            }
+            lo[nt] = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic), and_or(d1s, m_lo, magic));
+            hi[nt] = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic), and_or(d1s, m_hi, magic));
         }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) tmp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr], lo[nt], tmp[mt][nt], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) tmp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr + 1], hi[nt], tmp[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
         const float s_f = (float)half_at(sbits, nt0 + nt);
         const float z_f = HAS_ZP ? (float)half_at(zbits, nt0 + nt) : 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = HAS_ZP ? tmp[mt][r] - z_f * s_sum[mt][r] : tmp[mt][r];
+                float v = HAS_ZP ? tmp[mt][nt][r] - z_f * s_sum[mt][r] : tmp[mt][nt][r];
                 acc[mt][nt][r] += s_f * v;
             }
     }
@@ -660,7 +703,7 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) 
     auto consume = [&](int buf) {
         const unsigned long long sb = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
         const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
-        w4_consume_group<MT, NT, HAS_ZP>(wq[buf], sb, zb, nt0, af[buf], acc);
+        w4_consume_group<MT, NT, HAS_ZP, false>(wq[buf], sb, zb, nt0, af[buf], acc);
     };
 #define FH_PIN() __builtin_amdgcn_sched_barrier(0)
     if (g0 < g1) {
@@ -1023,6 +1066,42 @@ int w4_gemm_dense_slabs(const W4Device& w, const __half* x, float* slabs, size_t
     *n_pad_out = a.n_pad;
     // S == 1 still writes a slab (the MODE-0 kernel writes fp16 `out` only when S == 1 → force the slab path)
     return launch_w4_slabs(a, mt, w.zp != nullptr, dim3(cdiv(w.n64, 4), row_blocks, S), stream);
+}
+
+// Split count the LDS-shared-activation kernel wants for this shape (tools/exp_dense.py sweeps): enough workgroups to
+// cover the chip (≥ 128–256 of 4 waves) while every split keeps ≥ 8 quant groups.
+int w4_gemm_dense_lds_splits(const W4Device& w, int m) {
+    const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
+    const int row_blocks = cdiv(m, 16 * mt), cols = cdiv(w.n64, 4);
+    int S = 1;
+    int min_wgs = 128, min_groups = 8;
+    if (const char* e = getenv("FERRUM_HIP_LDS_MIN_WGS")) min_wgs = atoi(e);
+    if (const char* e = getenv("FERRUM_HIP_LDS_MIN_GROUPS")) min_groups = atoi(e);
+    while ((long)cols * row_blocks * S < min_wgs && w.G / (S * 2) >= min_groups) S *= 2;
+    return S;
+}
+
+// Dense projection for 17–32 rows as S fp32 slabs through w4_gemm_ldsa_kernel (activations staged once per workgroup in
+// LDS); the consumer kernel sums the slabs in order.  S ≤ 0 → w4_gemm_dense_lds_splits.
+int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_inout,
+                            int* rows_pad_out, int* n_pad_out, hipStream_t stream) {
+    if (m <= 0) return 0;
+    FH_REQUIRE(w.perm == nullptr && w.bias == nullptr, "w4_gemm_dense_slabs_lds: act-order / bias weights use the direct path");
+    FH_REQUIRE(m > 16 && m <= 32, "w4_gemm_dense_slabs_lds: m=%d (17..32 rows)", m);
+    int S = *S_inout > 0 ? *S_inout : w4_gemm_dense_lds_splits(w, m);
+    S = std::max(1, std::min(S, w.G));
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.x = x; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n;
+    a.rows_pad = 32;
+    a.n_pad = w.n64 * 64;
+    FH_REQUIRE((size_t)S * a.rows_pad * a.n_pad * sizeof(float) <= slab_bytes, "w4_gemm_dense_slabs_lds: workspace too small");
+    a.S = S;
+    a.partial = slabs;
+    *S_inout = S;
+    *rows_pad_out = a.rows_pad;
+    *n_pad_out = a.n_pad;
+    return launch_ldsa<2, 4>(a, w.zp != nullptr, dim3(cdiv(w.n64, 4), 1, S), stream);
 }
 
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,

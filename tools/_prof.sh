@@ -1,13 +1,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_p -o pf --output-format csv -- python3 $R/tools/prefill_only.py > $R/gpurun_out/prefill.log 2> $R/gpurun_out/prefill.err
+export FERRUM_HIP_NO_GRAPH=1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS --kernel-trace -d $R/gpurun_out/pmc_l -o p --output-format csv -- python3 $R/bench.py --model llama31-8b --no-sweep --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2> $R/gpurun_out/pmc_l.err
 cd $R
-cat gpurun_out/prefill.log
-python3 - <<'PY'
-import csv
-rows=list(csv.DictReader(open('gpurun_out/prof_p/pf_kernel_stats.csv')))
-tot=sum(float(r['TotalDurationNs']) for r in rows)
-for r in rows[:16]:
-    print(f"{r['Name'][:90]:90s} calls={r['Calls']:>5s} avg={float(r['AverageNs'])/1e3:9.1f}us total={float(r['TotalDurationNs'])/1e6:8.2f}ms {100*float(r['TotalDurationNs'])/tot:5.1f}%")
-PY
+python tools/pmc_summary.py gpurun_out/pmc_l ldsa
+python tools/pmc_summary.py gpurun_out/pmc_l "w4_gemm_kernel<1"
