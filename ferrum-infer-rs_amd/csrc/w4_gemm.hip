@@ -441,8 +441,12 @@ __device__ __forceinline__ bool inline_align_block(const int* s_ids, int P, int 
 }
 
 // MODE: 0 dense, 1 MoE (plain output), 2 MoE gate_up with fused silu·mul epilogue
-template <int MT, bool HAS_ZP, int MODE>
-__global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
+// KW (MoE only): waves per workgroup that split K.  Small batches (≤ 64 pairs) launch too few one-wave workgroups to
+// cover the chip and each streams its 64 KiB at one group per memory round trip; with KW = 4 every wave takes a quarter
+// of K (all its groups in flight) and the partial sums meet in LDS — c=1 gate_up 11.8 → ≈6 µs.  Each wave runs the
+// (cheap) routing prologue on its own LDS slice, so no cross-wave protocol is needed before the reduce.
+template <int MT, bool HAS_ZP, int MODE, int KW = 1>
+__global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Args p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
     // dense: 4 waves per workgroup, one 64-column supertile each.  MoE: ONE wave per workgroup — the
@@ -469,23 +473,26 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
     } else {
         // MoE: one 16-row block of sorted pair ids, all of one expert.
         // LDS: raw[0..8K) holds the route candidates during the merge, then (first 2 KB) the histogram
-        __shared__ __attribute__((aligned(16))) unsigned char s_raw[8192];
-        __shared__ int s_ids[1024], s_rows[16];
+        __shared__ __attribute__((aligned(16))) unsigned char s_raw_all[KW][KW == 1 ? 8192 : 2048];
+        __shared__ int s_ids_all[KW][KW == 1 ? 1024 : 64], s_rows_all[KW][16];
+        unsigned char* s_raw = s_raw_all[KW == 1 ? 0 : wave];
+        int* s_ids = s_ids_all[KW == 1 ? 0 : wave];
+        int* s_rows = s_rows_all[KW == 1 ? 0 : wave];
         int* s_cnt = reinterpret_cast<int*>(s_raw);
         int e, id;
         if (p.cand || p.pair_expert_ids) {
-            const bool publisher = blockIdx.x == 0 && rb == 0;
-            if (p.cand) {
+            const bool publisher = blockIdx.x == 0 && rb == 0 && wave == 0;
+            if (KW == 1 && p.cand) {
                 merge_route_candidates(p.cand, p.stats, p.route_T, p.route_Q, p.route_K, p.norm_topk,
                                        reinterpret_cast<RouteCand*>(s_raw), s_ids, publisher, p.pub_expert_ids, p.pub_expert_w);
             } else {
-                for (int i = threadIdx.x; i < p.M; i += 64) s_ids[i] = p.pair_expert_ids[i];
+                for (int i = lane; i < p.M; i += 64) s_ids[i] = p.pair_expert_ids[i];
                 __syncthreads();
             }
             int total_blocks;
             if (!inline_align_block(s_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
             id = s_rows[b];
-            if (p.pub_sorted_token_ids && blockIdx.x == 0) {
+            if (p.pub_sorted_token_ids && blockIdx.x == 0 && wave == 0) {
                 if (threadIdx.x < 16) p.pub_sorted_token_ids[rb * 16 + threadIdx.x] = s_rows[threadIdx.x];
                 if (threadIdx.x == 0) {
                     p.pub_block_ids[rb] = e;
@@ -506,7 +513,12 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
         row_in[0] = row_ok[0] ? id / p.top_k : 0;
     }
 
-    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+    int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+    if (MODE != 0 && KW > 1) {   // this wave's quarter of K
+        const int span = g1 - g0, base = g0;
+        g0 = base + span * wave / KW;
+        g1 = base + span * (wave + 1) / KW;
+    }
     // per-lane bases
     typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
     const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(qw) + ((long)st * p.G * 4) * 64 + lane;
@@ -571,6 +583,25 @@ __global__ __launch_bounds__(256) void w4_gemm_kernel(W4Args p) {
         }
     }
 #undef FH_PIN
+    if (MODE != 0 && KW > 1) {
+        // partial sums of the KW K-quarters meet in LDS; wave 0 adds them in wave order and owns the epilogue
+        __shared__ float kred[KW][16][64];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) kred[wave][nt * 4 + r][lane] = acc[0][nt][r];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float s = kred[0][nt * 4 + r][lane];
+#pragma unroll
+                for (int k = 1; k < KW; k++) s += kred[k][nt * 4 + r][lane];
+                acc[0][nt][r] = s;
+            }
+    }
 
     // accumulator map (v_mfma_f32_16x16x32): column = lane&15 → n, row = 4·(lane>>4)+r → token.
     // Lanes exchange nothing: every lane owns token rows 4a..4a+3 of column b.  The A operand
@@ -919,7 +950,12 @@ static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_
 #define FH_W4_CASE(MTV, ZPV)                                                       \
     hipLaunchKernelGGL((w4_gemm_kernel<MTV, ZPV, MODE>), grid, dim3(MODE == 0 ? 256 : 64), 0, stream, a)
     if constexpr (MODE != 0) {
-        if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false);
+        // few pairs (decode at c ≤ 8): 4 waves per workgroup split K (see KW); the candidate-merge prologue keeps KW = 1
+        static const int kw_pairs = getenv("FERRUM_HIP_MOE_KW_PAIRS") ? atoi(getenv("FERRUM_HIP_MOE_KW_PAIRS")) : 8;   // measured: c=1 +10 %, c ≥ 4 slightly slower
+        if (a.M <= kw_pairs && a.cand == nullptr && a.G >= 4) {
+            if (has_zp) hipLaunchKernelGGL((w4_gemm_kernel<1, true, MODE, 4>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((w4_gemm_kernel<1, false, MODE, 4>), grid, dim3(256), 0, stream, a);
+        } else if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false);
     } else {
         if (mt == 1) { if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false); }
         else if (mt == 2) { if (has_zp) FH_W4_CASE(2, true); else FH_W4_CASE(2, false); }
