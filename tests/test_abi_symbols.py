@@ -143,3 +143,19 @@ def test_block_hash_chain_matches_restatement_and_published_siphash(pkg, oracle)
                                                out.ctypes.data_as(C.POINTER(C.c_uint64)), len(out), C.byref(cnt)) == 0
         ref = oracle.block_hash_chain(toks, 16)
         assert cnt.value == n // 16 == len(ref) and np.array_equal(out[:cnt.value], ref)
+
+
+def test_native_operator_manifest_matches_the_binary(pkg, tmp_path):
+    """tools/make_manifest.py emits the reference's manifest schema (native_operator.rs:39-58); the resolver's fail-closed
+    checks (resolver.rs:136-318) are reproduced here: sha256 of the file, every declared export visible to nm."""
+    import hashlib
+    import json
+    subprocess.check_call(["python", os.path.join(ROOT, "tools", "make_manifest.py")])
+    m = json.load(open(os.path.join(os.path.dirname(pkg.LIB_PATH), "native_operator_manifest.json")))
+    assert m["schema_version"] == 1 and m["ferrum_native_abi_version"] == "1" and m["linkage"] == "dynamic"
+    assert m["binary_sha256"] == hashlib.sha256(open(pkg.LIB_PATH, "rb").read()).hexdigest()
+    assert len(m["inputs_sha256"]) == 64 and m["compute_capabilities"] == ["gfx950"]
+    out = subprocess.check_output(["nm", "-g", "--defined-only", pkg.LIB_PATH], text=True)
+    visible = set(line.split()[-1] for line in out.splitlines())
+    assert "ferrum_native_op_init" in m["exports"] and "ferrum_native_op_descriptor" in m["exports"]
+    assert all(e in visible for e in m["exports"])
