@@ -925,6 +925,229 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
         }
 }
 
+// ── prefill GEMM: 64-row tiles, activations through LDS, 4 waves × 64 columns ───────────────────────────────────
+// For M ≥ 64 (prefill chunks; MoE blocks of 64 sorted pairs) the skinny kernels re-fetch their A fragments from L2 for
+// every 64-column supertile and spend half their time on it.  Here a workgroup owns 64 rows × 256 columns: every 128-k
+// group's 64×128 activation tile is gathered once (dense rows, or MoE pair rows through sorted_token_ids) into a
+// double-buffered fragment-major LDS tile, each wave streams the INT4 group of ITS 64-column supertile straight to
+// registers, expands it once and runs it against all four 16-row tiles (80 MFMAs per 4 KiB of weights instead of 20).
+// MODE 0 dense (+bias), 1 MoE plain, 2 MoE gate_up with the fused silu·mul epilogue.  Same arithmetic as
+// w4_consume_group (exact integer-valued products, fp32 scale), restructured k-pair-major to hold 250 VGPRs.
+template <bool HAS_ZP, int MODE>
+__global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][4 mt][4 s][64] half8 = 2 × 16 KiB
+    constexpr int FR = 1024;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int st_raw = blockIdx.x * 4 + wave;
+    const bool st_ok = st_raw < p.n64;
+    const int st = st_ok ? st_raw : p.n64 - 1;
+    const int rb = blockIdx.y;
+
+    const uint32_t* qw = p.qw;
+    const __half* sc = p.sc;
+    const __half* zp = p.zp;
+    // rows of this tile: fragment loads are split by wave (k-step s = wave), so every thread needs the 4 rows
+    // mt·16 + b of its lane; the epilogue needs rows mt·16 + 4a + r
+    int row_in[4], row_out_l[4];
+    if (MODE == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const int r = rb * 64 + mt * 16 + b;
+            row_out_l[mt] = r < p.M ? r : -1;
+            row_in[mt] = r < p.M ? r : p.M - 1;
+        }
+    } else {
+        const int total = *p.total_post_pad;
+        if (rb * 64 >= total) return;
+        const int e = p.block_ids[rb];
+        qw += (long)e * p.expert_stride_qw;
+        sc += (long)e * p.expert_stride_sc;
+        if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            const int id = p.sorted_token_ids[rb * 64 + mt * 16 + b];
+            row_out_l[mt] = id < p.M ? id : -1;
+            row_in[mt] = id < p.M ? id / p.top_k : 0;
+        }
+    }
+    const __half* asrc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++) asrc[mt] = p.x + (long)row_in[mt] * p.K + 32 * wave + 8 * a;
+
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(qw) + ((long)st * p.G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(zp) + ((long)st * p.G) * 16 + b : nullptr;
+
+    float4v acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    u32x4g wq[2][4];
+    uint2 scv[2], zpv[2];
+    half8 areg[4];
+    auto issue_w = [&](int slot, int g) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[slot] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[slot] = zp_lane[(long)g * 16];
+    };
+    auto issue_a = [&](int g) {
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) areg[mt] = *reinterpret_cast<const half8*>(asrc[mt] + (long)g * 128);
+    };
+    auto store_a = [&](int buf) {   // fragment (mt, s = wave, lane)
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) lds_a[buf * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];
+    };
+    const uint32_t magic = opaque_vgpr(0x64006400u);
+    const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
+    const half8 sixteenth = splat_half8(0.0625f);
+    const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -1024.0f : -1152.0f);
+    const half8 o_lo = splat_half8(1.0f), o_hi = splat_half8(16.0f);
+    auto half_at = [](unsigned long long bits, int i) {
+        union { uint16_t u; _Float16 h; } c;
+        c.u = (uint16_t)(bits >> (16 * i));
+        return c.h;
+    };
+    auto consume = [&](int slot, int abuf) {
+        const half8* at = lds_a + abuf * FR;
+        // expand the group once (16 B-operand fragments), then one 16-row tile at a time: 4 offset MFMAs seed the
+        // tile's 4 chains, 16 MFMAs extend them, the fp32 scale folds them into acc
+        half8 lo[2][4], hi[2][4];
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const uint32_t d0 = wq[slot][nt][2 * pr], d1 = wq[slot][nt][2 * pr + 1];
+                const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
+                lo[pr][nt] = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic), and_or(d1s, m_lo, magic));
+                hi[pr][nt] = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic), and_or(d1s, m_hi, magic));
+            }
+        const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++) {
+            half8 af[4];
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                af[s] = at[(mt * 4 + s) * 64 + lane];
+                if (s & 1) af[s] = af[s] * sixteenth;
+            }
+            float4v t = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], (s & 1) ? b_hi : b_lo, t, 0, 0, 0);
+                if (HAS_ZP) u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], (s & 1) ? o_hi : o_lo, u, 0, 0, 0);
+            }
+            float4v tmp[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) tmp[nt] = t;
+#pragma unroll
+            for (int pr = 0; pr < 2; pr++) {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) tmp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * pr], lo[pr][nt], tmp[nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) tmp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[2 * pr + 1], hi[pr][nt], tmp[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const float s_f = (float)half_at(sb, nt);
+                const float z_f = HAS_ZP ? (float)half_at(zb, nt) : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float v = HAS_ZP ? tmp[nt][r] - z_f * u[r] : tmp[nt][r];
+                    acc[mt][nt][r] += s_f * v;
+                }
+            }
+        }
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    const int gz0 = MODE == 0 ? (int)((long)p.G * blockIdx.z / p.S) : 0;
+    const int gz1 = MODE == 0 ? (int)((long)p.G * (blockIdx.z + 1) / p.S) : p.G;
+    {
+        const int gl = gz1 - 1;
+        issue_w(0, gz0);
+        issue_a(gz0);
+        FH_PIN();
+        store_a(0);
+        issue_a(min(gz0 + 1, gl));
+        __syncthreads();
+        int g = gz0;
+        for (; g + 2 <= gz1; g += 2) {              // two groups per trip: static buffer indices, no conditional loads
+            issue_w(1, min(g + 1, gl));
+            store_a(1);                              // A(g+1), requested one group ago
+            issue_a(min(g + 2, gl));
+            FH_PIN();
+            consume(0, 0);
+            FH_PIN();
+            __syncthreads();
+            issue_w(0, min(g + 2, gl));
+            store_a(0);                              // A(g+2)
+            issue_a(min(g + 3, gl));
+            FH_PIN();
+            consume(1, 1);
+            FH_PIN();
+            __syncthreads();
+        }
+        if (g < gz1) consume(0, 0);                  // odd group count: the last group is already staged
+    }
+#undef FH_PIN
+    if (!st_ok) return;
+    if (MODE == 0 && p.partial) {                    // split-K: fp32 slab, summed by the reduce launch
+        float* slab = p.partial + (long)blockIdx.z * p.rows_pad * p.n_pad;
+#pragma unroll
+        for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * 64 + mt * 16 + 4 * a + r;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) slab[(long)row * p.n_pad + st * 64 + nt * 16 + b] = acc[mt][nt][r];
+            }
+        return;
+    }
+    // epilogue: D row 4a + r of tile mt ↔ tile row mt·16 + 4a + r, whose routing lives in lane (·, b = 4a + r)
+#pragma unroll
+    for (int mt = 0; mt < 4; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int orow = __shfl(row_out_l[mt], 4 * a + r, 64);
+            if (orow < 0) continue;
+            if (MODE == 2) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const float gt = acc[mt][j][r], up = acc[mt][2 + j][r];
+                    const float v = (gt / (1.0f + __expf(-gt))) * up;
+                    const int col = st * 32 + j * 16 + b;
+                    if (col < p.ldo) p.out[(long)orow * p.ldo + col] = __float2half(v);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const int col = st * 64 + nt * 16 + b;
+                    if (col < p.N) {
+                        float v = acc[mt][nt][r];
+                        if (MODE == 0 && p.bias) v += __half2float(p.bias[col]);
+                        p.out[(long)orow * p.ldo + col] = __float2half(v);
+                    }
+                }
+            }
+        }
+}
+
+template <int MODE>
+static int launch_tile(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)2 * 1024 * 16;
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_tile_kernel<true, MODE>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_tile_kernel<false, MODE>), grid, dim3(256), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 template <int MT, int NW>
 static int launch_ldsa(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)2 * MT * 256 * 16;
@@ -982,6 +1205,26 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // LDS-shared activations (w4_gemm_ldsa_kernel) + fp32 split-K slabs + one reduce launch.  Measured at m = 32 against
     // the one-launch intra-workgroup split below (tools/exp_dense.py): down 14336→4096 31.3 → 18.4 µs (S = 8),
     // gate_up 4096→28672 25.7 → 23.2 µs (S = 2); the small projections (qkv, o) tie, so they keep the single launch.
+    static const int tile_min_m = getenv("FERRUM_HIP_W4_TILE_MIN_M") ? atoi(getenv("FERRUM_HIP_W4_TILE_MIN_M")) : 64;
+    if (m >= tile_min_m && w.perm == nullptr) {   // prefill: 64-row LDS tiles (w4_gemm_tile_kernel)
+        // too few tiles to cover the chip (narrow N or few rows): split K over grid.z into fp32 slabs + one reduce launch,
+        // keeping ≥ 8 quant groups per split
+        static const int tile_wgs = getenv("FERRUM_HIP_W4_TILE_WGS") ? atoi(getenv("FERRUM_HIP_W4_TILE_WGS")) : 256;
+        const int cols = cdiv(w.n64, 4), rts = cdiv(m, 64);
+        int S = 1;
+        while ((long)cols * rts * S < tile_wgs && w.G / (S * 2) >= 8) S *= 2;
+        const int rows_pad = rts * 64, n_pad = w.n64 * 64;
+        if (S > 1 && (workspace == nullptr || (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes)) S = 1;
+        a.S = S;
+        a.rows_pad = rows_pad; a.n_pad = n_pad;
+        a.partial = S > 1 ? workspace : nullptr;
+        if (int rc = launch_tile<0>(a, w.zp != nullptr, dim3(cols, rts, S), stream)) return rc;
+        if (S == 1) return 0;
+        hipLaunchKernelGGL(splitk_reduce_bias_kernel, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, w.bias, S, m,
+                           w.n, rows_pad, n_pad, w.n);
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
     static const int lds_mode = getenv("FERRUM_HIP_W4_LDSA") ? atoi(getenv("FERRUM_HIP_W4_LDSA")) : 1;
     const bool lds_shape = (w.G >= 64 && w.n64 >= 32) || w.n64 >= 256;
     if (mt >= 2 && w.perm == nullptr && (lds_mode == 2 || (lds_mode == 1 && lds_shape && mt == 2))) {
