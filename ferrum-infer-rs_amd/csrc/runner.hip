@@ -244,6 +244,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_FUSE_ROPE")) m->fuse_rope_attn = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_O_SLABS")) m->o_slabs = std::max(0, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_DENSE_SLABS")) m->dense_slabs = atoi(e) != 0;
+    if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
     return 0;
 }
@@ -472,7 +473,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     rc |= dev_alloc(&m->logits, S * (size_t)c.vocab);
     rc |= dev_alloc(&m->out_tokens, S);
     if (c.num_experts > 0) {
-        const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 16;
+        const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 64;   // room for 64-row blocks (prefill)
         rc |= dev_alloc(&m->router_logits, T * c.num_experts);
         rc |= dev_alloc(&m->expert_ids, P);
         rc |= dev_alloc(&m->expert_w, P);
@@ -828,13 +829,23 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                 if (P <= 1024) {
                     RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
                                                  m->sorted_ids, m->block_ids, m->total_post_pad, s));
+                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                    max_blocks, 1, 0, s));
+                } else if (P >= m->moe_tile_min_pairs_per_expert * E) {
+                    // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
+                    const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
+                    RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
+                    RUN(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                         max_blocks64, K, 1, s));
+                    RUN(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                         max_blocks64, 1, 0, s));
                 } else {
                     RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
                     RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                                     max_blocks, K, 1, s));
+                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                    max_blocks, 1, 0, s));
                 }
-                RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                max_blocks, 1, 0, s));
                 RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
                                                  m->norm_out, T, K, H, s));
             }

@@ -1401,6 +1401,26 @@ int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* 
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
 }
 
+// MoE grouped GEMM over 64-row blocks (moe_align_block_size with block 64): prefill-sized batches, where an expert sees
+// tens to hundreds of pairs and the 16-row kernel would re-stream its weights once per 16 pairs.
+int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids, const int32_t* block_ids,
+                     const int32_t* total_post_pad, int num_valid_pairs, int max_blocks64, int top_k, int fused_silu,
+                     hipStream_t stream) {
+    if (num_valid_pairs <= 0 || max_blocks64 <= 0) return 0;
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
+    a.expert_stride_sc = (long)w.n64 * w.G * 16 * 4;
+    a.x = x; a.out = out; a.M = num_valid_pairs; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64;
+    a.ldo = fused_silu ? w.n / 2 : w.n;
+    a.S = 1;
+    a.sorted_token_ids = sorted_token_ids; a.block_ids = block_ids; a.total_post_pad = total_post_pad;
+    a.top_k = top_k;
+    dim3 grid(cdiv(w.n64, 4), max_blocks64, 1);
+    if (fused_silu) return launch_tile<2>(a, w.zp != nullptr, grid, stream);
+    return launch_tile<1>(a, w.zp != nullptr, grid, stream);
+}
+
 // ───────────────────────── fp16 skinny GEMM (router, lm_head) ───────────────
 // out[M,N] = x[M,K]·Wᵀ with W [N,K] fp16 row-major (B::gemm, traits.rs:190; cuBLAS hgemm on the
 // reference's CUDA lane).  Same operand roles as the INT4 kernel: W rows are B-operand columns.

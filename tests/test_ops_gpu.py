@@ -520,6 +520,22 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
         B.moe_combine(ctx, down, wd, out, tokens, K, H)
         ctx.sync()
         assert nmse(ref, host(out)) < 3e-6, fused            # three fp16 roundings (act, down, out)
+        if fused and P >= 64:
+            # 64-row blocks through the prefill tile kernel: same maths, different block shape
+            sd64 = torch.empty(P + E * 64, dtype=torch.int32, device="cuda")
+            bd64 = torch.empty((P + E * 64) // 64 + 1, dtype=torch.int32, device="cuda")
+            td64 = torch.zeros(1, dtype=torch.int32, device="cuda")
+            B.moe_align_block_size_pair_ids(ctx, ids_d, sd64, bd64, td64, P, E, 64, P + E * 64)
+            mb64 = (P + E * 64) // 64
+            act64 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
+            down64 = torch.zeros(P, H, dtype=torch.float16, device="cuda")
+            stack.gemm_phase_vllm(ctx, xd, sd64, bd64, td64, act64, P, 64, K, mb64, fused_silu_mul=True)
+            down_stack.gemm_phase_vllm(ctx, act64, sd64, bd64, td64, down64, P, 64, 1, mb64)
+            out64 = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+            B.moe_combine(ctx, down64, wd, out64, tokens, K, H)
+            ctx.sync()
+            assert torch.equal(act64, act)                       # per-row sums are independent of the block shape
+            assert nmse(ref, host(out64)) < 3e-6
         if fused:
             # align computed inside the GEMM from the raw expert ids: bit-identical outputs
             act2 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
