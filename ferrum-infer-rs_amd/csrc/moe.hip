@@ -99,18 +99,20 @@ int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* 
 // One workgroup per expert: histogram of every pair (LDS atomics, order-free) → padded prefix →
 // ordered compaction of this expert's pair ids (ballot prefix keeps ascending pair id).
 constexpr int MAX_EXPERTS = 512;
-__global__ __launch_bounds__(256) void moe_align_kernel(const int32_t* __restrict__ expert_ids,
-                                                        int32_t* __restrict__ sorted_token_ids,
-                                                        int32_t* __restrict__ block_ids,
-                                                        int32_t* __restrict__ total_post_pad, int n_pairs,
-                                                        int num_experts, int block_size, int sorted_max) {
+constexpr int ALIGN_THREADS = 1024;
+__global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t* __restrict__ expert_ids,
+                                                                  int32_t* __restrict__ sorted_token_ids,
+                                                                  int32_t* __restrict__ block_ids,
+                                                                  int32_t* __restrict__ total_post_pad, int n_pairs,
+                                                                  int num_experts, int block_size, int sorted_max) {
     __shared__ int counts[MAX_EXPERTS];
-    __shared__ int wave_cnt[4];
+    __shared__ int wave_cnt[ALIGN_THREADS / 64];
     __shared__ int s_offset, s_total;
+    constexpr int NT = ALIGN_THREADS, NWV = ALIGN_THREADS / 64;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < num_experts; i += 256) counts[i] = 0;
+    for (int i = tid; i < num_experts; i += NT) counts[i] = 0;
     __syncthreads();
-    for (int p = tid; p < n_pairs; p += 256) {
+    for (int p = tid; p < n_pairs; p += NT) {
         int x = expert_ids[p];
         if (x >= 0 && x < num_experts) atomicAdd(&counts[x], 1);
     }
@@ -130,22 +132,40 @@ __global__ __launch_bounds__(256) void moe_align_kernel(const int32_t* __restric
     const int cnt = counts[e];
     const int padded = ((cnt + block_size - 1) / block_size) * block_size;
     // sentinel for the padding tail of this expert and (striped) the unused end of the array
-    for (int i = cnt + tid; i < padded; i += 256) sorted_token_ids[offset + i] = n_pairs;
-    for (int i = total + e * 256 + tid; i < sorted_max; i += 256 * gridDim.x) sorted_token_ids[i] = n_pairs;
-    for (int b = tid; b < padded / block_size; b += 256) block_ids[offset / block_size + b] = e;
-    // ordered compaction
+    for (int i = cnt + tid; i < padded; i += NT) sorted_token_ids[offset + i] = n_pairs;
+    for (int i = total + e * NT + tid; i < sorted_max; i += NT * gridDim.x) sorted_token_ids[i] = n_pairs;
+    for (int b = tid; b < padded / block_size; b += NT) block_ids[offset / block_size + b] = e;
+    // ordered compaction, 4 consecutive pairs per thread and 4096 per trip (ascending pair id is kept: thread order,
+    // then element order); a prefill batch has tens of thousands of pairs, so barrier trips matter
     int base = 0;
-    for (int p0 = 0; p0 < n_pairs; p0 += 256) {
-        int p = p0 + tid;
-        bool mine = p < n_pairs && expert_ids[p] == e;
-        unsigned long long bal = __ballot(mine);
-        int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    for (int p0 = 0; p0 < n_pairs; p0 += NT * 4) {
+        const int p = p0 + tid * 4;
+        bool mine[4];
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            mine[j] = p + j < n_pairs && expert_ids[p + j] == e;
+            c += mine[j] ? 1 : 0;
+        }
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wave_cnt[wave] = incl;
         __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wave; w++) before += wave_cnt[w];
-        int chunk_total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        if (mine) sorted_token_ids[offset + base + before + in_wave] = p;
+        int before = 0, chunk_total = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; w++) {
+            const int wc = wave_cnt[w];
+            if (w < wave) before += wc;
+            chunk_total += wc;
+        }
+        int pos = offset + base + before + incl - c;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (mine[j]) sorted_token_ids[pos++] = p + j;
         base += chunk_total;
         __syncthreads();
     }
@@ -157,7 +177,7 @@ int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, i
     FH_REQUIRE(num_experts > 0 && num_experts <= MAX_EXPERTS, "moe align: num_experts=%d must be in [1,%d]", num_experts, MAX_EXPERTS);
     FH_REQUIRE(block_size > 0, "moe align: block_size=%d", block_size);
     FH_REQUIRE(sorted_max >= batch_x_topk, "moe align: sorted_max=%d < pairs=%d", sorted_max, batch_x_topk);
-    hipLaunchKernelGGL(moe_align_kernel, dim3(num_experts), dim3(256), 0, s, expert_ids, sorted_token_ids, block_ids,
+    hipLaunchKernelGGL(moe_align_kernel, dim3(num_experts), dim3(ALIGN_THREADS), 0, s, expert_ids, sorted_token_ids, block_ids,
                        total_post_pad, batch_x_topk, num_experts, block_size, sorted_max);
     FH_CHECK_LAUNCH();
     return 0;

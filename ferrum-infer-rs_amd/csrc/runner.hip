@@ -244,6 +244,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_FUSE_ROPE")) m->fuse_rope_attn = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_O_SLABS")) m->o_slabs = std::max(0, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_DENSE_SLABS")) m->dense_slabs = atoi(e) != 0;
+    if (const char* e = getenv("FERRUM_HIP_ROUTE_GEMM_TOKENS")) m->route_gemm_min_tokens = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
     return 0;
@@ -823,9 +824,17 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             } else {
                 RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
                 RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
-                // residual += o; post-attention norm; router logits; top-k — one launch (fused.hip B)
-                RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
-                                                 c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
+                if (T >= m->route_gemm_min_tokens) {
+                    // prefill: one workgroup per token would pull the whole router (E·H·2 B) from L2 per token (2048 tokens:
+                    // 1 GB, 95 µs) — run the router as a GEMM over all tokens instead, then the top-k kernel
+                    RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                    RUN(f16t_gemm_f32out(m->norm_out, L.router, m->router_logits, T, E, H, m->workspace, m->workspace_bytes, s));
+                    RUN(moe_route_topk_softmax_f32(m->router_logits, m->expert_ids, m->expert_w, T, E, K, c.norm_topk_prob, s));
+                } else {
+                    // residual += o; post-attention norm; router logits; top-k — one launch (fused.hip B)
+                    RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
+                                                     c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
+                }
                 if (P <= 1024) {
                     RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
                                                  m->sorted_ids, m->block_ids, m->total_post_pad, s));
