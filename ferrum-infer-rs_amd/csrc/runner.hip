@@ -1019,13 +1019,14 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
     if (n <= 0 || steps <= 0) return 0;
     const FerrumHipModelConfig& c = m->cfg;
     FH_REQUIRE(n <= c.max_seqs && n <= 1024, "decode_steps: %d sequences > max_seqs %d (or 1024)", n, c.max_seqs);
-    FH_REQUIRE(c.sliding_window == 0, "decode_steps: sliding-window models use unified_forward");
     // admission for the whole run up front: block tables are then constant across the steps
     std::vector<FerrumHipKvSlotRequest> reqs(n);
     StepShape sh{};
     sh.m_total = sh.num_seqs = sh.num_sampled = n;
     sh.max_q_len = 1;
-    sh.pure_decode = true;
+    // uniform sliding window: every layer takes the windowed varlen path (cu / pos live on the device like kv_lens);
+    // a local/global pattern decides per layer inside enqueue_forward
+    sh.pure_decode = !(c.sliding_window > 0 && c.sliding_window_pattern == 0);
     for (int i = 0; i < n; i++) {
         auto f = m->seqs.find(seq_ids[i]);
         FH_REQUIRE(f != m->seqs.end() && f->second.len > 0, "decode_steps: sequence %llu has no prefilled context", (unsigned long long)seq_ids[i]);

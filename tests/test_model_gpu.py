@@ -258,6 +258,43 @@ def test_block_level_prefix_cache_reuses_kv_and_matches_full_prefill(pkg):
     assert modelgen.cosine(l48[0], l3) > 0.99999
 
 
+@pytest.mark.parametrize("kind", ["gemma3", "mistral_window"])
+def test_decode_steps_graph_on_windowed_models(pkg, kind):
+    """The hipGraph decode loop on sliding-window models: local layers run the windowed varlen kernels from the device-side
+    position arrays.  Ids must equal step-by-step unified_forward and follow the oracle where its margin is clear."""
+    from tests import modelgen
+    kw = (dict(activation=1, sandwich=True, sliding_window=8, sliding_window_pattern=2, rope_local_theta=10000.0,
+               rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=16.0) if kind == "gemma3"
+          else dict(qk_norm=False, sliding_window=12, rope_theta=10000.0))
+    tm = modelgen.TinyModel(False, layers=4, seed=81, **kw)
+    rng = np.random.default_rng(82)
+    prompts = [rng.integers(0, tm.cfg["vocab"], size=n).astype(np.uint32) for n in (21, 9)]
+    steps = 14
+    outs = []
+    for mode in ("graph", "unified"):
+        hm = tm.hip_model(pkg, kv_num_blocks=32, max_seqs=4, max_tokens=64)
+        first, _ = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+        if mode == "graph":
+            outs.append(hm.decode_steps([0, 1], first, steps))
+        else:
+            cur, hist = first.copy(), []
+            for s in range(steps):
+                cur, _ = hm.unified_forward([(i, [int(cur[i])], len(prompts[i]) + s, True) for i in range(2)], greedy=True)
+                hist.append(cur.copy())
+            outs.append(np.stack(hist))
+    assert np.array_equal(outs[0], outs[1])
+    om = tm.oracle_model()
+    for i, p in enumerate(prompts):
+        lg = om.forward(i, p, 0)
+        seq = [int(first[i])] + [int(t) for t in outs[0][:, i]]
+        pos = len(p)
+        for s in range(steps):
+            lg = om.forward(i, np.array([seq[s]], np.uint32), pos)
+            pos += 1
+            if modelgen.margin(lg) > 0.05 * np.max(np.abs(lg)):
+                assert int(np.argmax(lg)) == seq[s + 1], (kind, i, s)
+
+
 def test_kv_admission_contract(pkg):
     """reserve_kv_slots is atomic and release returns blocks LIFO (model_executor.rs:484, paged_pool.rs:333-345)."""
     from tests import modelgen
