@@ -303,12 +303,12 @@ class HipBackend:
     @staticmethod
     def paged_decode_attention_fused_qkv(ctx, qkv, q_norm_w, k_norm_w, cos, sin, eps, qk_mode, k_pool, v_pool, out,
                                          block_tables, valid_kv_lens, num_seqs, max_kv_len, num_heads, num_kv_heads,
-                                         head_dim, block_size, max_num_blocks_per_seq):
+                                         head_dim, block_size, max_num_blocks_per_seq, sliding_window=0):
         """split_qkv_norm_rope_into_paged_cache_varlen (one token per sequence) + paged_batched_decode_attention."""
         _check(ctx.lib.ferrum_hip_paged_decode_attention_fused_qkv_f16(
             _ptr(qkv), _ptr(q_norm_w), _ptr(k_norm_w), _ptr(cos), _ptr(sin), C.c_float(eps), qk_mode, _ptr(k_pool),
             _ptr(v_pool), _ptr(out), _ptr(block_tables), _ptr(valid_kv_lens), num_seqs, max_kv_len, num_heads,
-            num_kv_heads, head_dim, block_size, max_num_blocks_per_seq, ctx.ws, ctx.stream),
+            num_kv_heads, head_dim, sliding_window, block_size, max_num_blocks_per_seq, ctx.ws, ctx.stream),
             "paged_decode_attention_fused_qkv")
 
     @staticmethod

@@ -403,15 +403,16 @@ int ferrum_hip_paged_decode_attention_fused_qkv_f16(const void* qkv, const void*
                                                     const float* cos_tab, const float* sin_tab, float eps, int qk_mode,
                                                     void* k_pool, void* v_pool, void* out, const int32_t* block_tables,
                                                     const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len,
-                                                    int num_heads, int num_kv_heads, int head_dim, int block_size,
-                                                    int max_num_blocks_per_seq, FerrumHipWorkspace* ws, void* stream) {
+                                                    int num_heads, int num_kv_heads, int head_dim, int sliding_window,
+                                                    int block_size, int max_num_blocks_per_seq, FerrumHipWorkspace* ws,
+                                                    void* stream) {
     FH_REQUIRE(num_seqs == 0 || (qkv && k_pool && v_pool && out && block_tables && valid_kv_lens),
                "paged_decode_attention_fused_qkv: null buffer");
     FH_REQUIRE(qk_mode == 0 || (cos_tab && sin_tab), "paged_decode_attention_fused_qkv: rope tables missing");
     FH_REQUIRE(qk_mode != 1 || (q_norm_w && k_norm_w), "paged_decode_attention_fused_qkv: norm weights missing for qk_mode 1");
     return paged_decode_attention_fused_qkv_f16(CH(qkv), CH(q_norm_w), CH(k_norm_w), cos_tab, sin_tab, eps, qk_mode,
                                                 H(k_pool), H(v_pool), H(out), block_tables, valid_kv_lens, num_seqs,
-                                                max_kv_len, num_heads, num_kv_heads, head_dim, block_size,
+                                                max_kv_len, num_heads, num_kv_heads, head_dim, sliding_window, block_size,
                                                 max_num_blocks_per_seq, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0,
                                                 ST(stream));
 }

@@ -443,14 +443,14 @@ int paged_decode_attention_fused_qkv_f16(const __half* qkv, const __half* q_norm
                                          const float* cos_t, const float* sin_t, float eps, int qk_mode, __half* k_pool,
                                          __half* v_pool, __half* out, const int32_t* block_tables,
                                          const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len, int num_heads,
-                                         int num_kv_heads, int head_dim, int block_size, int max_blocks_per_seq,
-                                         float* workspace, size_t workspace_bytes, hipStream_t s) {
+                                         int num_kv_heads, int head_dim, int sliding_window, int block_size,
+                                         int max_blocks_per_seq, float* workspace, size_t workspace_bytes, hipStream_t s) {
     FH_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0 && num_heads / num_kv_heads <= 14,
                "fused decode attention: GQA group %d/%d must be <= 14", num_heads, num_kv_heads);
     FH_REQUIRE(qk_mode >= 0 && qk_mode <= 3, "fused decode attention: qk_mode=%d out of range", qk_mode);
     FusedQkv fq{qkv, q_norm_w, k_norm_w, cos_t, sin_t, k_pool, v_pool, eps, qk_mode};
     return paged_attention_launch(nullptr, k_pool, v_pool, out, nullptr, nullptr, valid_kv_lens, block_tables, num_seqs,
-                                  num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, 0, block_size,
+                                  num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, sliding_window, block_size,
                                   max_blocks_per_seq, workspace, workspace_bytes, s, &fq);
 }
 

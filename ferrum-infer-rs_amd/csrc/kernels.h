@@ -110,8 +110,8 @@ int paged_decode_attention_fused_qkv_f16(const __half* qkv, const __half* q_norm
                                          const float* cos_t, const float* sin_t, float eps, int qk_mode, __half* k_pool,
                                          __half* v_pool, __half* out, const int32_t* block_tables,
                                          const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len, int num_heads,
-                                         int num_kv_heads, int head_dim, int block_size, int max_blocks_per_seq,
-                                         float* workspace, size_t workspace_bytes, hipStream_t s);
+                                         int num_kv_heads, int head_dim, int sliding_window, int block_size,
+                                         int max_blocks_per_seq, float* workspace, size_t workspace_bytes, hipStream_t s);
 int paged_batched_decode_attention_f16(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
                                        const int32_t* block_tables, const uint32_t* valid_kv_lens, int num_seqs,
                                        int max_kv_len, int num_heads, int num_kv_heads, int head_dim, int block_size,

@@ -713,7 +713,8 @@ namespace {
 
 struct StepShape {
     int m_total, num_seqs, max_q_len, max_kv_len, num_sampled;
-    bool pure_decode;
+    bool pure_decode;        // every item is one token AND the model has no uniform sliding window (full-attention decode)
+    bool all_single_token;   // every item is one token (windowed layers included): the fused decode attention applies
 };
 
 template <typename T>
@@ -756,11 +757,11 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         const float* cos_l = (!is_global && m->cos_local) ? m->cos_local : m->cos_t;
         const float* sin_l = (!is_global && m->sin_local) ? m->sin_local : m->sin_t;
         const bool layer_decode = sh.pure_decode && layer_window == 0;
-        if (layer_decode && m->fuse_rope_attn && nq / nkv <= 14) {
+        if (sh.all_single_token && m->fuse_rope_attn && nq / nkv <= 14) {
             // decode: QK-norm + RoPE + KV write happen in the attention kernel's prologue (one launch fewer)
             RUN(paged_decode_attention_fused_qkv_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
                                                      cos_l, sin_l, c.rms_eps, qk_mode, L.k_pool, L.v_pool, m->attn_out,
-                                                     bt, kvl, sh.num_seqs, sh.max_kv_len, nq, nkv, hd, KV_BLOCK,
+                                                     bt, kvl, sh.num_seqs, sh.max_kv_len, nq, nkv, hd, layer_window, KV_BLOCK,
                                                      m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
         } else {
             RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy,
@@ -974,7 +975,8 @@ int ferrum_hip_model_unified_forward(FerrumHipModel* m, const FerrumHipBatchItem
         reqs[i] = {it.seq_id, it.pos_offset + it.num_q_tokens, 0};
     }
     FH_REQUIRE(sh.m_total <= c.max_tokens, "unified_forward: %d tokens > max_tokens %d", sh.m_total, c.max_tokens);
-    if (c.sliding_window > 0 && c.sliding_window_pattern == 0) sh.pure_decode = false;   // uniform window: varlen path on every layer
+    sh.all_single_token = sh.pure_decode;
+    if (c.sliding_window > 0 && c.sliding_window_pattern == 0) sh.pure_decode = false;   // uniform window: no full-attention layer
     if (int rc = reserve(m, reqs.data(), num_items, nullptr)) return rc;
 
     // index block
@@ -1027,6 +1029,7 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
     // uniform sliding window: every layer takes the windowed varlen path (cu / pos live on the device like kv_lens);
     // a local/global pattern decides per layer inside enqueue_forward
     sh.pure_decode = !(c.sliding_window > 0 && c.sliding_window_pattern == 0);
+    sh.all_single_token = true;
     for (int i = 0; i < n; i++) {
         auto f = m->seqs.find(seq_ids[i]);
         FH_REQUIRE(f != m->seqs.end() && f->second.len > 0, "decode_steps: sequence %llu has no prefilled context", (unsigned long long)seq_ids[i]);

@@ -178,13 +178,15 @@ int ferrum_hip_paged_batched_decode_attention_f16(const void* q, const void* k_p
                                                   FerrumHipWorkspace* ws, void* stream);
 /* Decode step of one layer in ONE launch: split_qkv_norm_rope_into_paged_cache_varlen with one token per sequence
  * at position valid_kv_lens[s] − 1, then paged_batched_decode_attention.  Bit-identical to the two-op chain
- * (same float operations per row); q is never materialised.  GQA group ≤ 14. */
+ * (same float operations per row); q is never materialised.  GQA group ≤ 14.  sliding_window > 0 restricts every
+ * sequence to its last `sliding_window` keys (the varlen op's window rule). */
 int ferrum_hip_paged_decode_attention_fused_qkv_f16(const void* qkv, const void* q_norm_w, const void* k_norm_w,
                                                     const float* cos_tab, const float* sin_tab, float eps, int qk_mode,
                                                     void* k_pool, void* v_pool, void* out, const int32_t* block_tables,
                                                     const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len,
-                                                    int num_heads, int num_kv_heads, int head_dim, int block_size,
-                                                    int max_num_blocks_per_seq, FerrumHipWorkspace* ws, void* stream);
+                                                    int num_heads, int num_kv_heads, int head_dim, int sliding_window,
+                                                    int block_size, int max_num_blocks_per_seq, FerrumHipWorkspace* ws,
+                                                    void* stream);
 /* Gather one sequence's K/V to token-major [kv_len, kv_heads, head_dim] (ferrum-kv read_kv order,
  * ferrum-kv/src/managers/paged.rs:528-561).  Off the hot path (tests, prefix export). */
 int ferrum_hip_paged_kv_read_f16(const void* cache_k, const void* cache_v, const int32_t* block_table, int kv_len,

@@ -381,10 +381,11 @@ def test_paged_decode_long_context_split_kv(env):
         assert nmse(ref, got[s:s + 1]) < 1e-5
 
 
-@pytest.mark.parametrize("nq,nkv,hd,kv_lens,qk_mode", [
-    (32, 4, 128, [1, 16, 17, 257, 300, 384, 33, 250], 1), (32, 8, 128, [100, 5], 2), (8, 8, 128, [48], 3),
-    (16, 2, 128, [700, 31], 0), (4, 2, 64, [77, 64, 65], 1), (8, 2, 256, [40, 130], 1), (32, 4, 128, [4096, 1500], 1)])
-def test_paged_decode_attention_fused_qkv_equals_two_op_chain(env, nq, nkv, hd, kv_lens, qk_mode):
+@pytest.mark.parametrize("nq,nkv,hd,kv_lens,qk_mode,window", [
+    (32, 4, 128, [1, 16, 17, 257, 300, 384, 33, 250], 1, 0), (32, 8, 128, [100, 5], 2, 0), (8, 8, 128, [48], 3, 0),
+    (16, 2, 128, [700, 31], 0, 0), (4, 2, 64, [77, 64, 65], 1, 0), (8, 2, 256, [40, 130], 1, 0), (32, 4, 128, [4096, 1500], 1, 0),
+    (32, 16, 128, [300, 7, 1024, 1025, 40], 1, 64), (8, 2, 128, [90, 33], 2, 17)])
+def test_paged_decode_attention_fused_qkv_equals_two_op_chain(env, nq, nkv, hd, kv_lens, qk_mode, window):
     """One-launch decode (QK-norm + RoPE + KV write in the attention prologue) is bit-identical — attention output
     AND both cache pools — to split_qkv_norm_rope_into_paged_cache_varlen + paged_batched_decode_attention."""
     pkg, B, ctx, O, torch = env
@@ -415,9 +416,13 @@ def test_paged_decode_attention_fused_qkv_equals_two_op_chain(env, nq, nkv, hd, 
     B.split_qkv_norm_rope_into_paged_cache_varlen(ctx, qkv, qn, kn, cosd, sind, q_out, ck, cv,
                                                   torch.arange(S + 1, dtype=torch.int32, device="cuda"), lens - 1, td, S, S,
                                                   nq, nkv, hd, 1e-6, qk_mode, 16, max_blocks)
-    B.paged_batched_decode_attention(ctx, q_out, ck, cv, out1, td, lens, S, max(kv_lens), nq, nkv, hd, 16, max_blocks)
+    if window:      # sliding window: the varlen op is the two-op reference (decode form: one query token per sequence)
+        B.paged_varlen_attention(ctx, q_out, ck, cv, out1, torch.arange(S + 1, dtype=torch.int32, device="cuda"), lens - 1, td, S, S,
+                                 max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max_q_len=1)
+    else:
+        B.paged_batched_decode_attention(ctx, q_out, ck, cv, out1, td, lens, S, max(kv_lens), nq, nkv, hd, 16, max_blocks)
     B.paged_decode_attention_fused_qkv(ctx, qkv, qn, kn, cosd, sind, 1e-6, qk_mode, ck2, cv2, out2, td, lens, S, max(kv_lens),
-                                       nq, nkv, hd, 16, max_blocks)
+                                       nq, nkv, hd, 16, max_blocks, sliding_window=window)
     ctx.sync()
     assert torch.equal(ck, ck2) and torch.equal(cv, cv2)
     assert torch.equal(out1, out2)
