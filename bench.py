@@ -45,14 +45,19 @@ def build_model(pkg, cfg, c, max_seq_len, prefill_tokens, seed, layers=None):
     return m
 
 
-def prefill(model, prompts, first_id, chunk_tokens):
-    """Whole-prompt prefill in batches of ≤ chunk_tokens query tokens; returns the first sampled tokens."""
+def prefill(model, prompts, first_id, chunk_tokens, ttft_ms=None):
+    """Whole-prompt prefill in batches of ≤ chunk_tokens query tokens; returns the first sampled tokens.
+    ttft_ms (list) receives, per prompt, the time from the start of the call to its first token (all prompts are
+    submitted together, like a closed-loop client at concurrency len(prompts))."""
     out = []
     per = max(1, chunk_tokens // len(prompts[0]))
+    t0 = time.perf_counter()
     for i in range(0, len(prompts), per):
         items = [(first_id + i + j, p, 0, True) for j, p in enumerate(prompts[i:i + per])]
-        toks, _ = model.unified_forward(items, greedy=True)
+        toks, _ = model.unified_forward(items, greedy=True)        # returns after the tokens are on the host
         out.extend(int(t) for t in toks)
+        if ttft_ms is not None:
+            ttft_ms.extend([(time.perf_counter() - t0) * 1e3] * len(items))
     return np.array(out, np.uint32)
 
 
@@ -165,14 +170,17 @@ def main():
         torch.cuda.synchronize()
 
     prefill_ms = {}
+    ttft_by_c = {}
 
     def run_case(model, conc, steps, warm, first_id):
         rng = np.random.default_rng(9271 + rank)               # seed of the reference's bench-serve command
         prompts = [rng.integers(256, cfg["vocab"], size=PL).astype(np.uint32) for _ in range(conc)]
         torch.cuda.synchronize()
         tp0 = time.perf_counter()
-        first = prefill(model, prompts, first_id, chunk)
+        tt = []
+        first = prefill(model, prompts, first_id, chunk, tt)
         prefill_ms[conc] = (time.perf_counter() - tp0) * 1e3   # all `conc` prompts prefilled (≤ 2048 tokens per forward)
+        ttft_by_c[conc] = float(np.median(tt))
         ids = list(range(first_id, first_id + conc))
         warm_toks = model.decode_steps(ids, first, warm) if warm > 0 else None
         nxt = warm_toks[-1] if warm > 0 else first
@@ -256,6 +264,8 @@ def main():
             extra["sweep_tok_s"] = sweep
             extra["ttft_ms_p50_c1"] = round(float(np.median(ttft)), 2)
             extra["prefill_ms_all_prompts"] = {str(k): round(v, 2) for k, v in sorted(prefill_ms.items())}
+            # p50 time-to-first-token when all c prompts arrive together (BASELINE.md quotes the reference's per-c TTFT)
+            extra["ttft_ms_p50_by_c"] = {str(k): round(v, 2) for k, v in sorted(ttft_by_c.items())}
         if not args.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline(cfg)
 
