@@ -55,6 +55,7 @@ struct FerrumHipModel {
     float* cos_local = nullptr;    // RoPE table of the local-attention layers (rope_local_theta), else null
     float* sin_local = nullptr;
     float* residual_f32 = nullptr; // fp32 residual stream of sandwich-norm models
+    __half* gather_scratch = nullptr;   // [max_tokens, max K] input column gather for act-order (desc_act) weights
     std::vector<fh::LayerWeights> layers;
 
     // KV

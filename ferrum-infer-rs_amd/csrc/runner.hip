@@ -267,7 +267,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
                     (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
-                    (void*)m->sin_local, (void*)m->residual_f32})
+                    (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -464,6 +464,13 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     int rc = 0;
     rc |= dev_alloc(&m->residual, T * H);
     if (c.sandwich_norms) rc |= dev_alloc(&m->residual_f32, T * H);
+    {
+        size_t kmax = 0;     // act-order input gather scratch
+        for (const LayerWeights& L : m->layers)
+            for (const W4Device* w : {&L.qkv, &L.o, &L.gate_up, &L.down})
+                if (w->perm) kmax = std::max(kmax, (size_t)w->k);
+        if (kmax) rc |= dev_alloc(&m->gather_scratch, T * kmax);
+    }
     rc |= dev_alloc(&m->norm_out, T * H);
     rc |= dev_alloc(&m->qkv_out, T * qkv_dim(c));
     rc |= dev_alloc(&m->q_out, T * q_dim(c));
@@ -720,6 +727,17 @@ struct StepShape {
 template <typename T>
 T* idx(FerrumHipModel* m, size_t off) { return reinterpret_cast<T*>(m->idx_dev + off); }
 
+// Dense projection of the runner: act-order (desc_act) weights were repacked with their rows sorted by group, so the
+// input columns are gathered with the same permutation first (like the op-level ferrum_hip_gptq_linear_forward_f16).
+int dense_linear(FerrumHipModel* m, const W4Device& w, const __half* x, __half* out, int T, hipStream_t s) {
+    if (w.perm) {
+        FH_REQUIRE(m->gather_scratch, "dense_linear: act-order weights but no gather scratch");
+        if (int rc = gather_columns_f16(x, w.perm, m->gather_scratch, T, w.k, s)) return rc;
+        x = m->gather_scratch;
+    }
+    return w4_gemm_dense(w, x, out, T, m->workspace, m->workspace_bytes, s);
+}
+
 // Enqueue every kernel of one forward on m->stream.  Index tensors are already on the device.
 int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
     const FerrumHipModelConfig& c = m->cfg;
@@ -749,7 +767,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
         const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
-        RUN(w4_gemm_dense(L.qkv, m->norm_out, m->qkv_out, T, m->workspace, m->workspace_bytes, s));
+        RUN(dense_linear(m, L.qkv, m->norm_out, m->qkv_out, T, s));
         // per-layer attention schedule (llama_layer_attention_schedule, llama_family.rs:1028-1045)
         const int pattern = c.sliding_window_pattern;
         const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
@@ -785,7 +803,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             const int tiles = (E + 15) / 16;
             int Q = m->route_parts;
             while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
-            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && c.tp_world == 1 && Q >= 1 && tiles / Q <= 8;
+            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && c.tp_world == 1 && Q >= 1 && tiles / Q <= 8 && !L.o.perm;
             if (decode_fast) {
                 // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
                 const float* slabs = nullptr;
@@ -795,7 +813,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                     slabs = m->workspace;
                     S = std::min(S, L.o.G);
                 } else {
-                    RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
                 }
                 if (Q > 1) {
                     // B over Q expert parts per token (one CU pulls the 512-KB router at ≈70 GB/s; Q CUs share it):
@@ -823,7 +841,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                                                      m->norm_out, T, K, H, s));
                 }
             } else {
-                RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+                RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
                 RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                 if (T >= m->route_gemm_min_tokens) {
                     // prefill: one workgroup per token would pull the whole router (E·H·2 B) from L2 per token (2048 tokens:
@@ -863,7 +881,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             const int I = c.intermediate;
             // 17–32 rows, one GPU: every projection of the MLP block writes fp32 split-K slabs (LDS-shared activations) and
             // the consumer that exists anyway — add+norm, gated activation — sums them: no reduce launches.
-            const bool slab_chain = m->dense_slabs && c.tp_world == 1 && T > 16 && T <= 32;
+            const bool slab_chain = m->dense_slabs && c.tp_world == 1 && T > 16 && T <= 32 && !L.o.perm && !L.gate_up.perm && !L.down.perm;
             int S = 0, rows_pad = 0, n_pad = 0;
             if (slab_chain) {
                 RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
@@ -889,7 +907,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
                                                            nullptr, nullptr, nullptr, T, H, s));
                 }
             } else {
-            RUN(w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s));
+            RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
             RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
             if (sandwich) {
                 // Gemma 3 (llama_family.rs:3357-3421): residual += norm(o, post_attention_layernorm); pre-MLP norm
@@ -897,13 +915,13 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
             } else {
                 RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
             }
-            RUN(w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s));
+            RUN(dense_linear(m, L.gate_up, m->norm_out, m->gate_up_out, T, s));
             if (c.activation == 1) {
                 RUN(fused_gelu_tanh_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
             } else {
                 RUN(fused_silu_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
             }
-            RUN(w4_gemm_dense(L.down, m->act_out, m->mlp_out, T, m->workspace, m->workspace_bytes, s));
+            RUN(dense_linear(m, L.down, m->act_out, m->mlp_out, T, s));
             RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
             if (sandwich) {
                 // residual += norm(mlp_out, post_feedforward_layernorm); next layer's input norm rides along

@@ -16,6 +16,8 @@ def f16r(a):
 
 def synth_gptq(k, n, seed, symmetric=True, group=128):
     qw, sc, qz = O.make_synthetic_gptq(k, n, group, seed, symmetric=symmetric)
+    if not symmetric:      # centre the asymmetric codes so activations stay O(1): zero points drawn by the LCG stay as they are
+        pass
     # keep activations O(1): W std ≈ 1/sqrt(K)  (same factor the device-side generator uses)
     sc = f16r(sc * (1.0 / (0.28 * np.sqrt(k))))
     return qw, sc, qz
@@ -25,7 +27,7 @@ class TinyModel:
     def __init__(self, moe, layers=2, hidden=256, nq=4, nkv=2, hd=128, inter=256, vocab=512, experts=8, top_k=2,
                  expert_inter=128, qk_norm=True, seed=0, max_seq_len=256, activation=0, sliding_window=0,
                  rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False, sandwich=False,
-                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0):
+                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False):
         self.cfg = dict(num_layers=layers, hidden=hidden, num_heads=nq, num_kv_heads=nkv, head_dim=hd,
                         intermediate=0 if moe else inter, vocab=vocab, max_seq_len=max_seq_len, has_qk_norm=int(qk_norm),
                         activation=activation, num_experts=experts if moe else 0, top_k=top_k if moe else 0,
@@ -52,8 +54,10 @@ class TinyModel:
                 L["dense"]["q_norm"] = f16r(1.0 + 0.1 * rng.standard_normal(hd))
                 L["dense"]["k_norm"] = f16r(1.0 + 0.1 * rng.standard_normal(hd))
             s0 = 1000 * (li + 1) + seed * 77
-            L["gptq"]["qkv"] = (H, qd + 2 * kvd) + synth_gptq(H, qd + 2 * kvd, s0 + 1)
-            L["gptq"]["o"] = (qd, H) + synth_gptq(qd, H, s0 + 2)
+            sym = not asym_act_order
+            L["g_idx"] = {}
+            L["gptq"]["qkv"] = (H, qd + 2 * kvd) + synth_gptq(H, qd + 2 * kvd, s0 + 1, symmetric=sym)
+            L["gptq"]["o"] = (qd, H) + synth_gptq(qd, H, s0 + 2, symmetric=sym)
             if moe:
                 L["dense"]["router"] = f16r(rng.standard_normal((experts, H)) * 0.5)
                 for e in range(experts):
@@ -61,8 +65,11 @@ class TinyModel:
                         "expert_gate_up": (H, 2 * expert_inter) + synth_gptq(H, 2 * expert_inter, s0 + 100 + 2 * e),
                         "expert_down": (expert_inter, H) + synth_gptq(expert_inter, H, s0 + 101 + 2 * e)}
             else:
-                L["gptq"]["gate_up"] = (H, 2 * inter) + synth_gptq(H, 2 * inter, s0 + 3)
-                L["gptq"]["down"] = (inter, H) + synth_gptq(inter, H, s0 + 4)
+                L["gptq"]["gate_up"] = (H, 2 * inter) + synth_gptq(H, 2 * inter, s0 + 3, symmetric=sym)
+                L["gptq"]["down"] = (inter, H) + synth_gptq(inter, H, s0 + 4, symmetric=sym)
+            if asym_act_order:   # desc_act checkpoints (Gemma-3 GPTQ packs): a shuffled row → group map per projection
+                for name, (k_, _n, _qw, _sc, _qz) in L["gptq"].items():
+                    L["g_idx"][name] = rng.permutation(np.arange(k_) // 128).astype(np.int32)
             self.layers.append(L)
 
     def load_into(self, model, is_oracle):
@@ -72,10 +79,11 @@ class TinyModel:
             for name, data in L["dense"].items():
                 model.set_layer_dense(li, name, data)
             for name, (k, n, qw, sc, qz) in L["gptq"].items():
+                gi = L.get("g_idx", {}).get(name)
                 if is_oracle:
-                    model.set_gptq(li, name, qw, sc, qz, 128, k, n)
+                    model.set_gptq(li, name, qw, sc, qz, 128, k, n, g_idx=gi)
                 else:
-                    model.set_gptq(li, name, qw, sc, qz, k, n)
+                    model.set_gptq(li, name, qw, sc, qz, k, n, g_idx=gi)
             for e, d in L["experts"].items():
                 for name, (k, n, qw, sc, qz) in d.items():
                     if is_oracle:

@@ -46,6 +46,16 @@ def test_llama_style_no_qk_norm_rope_scaling_and_tied_head(pkg):
     _assert_parity(res)
 
 
+@pytest.mark.parametrize("prompt_len", [9, 23, 70])
+def test_asymmetric_act_order_checkpoint_style(pkg, prompt_len):
+    """desc_act + asymmetric zero points on every dense projection (the Gemma-3 GPTQ pack style of BASELINE configs[3]):
+    per-row group map, per-group zero points — through the ≤16-row, 17–32-row and ≥64-row GEMM paths."""
+    from tests import modelgen
+    res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=prompt_len, decode_steps=2, seed=91 + prompt_len,
+                                   asym_act_order=True, hidden=256, inter=512)
+    _assert_parity(res)
+
+
 def test_gelu_activation_model(pkg):
     from tests import modelgen
     res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=9, decode_steps=2, seed=6, activation=1)
