@@ -29,7 +29,17 @@ QWEN3_30B_A3B = dict(num_layers=48, hidden=2048, num_heads=32, num_kv_heads=4, h
 LLAMA31_8B = dict(num_layers=32, hidden=4096, num_heads=32, num_kv_heads=8, head_dim=128, intermediate=14336,
                   vocab=128256, has_qk_norm=0, activation=0, num_experts=0, top_k=0, expert_inter=0, norm_topk_prob=0,
                   rms_eps=1e-5, rope_theta=5e5)
-MODELS = {"qwen3-30b-a3b": QWEN3_30B_A3B, "llama31-8b": LLAMA31_8B}
+# BASELINE configs[3]/[4] are TP=2 / TP=8 on the reference's 24 GB cards; one 288 GB MI355X holds them whole, so they are
+# benchable here at TP=1 (extra workloads, not the metric).
+GEMMA3_27B = dict(num_layers=62, hidden=5376, num_heads=32, num_kv_heads=16, head_dim=128, intermediate=21504, vocab=262208,
+                  has_qk_norm=1, activation=1, num_experts=0, top_k=0, expert_inter=0, norm_topk_prob=0, rms_eps=1e-6,
+                  rope_theta=1e6, rope_scaling_kind=1, rope_p0=8.0, sliding_window=1024, sliding_window_pattern=6,
+                  sandwich_norms=1, embed_scale=73.5, rope_local_theta=10000.0)
+LLAMA3_70B = dict(num_layers=80, hidden=8192, num_heads=64, num_kv_heads=8, head_dim=128, intermediate=28672, vocab=128256,
+                  has_qk_norm=0, activation=0, num_experts=0, top_k=0, expert_inter=0, norm_topk_prob=0, rms_eps=1e-5,
+                  rope_theta=5e5)
+MODELS = {"qwen3-30b-a3b": QWEN3_30B_A3B, "llama31-8b": LLAMA31_8B, "gemma3-27b": GEMMA3_27B, "llama3-70b": LLAMA3_70B}
+BASELINE_CFG_INDEX = {"qwen3-30b-a3b": 2, "llama31-8b": 1, "gemma3-27b": 3, "llama3-70b": 4}
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -273,16 +283,18 @@ def main():
         # BASELINE.md's published c=32 number for this model (RTX 4090, ferrum 0.7.7 gate, `ferrum bench-serve`: output
         # tokens over the whole 256-in/128-out run, i.e. prefill included).  `value` is the decode-loop rate BASELINE.md
         # line 52 defines; `e2e_tok_s` is the serve-like form (prefill of all prompts + 128 decode steps) for a like-for-like ratio.
-        ref_c32 = 706.0 if moe else 745.6
+        ref_c32 = 706.0 if moe else 745.6          # the reference publishes c=32 numbers for configs[2] and configs[1] only
         if c in prefill_ms:
             e2e = world * c * 128 / (prefill_ms[c] / 1e3 + 128 * t_max / K)
             extra["e2e_tok_s"] = round(e2e, 1)
-            extra["e2e_vs_baseline"] = round(e2e / ref_c32, 2)
+            if args.model in ("qwen3-30b-a3b", "llama31-8b"):
+                extra["e2e_vs_baseline"] = round(e2e / ref_c32, 2)
         if moe:
             extra["baseline"] = {"value": ref_c32, "unit": "tok/s", "hardware": "1x RTX 4090 (reference CUDA lane)",
                                  "source": "BASELINE.md table row 'Qwen3-30B-A3B-GPTQ-Int4 output tok/s (0.7.7 gate)', c=32"}
         is_metric = args.model == "qwen3-30b-a3b" and c == 32 and model.cfg.num_layers == cfg["num_layers"]
-        mname = {"qwen3-30b-a3b": "Qwen3-30B-A3B", "llama31-8b": "Llama-3.1-8B"}[args.model]
+        mname = {"qwen3-30b-a3b": "Qwen3-30B-A3B", "llama31-8b": "Llama-3.1-8B", "gemma3-27b": "Gemma-3-27B",
+                 "llama3-70b": "Llama-3-70B"}[args.model]
         if args.model == "llama31-8b":
             extra["baseline"] = {"value": 745.6, "unit": "tok/s", "hardware": "1x RTX 4090 (reference CUDA lane)",
                                  "source": "BASELINE.md row 'Llama-3.1-8B-Instruct-GPTQ-INT4 output tok/s', c=32"}
@@ -292,7 +304,7 @@ def main():
                 "vs_baseline": round(value / ref_c32, 2) if is_metric else None,
                 "dtype": "int4-weights/f16-activations/f32-accumulate",
                 "data": "synthetic",
-                "config": {"workload": f"{mname} GPTQ-INT4 (BASELINE configs[{2 if moe else 1}]), TP=1 per GPU, replicas across GPUs",
+                "config": {"workload": f"{mname} GPTQ-INT4 (BASELINE configs[{BASELINE_CFG_INDEX[args.model]}]), TP=1 per GPU, replicas across GPUs",
                            "concurrency": c, "prompt_len": PL, "kv_len_range": [PL + W, PL + W + K], "kv_block": 16,
                            "layers": model.cfg.num_layers, "parallelism": f"replica x{world}"}}
         line.update(extra)

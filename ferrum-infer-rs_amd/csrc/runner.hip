@@ -396,6 +396,10 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
         uint64_t ls = seed + 0x1000003ull * (uint64_t)(li + 1);
         if (int rc = alloc_fill(&L.input_ln, c.hidden, 1.0f)) return rc;
         if (int rc = alloc_fill(&L.post_ln, c.hidden, 1.0f)) return rc;
+        if (c.sandwich_norms) {
+            if (int rc = alloc_fill(&L.post_attn_ln, c.hidden, 1.0f)) return rc;
+            if (int rc = alloc_fill(&L.post_ffn_ln, c.hidden, 1.0f)) return rc;
+        }
         if (c.has_qk_norm) {
             if (int rc = alloc_fill(&L.q_norm, c.head_dim, 1.0f)) return rc;
             if (int rc = alloc_fill(&L.k_norm, c.head_dim, 1.0f)) return rc;
