@@ -1233,6 +1233,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
         const int cols = cdiv(w.n64, nw);
         int S = 1;
         while ((long)cols * row_blocks * S < 128 && w.G / (S * 2) >= 8) S *= 2;
+        while (w.n64 <= 128 && (long)cols * row_blocks * S < 256 && w.G / (S * 2) >= 16) S *= 2;
         if (const char* e = getenv("FERRUM_HIP_W4_LDSA_S")) S = std::max(1, std::min(atoi(e), w.G));
         const int rows_pad = row_blocks * 16 * mt, n_pad = w.n64 * 64;
         if (S > 1 && (workspace == nullptr || (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes)) S = 1;
@@ -1357,6 +1358,9 @@ int w4_gemm_dense_lds_splits(const W4Device& w, int m) {
     if (const char* e = getenv("FERRUM_HIP_LDS_MIN_WGS")) min_wgs = atoi(e);
     if (const char* e = getenv("FERRUM_HIP_LDS_MIN_GROUPS")) min_groups = atoi(e);
     while ((long)cols * row_blocks * S < min_wgs && w.G / (S * 2) >= min_groups) S *= 2;
+    // deep K (≥ 16 groups per split left): go on to one workgroup per CU — Llama-70B down 28672→8192 ran on 128 of 256 CUs
+    // (narrow N only: for wide N the extra fp32 slabs cost more than the idle CUs — Gemma-3 gate_up 5376→43008 got slower)
+    while (w.n64 <= 128 && (long)cols * row_blocks * S < 2 * min_wgs && w.G / (S * 2) >= 2 * min_groups) S *= 2;
     return S;
 }
 
