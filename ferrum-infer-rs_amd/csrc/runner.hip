@@ -756,6 +756,9 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
     const int32_t* bt = idx<int32_t>(m, m->il.block_tables);
     int rc;
 #define RUN(x) if ((rc = (x))) return rc
+    // arrival counters of the split route kernel: re-armed by the kernel itself, but zeroed per forward as well so that an
+    // aborted launch can never poison the next one (one 256-byte memset node per step)
+    if (m->route_arrive) FH_CHECK_HIP(hipMemsetAsync(m->route_arrive, 0, 64 * sizeof(unsigned), s));
     RUN(embedding_lookup_f16(m->embed, tokens, m->residual, T, H, s));
     if (c.embed_scale != 0.0f) RUN(scale_inplace_f16(m->residual, c.embed_scale, (long)T * H, s));   // llama_family.rs:3656
     const bool sandwich = c.sandwich_norms != 0;
