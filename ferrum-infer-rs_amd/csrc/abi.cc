@@ -302,9 +302,8 @@ int ferrum_hip_gptq_linear_forward_f16(const FerrumHipGptq* handle, const void* 
         if (int rc = gather_columns_f16(x, g->dev.perm, g->gather_scratch, m, g->dev.k, ST(stream))) return rc;
         x = g->gather_scratch;
     }
-    if (int rc = w4_gemm_dense(g->dev, x, H(out), m, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream))) return rc;
-    if (g->dev.bias) return add_bias_f16(H(out), g->dev.bias, m, g->dev.n, ST(stream));
-    return 0;
+    // the bias (if any) is added in the GEMM epilogue / split-K reduce (W4Device::bias)
+    return w4_gemm_dense(g->dev, x, H(out), m, ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
 }
 
 int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input, const int32_t* sorted_token_ids,

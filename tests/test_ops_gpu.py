@@ -133,6 +133,29 @@ def test_gptq_asymmetric_and_act_order(env, k, n, m):
     assert nmse(ref, got) < NMSE_FP16_TOL
 
 
+@pytest.mark.parametrize("k,n,ms,sym", [
+    # row-count boundaries of the three dense kernels (≤16 wgsplit, 17–32 LDS-A / wgsplit, ≥64 tile + split-K, 33–63 wgsplit)
+    # on shapes that select each path: deep-K narrow-N (LDS-A with slabs), wide-N, tiny, N not a multiple of 64, asymmetric
+    (8192, 2048, (16, 17, 32, 33), True), (1024, 16384, (17, 32, 64, 65), True), (256, 64, (1, 16, 31, 63, 64, 127, 128, 200), True),
+    (1536, 1000, (5, 20, 64, 130), True), (2048, 640, (24, 64, 96), False), (14336, 512, (32, 64), True)])
+def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym):
+    pkg, B, ctx, O, torch = env
+    qw, sc, qz = O.make_synthetic_gptq(k, n, 128, k * 7 + n, symmetric=sym)
+    sc = f16r(sc / (0.28 * np.sqrt(k)))
+    bias = f16r(np.random.default_rng(n).standard_normal(n)) if n == 640 else None
+    lin = pkg.GptqLinear.from_raw(qw, sc, qz, None, bias, 4, 128, k, n)
+    w = O.dequant_gptq(qw, sc, qz, 128, k, n)
+    for m in ms:
+        x = f16r(np.random.default_rng(m).standard_normal((m, k)))
+        out = torch.full((m + 1, n), 7.0, dtype=torch.float16, device="cuda")     # guard row: nothing may write past m rows
+        lin.forward(ctx, dev16(torch, x), out, m)
+        ctx.sync()
+        ref = O.gemm(x, w, m, n, k) + (bias[None, :] if bias is not None else 0.0)
+        got = host(out)
+        assert nmse(ref, got[:m]) < NMSE_FP16_TOL, (k, n, m)
+        assert np.all(got[m] == 7.0), (k, n, m)
+
+
 def test_gptq_linearity(env):
     # size-independent property at a BASELINE shape (Llama-8B o_proj 4096→4096): f(a·x+y) = a·f(x)+f(y)
     pkg, B, ctx, O, torch = env
