@@ -56,6 +56,23 @@ def test_asymmetric_act_order_checkpoint_style(pkg, prompt_len):
     _assert_parity(res)
 
 
+@pytest.mark.parametrize("kw", [
+    dict(moe=False, nq=4, nkv=4, hd=64, hidden=256),                        # MHA, head_dim 64
+    dict(moe=False, nq=14, nkv=2, hd=128, hidden=256),                      # GQA group 7 (Qwen2-7B style: 28/4)
+    dict(moe=False, nq=2, nkv=1, hd=256, hidden=384, inter=384),            # head_dim 256, hidden not a power of two
+    dict(moe=True, experts=60, top_k=4, expert_inter=128, hidden=256),      # expert count not a multiple of 16
+    dict(moe=True, experts=128, top_k=8, expert_inter=128, hidden=128),     # one quant group per down projection, 128 experts
+    dict(moe=False, vocab=1000, hidden=256),                                # vocabulary not a multiple of 16
+    dict(moe=True, vocab=777, experts=16, top_k=1, hidden=256),             # top-1 routing, odd vocabulary
+], ids=lambda kw: "-".join(f"{k}{v}" for k, v in kw.items()))
+def test_unusual_model_shapes(pkg, kw):
+    """Shapes off the BASELINE configs' beaten path, prefill 27 tokens (two KV blocks, ragged) + 3 decode steps."""
+    from tests import modelgen
+    kw = dict(kw)
+    res = modelgen.run_parity_case(pkg, layers=2, prompt_len=27, decode_steps=3, seed=101, **kw)
+    _assert_parity(res)
+
+
 def test_gelu_activation_model(pkg):
     from tests import modelgen
     res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=9, decode_steps=2, seed=6, activation=1)
