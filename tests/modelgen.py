@@ -14,12 +14,13 @@ def f16r(a):
     return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
 
 
-def synth_gptq(k, n, seed, symmetric=True, group=128):
+def synth_gptq(k, n, seed, symmetric=True, group=128, gain=1.0):
     qw, sc, qz = O.make_synthetic_gptq(k, n, group, seed, symmetric=symmetric)
-    if not symmetric:      # centre the asymmetric codes so activations stay O(1): zero points drawn by the LCG stay as they are
-        pass
-    # keep activations O(1): W std ≈ 1/sqrt(K)  (same factor the device-side generator uses)
-    sc = f16r(sc * (1.0 / (0.28 * np.sqrt(k))))
+    # keep activations O(1): W std ≈ gain/sqrt(K)  (same factor the device-side generator uses).  The projections that write
+    # into the residual stream (o, down) get gain 0.3, like trained models whose branch updates are small against the stream:
+    # with gain 1 the stream grows to rms ≈ 100 and single tokens end as near-cancellations of it, which turns the fp16
+    # storage rounding of the stream (2^-11 of its largest entries) into percent-level logit differences on those tokens.
+    sc = f16r(sc * (gain / (0.28 * np.sqrt(k))))
     return qw, sc, qz
 
 
@@ -57,16 +58,16 @@ class TinyModel:
             sym = not asym_act_order
             L["g_idx"] = {}
             L["gptq"]["qkv"] = (H, qd + 2 * kvd) + synth_gptq(H, qd + 2 * kvd, s0 + 1, symmetric=sym)
-            L["gptq"]["o"] = (qd, H) + synth_gptq(qd, H, s0 + 2, symmetric=sym)
+            L["gptq"]["o"] = (qd, H) + synth_gptq(qd, H, s0 + 2, symmetric=sym, gain=0.3)
             if moe:
                 L["dense"]["router"] = f16r(rng.standard_normal((experts, H)) * 0.5)
                 for e in range(experts):
                     L["experts"][e] = {
                         "expert_gate_up": (H, 2 * expert_inter) + synth_gptq(H, 2 * expert_inter, s0 + 100 + 2 * e),
-                        "expert_down": (expert_inter, H) + synth_gptq(expert_inter, H, s0 + 101 + 2 * e)}
+                        "expert_down": (expert_inter, H) + synth_gptq(expert_inter, H, s0 + 101 + 2 * e, gain=0.3)}
             else:
                 L["gptq"]["gate_up"] = (H, 2 * inter) + synth_gptq(H, 2 * inter, s0 + 3, symmetric=sym)
-                L["gptq"]["down"] = (inter, H) + synth_gptq(inter, H, s0 + 4, symmetric=sym)
+                L["gptq"]["down"] = (inter, H) + synth_gptq(inter, H, s0 + 4, symmetric=sym, gain=0.3)
             if asym_act_order:   # desc_act checkpoints (Gemma-3 GPTQ packs): a shuffled row → group map per projection
                 for name, (k_, _n, _qw, _sc, _qz) in L["gptq"].items():
                     L["g_idx"][name] = rng.permutation(np.arange(k_) // 128).astype(np.int32)

@@ -181,6 +181,13 @@ FULL_DIMS = {
     "qwen3-30b-a3b": dict(moe=True, hidden=2048, nq=32, nkv=4, hd=128, experts=128, top_k=8, expert_inter=768, c=32),
     "llama31-8b": dict(moe=False, hidden=4096, nq=32, nkv=8, hd=128, inter=14336, qk_norm=False, rope_theta=500000.0,
                        rope_scaling_kind=2, rope_p=(8.0, 1.0, 4.0, 8192.0), c=20),
+    # small models through the same batched harness: decode-sized fast paths (split router, slab chain) on odd shapes
+    "moe-60-experts": dict(moe=True, hidden=256, nq=4, nkv=2, hd=128, experts=60, top_k=4, expert_inter=128, layers=2, c=20,
+                           plen=5, steps=3),
+    "moe-top1-c64": dict(moe=True, hidden=256, nq=4, nkv=2, hd=128, experts=16, top_k=1, expert_inter=128, layers=2, c=64,
+                         plen=2, steps=2),
+    "dense-gqa7-c24": dict(moe=False, hidden=256, nq=14, nkv=2, hd=128, inter=384, layers=2, c=24, plen=4, steps=3),
+    "dense-hd64-c32": dict(moe=False, hidden=256, nq=8, nkv=8, hd=64, inter=256, layers=2, c=32, plen=3, steps=2),
     # Gemma-3 27B (configs[3]) layer at TP=1 dims: sandwich norms / fp32 residual, GeGLU, hidden 5376 = 42 quant groups;
     # two layers so that one is local (window 1024, θ 10k) and one global (linear-scaled θ 1M)
     "gemma3-27b": dict(moe=False, hidden=5376, nq=32, nkv=16, hd=128, inter=21504, activation=1, sandwich=True,
@@ -197,7 +204,7 @@ def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     layers, plen, steps = kw.pop("layers", 1), kw.pop("plen", 3), kw.pop("steps", 2)
     tm = modelgen.TinyModel(moe, layers=layers, vocab=2048, seed=41, max_seq_len=64, **kw)
     om = tm.oracle_model()
-    hm = tm.hip_model(pkg, kv_num_blocks=c + 4, max_seqs=c, max_tokens=4 * c)
+    hm = tm.hip_model(pkg, kv_num_blocks=c + 4, max_seqs=c, max_tokens=max(4, plen) * c)
     rng = np.random.default_rng(42)
     prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
     toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
@@ -233,8 +240,10 @@ def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     # Reference criterion (qwen3_cuda_parity_test.rs:194-240): argmax + cosine > 0.999.  The logits bound is wider than the
     # tiny models' 2 %: at these dims a numpy emulation of the fp16 lane's storage roundings (f16 after every op, same
     # experts picked) differs from the f32 CPU path by hidden NMSE 7.7e-4 on the worst token — the GPU shows 6.7e-4 there.
-    assert worst_cos > 0.999 and worst_rel < 5e-2, (worst_cos, worst_rel)
-    assert near <= c and route_ties <= c // 4                    # near-ties are rare; most rows must be decided
+    # (the hidden-256 entries average the fp16 storage rounding over 8–20× fewer terms than the BASELINE shapes: 0.995 / 10 %)
+    small = tm.cfg["hidden"] <= 256
+    assert worst_cos > (0.995 if small else 0.999) and worst_rel < (0.1 if small else 5e-2), (worst_cos, worst_rel)
+    assert near <= c and route_ties <= (c if small else c // 4)  # near-ties are rare at real dims; rows must be decided
     for i in (0, c - 1):
         for is_v in (0, 1):
             assert modelgen.nmse(om.read_kv(i, layers - 1, is_v), hm.read_kv(i, layers - 1, is_v)) < 3e-3
