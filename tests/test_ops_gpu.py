@@ -330,11 +330,11 @@ def test_paged_batched_decode_attention(env, nq, nkv, hd, kv_lens):
     assert NMSE_ATTN_TOL > 1e-5
 
 
-@pytest.mark.parametrize("window", [0, 24])
-def test_paged_varlen_attention_mixed_batch(env, window):
+@pytest.mark.parametrize("window,nq,nkv,hd", [(0, 8, 2, 128), (24, 8, 2, 128), (0, 14, 2, 128), (40, 28, 4, 128), (0, 4, 4, 64),
+                                              (17, 6, 6, 64), (0, 4, 1, 256), (33, 32, 16, 128), (1, 8, 2, 128)])
+def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd):
     pkg, B, ctx, O, torch = env
-    rng = np.random.default_rng(11 + window)
-    nq, nkv, hd = 8, 2, 128
+    rng = np.random.default_rng(11 + window + nq + hd)
     q_lens, pos_offs = [37, 1, 16, 3], [0, 90, 20, 250]       # fresh prefill, decode, chunk, late chunk
     S = len(q_lens)
     kv_lens = [p + t for p, t in zip(pos_offs, q_lens)]
