@@ -1209,6 +1209,38 @@ int ferrum_hip_tp_unique_id(uint8_t id[128]) {
     return 0;
 }
 
+// Plumbing self-test against the installed librccl: a 1-rank communicator on the current device all-reduces (fp16, sum,
+// in place) a known vector on a private stream; the vector must come back unchanged.  Exercises exactly the entry points,
+// enum values and by-value ncclUniqueId passing the tensor-parallel path uses (which needs ≥ 2 GPUs to run for real).
+int ferrum_hip_tp_selftest(int count) {
+    FH_REQUIRE(count > 0 && count <= (1 << 20), "tp_selftest: count=%d", count);
+    if (int rc = load_rccl()) return rc;
+    auto get_uid = (nccl_get_uid_t)dlsym(g_rccl, "ncclGetUniqueId");
+    auto init = (nccl_comm_init_rank_t)dlsym(g_rccl, "ncclCommInitRank");
+    auto destroy = (int (*)(void*))dlsym(g_rccl, "ncclCommDestroy");
+    FH_REQUIRE(get_uid && init && destroy, "tp_selftest: RCCL symbols missing");
+    UidBlob blob;
+    FH_REQUIRE(get_uid(blob.b) == 0, "tp_selftest: ncclGetUniqueId failed");
+    void* comm = nullptr;
+    FH_REQUIRE(init(&comm, 1, blob, 0) == 0 && comm, "tp_selftest: ncclCommInitRank failed");
+    std::vector<__half> host(count), back(count);
+    for (int i = 0; i < count; i++) host[i] = __float2half((float)(i % 257) * 0.25f - 16.0f);
+    __half* dev = nullptr;
+    hipStream_t s = nullptr;
+    FH_CHECK_HIP(hipMalloc((void**)&dev, (size_t)count * 2));
+    FH_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    FH_CHECK_HIP(hipMemcpyAsync(dev, host.data(), (size_t)count * 2, hipMemcpyHostToDevice, s));
+    const int rc = g_all_reduce(dev, dev, (size_t)count, 6 /* ncclFloat16 */, 0 /* ncclSum */, comm, s);
+    FH_CHECK_HIP(hipMemcpyAsync(back.data(), dev, (size_t)count * 2, hipMemcpyDeviceToHost, s));
+    FH_CHECK_HIP(hipStreamSynchronize(s));
+    (void)destroy(comm);
+    (void)hipStreamDestroy(s);
+    (void)hipFree(dev);
+    FH_REQUIRE(rc == 0, "tp_selftest: ncclAllReduce failed: %d", rc);
+    FH_REQUIRE(memcmp(host.data(), back.data(), (size_t)count * 2) == 0, "tp_selftest: 1-rank all-reduce changed the data");
+    return 0;
+}
+
 int ferrum_hip_model_tp_init(FerrumHipModel* m, const uint8_t id[128]) {
     FH_REQUIRE(m && id, "tp_init: null");
     if (m->cfg.tp_world <= 1) return 0;

@@ -439,6 +439,9 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* model, int which, int n_seqs, i
                                  float* avg_us, int* moe_blocks);
 /* Tensor parallel: 128-byte RCCL unique id created on rank 0 and broadcast by the host. */
 int ferrum_hip_tp_unique_id(uint8_t id[128]);
+/* 1-rank RCCL round trip on the current device (fp16 sum all-reduce, in place): checks the dlopen'ed entry points, enum values
+ * and by-value ncclUniqueId passing of the tensor-parallel path without needing a second GPU. */
+int ferrum_hip_tp_selftest(int count);
 int ferrum_hip_model_tp_init(FerrumHipModel* model, const uint8_t id[128]);
 
 #if defined(__GNUC__)

@@ -332,6 +332,13 @@ def test_decode_steps_graph_on_windowed_models(pkg, kind):
                 assert int(np.argmax(lg)) == seq[s + 1], (kind, i, s)
 
 
+def test_rccl_plumbing_selftest(pkg):
+    """The tensor-parallel path needs ≥ 2 GPUs; what can be checked on one is that the RCCL entry points resolve and a
+    1-rank fp16 sum all-reduce on a stream is the identity."""
+    lib = pkg.load_library()
+    assert lib.ferrum_hip_tp_selftest(4096 * 32) == 0, lib.ferrum_hip_last_error().decode()
+
+
 def test_kv_admission_contract(pkg):
     """reserve_kv_slots is atomic and release returns blocks LIFO (model_executor.rs:484, paged_pool.rs:333-345)."""
     from tests import modelgen
