@@ -103,4 +103,7 @@ struct FerrumHipModel {
 
     // tensor parallel (RCCL, resolved lazily by dlopen)
     void* nccl_comm = nullptr;
+    struct FerrumHipTpLoopback* tp_loopback = nullptr;   // in-process test stand-in for the communicator
+    __half* tp_tmp = nullptr;
+    size_t tp_tmp_elems = 0;
 };

@@ -14,6 +14,9 @@
 
 #include "runner.h"
 
+#include <condition_variable>
+#include <mutex>
+
 using namespace fh;
 
 namespace {
@@ -176,8 +179,62 @@ int load_rccl() {
     FH_REQUIRE(g_all_reduce, "tensor parallel: ncclAllReduce not found");
     return 0;
 }
+// Σ over ranks in rank order, fp32 accumulate, one rounding — every rank computes the same bits
+__global__ void loopback_sum_kernel(const __half* const* bufs, int world, __half* out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int r = 0; r < world; r++) s += __half2float(bufs[r][i]);
+    out[i] = __float2half(s);
+}
+}  // namespace
+
+// In-process stand-in for the RCCL communicator (tests): the ranks of one tensor-parallel group are runner models driven
+// by threads of ONE process on one GPU; an all-reduce is two host barriers around a device-side sum.  It validates the
+// runner's sharded forward (column-parallel qkv / gate_up, row-parallel o / down, kv heads split) end to end where only
+// one GPU exists; production uses ferrum_hip_model_tp_init (RCCL over xGMI).
+struct FerrumHipTpLoopback {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    long generation = 0;
+    const __half* bufs[8] = {};
+    const __half** bufs_dev = nullptr;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const long gen = generation;
+        if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+
+namespace {
+int loopback_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
+    FerrumHipTpLoopback* lb = m->tp_loopback;
+    if (m->tp_tmp_elems < count) {
+        if (m->tp_tmp) (void)hipFree(m->tp_tmp);
+        FH_CHECK_HIP(hipMalloc((void**)&m->tp_tmp, count * 2));
+        m->tp_tmp_elems = count;
+    }
+    FH_CHECK_HIP(hipStreamSynchronize(m->stream));             // this rank's partial is complete
+    { std::lock_guard<std::mutex> lk(lb->mu); lb->bufs[m->cfg.tp_rank] = buf; }
+    lb->barrier();                                             // every partial is complete and published
+    if (m->cfg.tp_rank == 0)
+        FH_CHECK_HIP(hipMemcpy((void*)lb->bufs_dev, lb->bufs, sizeof(void*) * lb->world, hipMemcpyHostToDevice));
+    lb->barrier();
+    hipLaunchKernelGGL(loopback_sum_kernel, dim3(cdiv((long)count, 256)), dim3(256), 0, m->stream, lb->bufs_dev, lb->world, m->tp_tmp,
+                       (long)count);
+    FH_CHECK_LAUNCH();
+    FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    lb->barrier();                                             // everyone has read every partial
+    FH_CHECK_HIP(hipMemcpyAsync(buf, m->tp_tmp, count * 2, hipMemcpyDeviceToDevice, m->stream));
+    return 0;
+}
+
 int tp_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
     if (m->cfg.tp_world <= 1) return 0;
+    if (m->tp_loopback) return loopback_all_reduce(m, buf, count);
     FH_REQUIRE(m->nccl_comm && g_all_reduce, "tensor parallel: communicator not initialised (ferrum_hip_model_tp_init)");
     // ncclFloat16 = 6, ncclSum = 0 (rccl.h); in-place fp16 sum like nccl_comm.rs all_reduce_in_place
     int rc = g_all_reduce(buf, buf, count, 6, 0, m->nccl_comm, m->stream);
@@ -1238,6 +1295,24 @@ int ferrum_hip_tp_selftest(int count) {
     (void)hipFree(dev);
     FH_REQUIRE(rc == 0, "tp_selftest: ncclAllReduce failed: %d", rc);
     FH_REQUIRE(memcmp(host.data(), back.data(), (size_t)count * 2) == 0, "tp_selftest: 1-rank all-reduce changed the data");
+    return 0;
+}
+
+int ferrum_hip_tp_loopback_create(FerrumHipTpLoopback** out, int world) {
+    FH_REQUIRE(out && world >= 2 && world <= 8, "tp_loopback_create: world=%d", world);
+    auto* lb = new FerrumHipTpLoopback();
+    lb->world = world;
+    if (hipMalloc((void**)&lb->bufs_dev, sizeof(void*) * 8) != hipSuccess) { delete lb; fh::set_error("tp_loopback_create: hipMalloc"); return 1; }
+    *out = lb;
+    return 0;
+}
+int ferrum_hip_tp_loopback_destroy(FerrumHipTpLoopback* lb) {
+    if (lb) { (void)hipFree((void*)lb->bufs_dev); delete lb; }
+    return 0;
+}
+int ferrum_hip_model_tp_attach_loopback(FerrumHipModel* m, FerrumHipTpLoopback* lb) {
+    FH_REQUIRE(m && lb && m->cfg.tp_world == lb->world && m->cfg.tp_rank < lb->world, "tp_attach_loopback: world mismatch");
+    m->tp_loopback = lb;
     return 0;
 }
 

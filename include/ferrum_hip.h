@@ -439,6 +439,13 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* model, int which, int n_seqs, i
                                  float* avg_us, int* moe_blocks);
 /* Tensor parallel: 128-byte RCCL unique id created on rank 0 and broadcast by the host. */
 int ferrum_hip_tp_unique_id(uint8_t id[128]);
+/* In-process stand-in for the communicator (tests, one GPU): the ranks of a tensor-parallel group are runner models driven
+ * by threads of one process; each all-reduce is two host barriers around a device-side rank-ordered sum.  Validates the
+ * sharded forward end to end without a second GPU. */
+typedef struct FerrumHipTpLoopback FerrumHipTpLoopback;
+int ferrum_hip_tp_loopback_create(FerrumHipTpLoopback** lb, int world);
+int ferrum_hip_tp_loopback_destroy(FerrumHipTpLoopback* lb);
+int ferrum_hip_model_tp_attach_loopback(FerrumHipModel* model, FerrumHipTpLoopback* lb);
 /* 1-rank RCCL round trip on the current device (fp16 sum all-reduce, in place): checks the dlopen'ed entry points, enum values
  * and by-value ncclUniqueId passing of the tensor-parallel path without needing a second GPU. */
 int ferrum_hip_tp_selftest(int count);

@@ -332,6 +332,87 @@ def test_decode_steps_graph_on_windowed_models(pkg, kind):
                 assert int(np.argmax(lg)) == seq[s + 1], (kind, i, s)
 
 
+def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg):
+    """TP=2 of the runner, end to end on one GPU: two rank models (per-rank config, Megatron-style GPTQ shards from tp.py:
+    column-parallel qkv / gate_up, row-parallel o / down, kv heads split) run on two threads and meet in an in-process
+    all-reduce after o_proj and down_proj (tp_decode.rs:363-366).  Both ranks must produce identical logits, equal to the
+    unsharded model's within fp16 tolerance (TP=n vs TP=1, ids equal)."""
+    import ctypes as C
+    import os
+    import threading
+    import __graft_entry__ as ge
+    from tests import modelgen
+    spec = ge.importlib.util.spec_from_file_location("fh_tp", os.path.join(os.path.dirname(pkg.__file__), "tp.py"))
+    tp = ge.importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tp)
+    nq, nkv, hd, H, I, world = 8, 4, 128, 256, 512, 2
+    tm = modelgen.TinyModel(False, layers=3, hidden=H, nq=nq, nkv=nkv, hd=hd, inter=I, seed=111)
+    full = tm.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    qd, kvd = nq * hd, nkv * hd
+    lib = pkg.load_library()
+    lb = C.c_void_p()
+    assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
+    ranks = []
+    for r in range(world):
+        cfg = dict(tm.cfg, num_heads=nq // world, num_kv_heads=nkv // world, intermediate=I // world, tp_rank=r, tp_world=world)
+        m = pkg.HipModel(group_size=128, kv_num_blocks=16, max_seqs=4, max_tokens=64, **cfg)
+        for name, data in tm.glob.items():
+            m.set_global(name, data)
+        for li, L in enumerate(tm.layers):
+            for name, data in L["dense"].items():
+                m.set_layer_dense(li, name, data)
+            k, n, qw, sc, qz = L["gptq"]["qkv"]
+            s = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [qd, kvd, kvd], r, world)
+            m.set_gptq(li, "qkv", *s, k, s[0].shape[1])
+            k, n, qw, sc, qz = L["gptq"]["o"]
+            s = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
+            m.set_gptq(li, "o", *s, k // world, n)
+            k, n, qw, sc, qz = L["gptq"]["gate_up"]
+            s = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [I, I], r, world)
+            m.set_gptq(li, "gate_up", *s, k, s[0].shape[1])
+            k, n, qw, sc, qz = L["gptq"]["down"]
+            s = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
+            m.set_gptq(li, "down", *s, k // world, n)
+        m.finalize()
+        assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
+        ranks.append(m)
+    rng = np.random.default_rng(112)
+    prompt = rng.integers(0, tm.cfg["vocab"], size=19).astype(np.uint32)
+    results = [None] * world
+    errors = []
+
+    def run(r):
+        try:
+            out = []
+            toks, lg = ranks[r].unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
+            out.append((int(toks[0]), lg[0].copy()))
+            for s in range(3):
+                toks, lg = ranks[r].unified_forward([(1, [out[-1][0]], len(prompt) + s, True)], greedy=True, want_logits=True)
+                out.append((int(toks[0]), lg[0].copy()))
+            results[r] = out
+        except Exception as e:      # a rank that dies would leave the other in the barrier: surface it
+            errors.append(e)
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    [t_.start() for t_ in th]
+    [t_.join(timeout=120) for t_ in th]
+    assert not errors, errors
+    assert all(r is not None for r in results), "a rank did not finish"
+    ref = []
+    toks, lg = full.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
+    ref.append((int(toks[0]), lg[0].copy()))
+    for s in range(3):
+        toks, lg = full.unified_forward([(1, [ref[-1][0]], len(prompt) + s, True)], greedy=True, want_logits=True)
+        ref.append((int(toks[0]), lg[0].copy()))
+    for s in range(4):
+        assert np.array_equal(results[0][s][1], results[1][s][1])               # ranks agree bit for bit
+        assert results[0][s][0] == ref[s][0]                                     # ids equal to TP=1
+        assert modelgen.cosine(ref[s][1], results[0][s][1]) > 0.99999
+        assert np.max(np.abs(ref[s][1] - results[0][s][1])) < 5e-3 * np.max(np.abs(ref[s][1]))
+    del ranks
+    lib.ferrum_hip_tp_loopback_destroy(lb)
+
+
 def test_rccl_plumbing_selftest(pkg):
     """The tensor-parallel path needs ≥ 2 GPUs; what can be checked on one is that the RCCL entry points resolve and a
     1-rank fp16 sum all-reduce on a stream is the identity."""
