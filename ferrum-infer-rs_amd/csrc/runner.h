@@ -102,6 +102,8 @@ struct FerrumHipModel {
     int graph_n = 0, graph_max_kv = 0;
 
     // tensor parallel (RCCL, resolved lazily by dlopen)
+    uint8_t* greedy_opts_dev = nullptr;    // token mask + sparse repetition-penalty arrays of the current forward
+    size_t greedy_opts_bytes = 0;
     void* nccl_comm = nullptr;
     struct FerrumHipTpLoopback* tp_loopback = nullptr;   // in-process test stand-in for the communicator
     __half* tp_tmp = nullptr;

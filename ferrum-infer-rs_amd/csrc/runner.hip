@@ -324,7 +324,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
                     (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
-                    (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch})
+                    (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch, (void*)m->greedy_opts_dev, (void*)m->tp_tmp})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -800,7 +800,11 @@ int dense_linear(FerrumHipModel* m, const W4Device& w, const __half* x, __half* 
 }
 
 // Enqueue every kernel of one forward on m->stream.  Index tensors are already on the device.
-int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
+struct GreedyDeviceOpts {          // device pointers, already uploaded on m->stream
+    const uint8_t* mask = nullptr; int mask_len = 0;
+    const uint32_t* row_offsets = nullptr; const uint32_t* token_ids = nullptr; const float* penalties = nullptr;
+};
+int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const GreedyDeviceOpts* gopts = nullptr) {
     const FerrumHipModelConfig& c = m->cfg;
     hipStream_t s = m->stream;
     const int T = sh.m_total, H = c.hidden, nq = c.num_heads, nkv = c.num_kv_heads, hd = c.head_dim;
@@ -1018,7 +1022,15 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy) {
         }
         RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, c.vocab, H, m->workspace,
                              m->workspace_bytes, s));
-        if (greedy) RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, nullptr, 0, sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, s));
+        if (greedy) {
+            // LogitsReturnPolicy::GreedyArgmax { token_mask, repetition_penalty } (model_executor.rs:109-150): the sparse
+            // penalty rewrites the listed logits in place, then raw or masked argmax (traits.rs:1571-1591)
+            if (gopts && gopts->row_offsets)
+                RUN(apply_repetition_penalties_sparse_f32(m->logits, gopts->row_offsets, gopts->token_ids, gopts->penalties,
+                                                          sh.num_sampled, c.vocab, s));
+            RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, gopts ? gopts->mask : nullptr, gopts ? gopts->mask_len : 0,
+                                   sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, s));
+        }
     }
 #undef RUN
     return 0;
@@ -1030,6 +1042,11 @@ extern "C" {
 
 int ferrum_hip_model_unified_forward(FerrumHipModel* m, const FerrumHipBatchItem* items, int num_items, int greedy,
                                      uint32_t* out_tokens, float* logits_out) {
+    return ferrum_hip_model_unified_forward_ex(m, items, num_items, greedy, nullptr, out_tokens, logits_out);
+}
+
+int ferrum_hip_model_unified_forward_ex(FerrumHipModel* m, const FerrumHipBatchItem* items, int num_items, int greedy,
+                                        const FerrumHipGreedyOptions* opts, uint32_t* out_tokens, float* logits_out) {
     FH_REQUIRE(m && m->finalized, "unified_forward: model not finalized");
     if (num_items <= 0) return 0;
     FH_REQUIRE(items, "unified_forward: null items");
@@ -1085,7 +1102,44 @@ int ferrum_hip_model_unified_forward(FerrumHipModel* m, const FerrumHipBatchItem
     // only the used prefix of the block-table region needs to travel
     size_t used = m->il.block_tables + (size_t)num_items * m->max_blocks_per_seq * 4;
     FH_CHECK_HIP(hipMemcpyAsync(m->idx_dev, m->idx_host, used, hipMemcpyHostToDevice, m->stream));
-    if (int rc = enqueue_forward(m, sh, greedy != 0)) return rc;
+    GreedyDeviceOpts g{};
+    if (greedy && opts && sh.num_sampled > 0) {
+        // device copies of the greedy options live in a growable side buffer: [mask | row_offsets | token_ids | penalties]
+        size_t total_ids = 0;
+        if (opts->penalty_row_offsets) {
+            FH_REQUIRE(opts->penalty_token_ids && opts->penalties, "unified_forward: incomplete repetition-penalty arrays");
+            FH_REQUIRE(opts->penalty_row_offsets[0] == 0, "unified_forward: penalty_row_offsets must start at 0");
+            for (int i = 0; i < sh.num_sampled; i++)
+                FH_REQUIRE(opts->penalty_row_offsets[i + 1] >= opts->penalty_row_offsets[i], "unified_forward: penalty_row_offsets not monotone");
+            total_ids = opts->penalty_row_offsets[sh.num_sampled];
+        }
+        const size_t mask_bytes = opts->valid_token_mask ? ((size_t)opts->mask_len + 15) / 16 * 16 : 0;
+        const size_t off_ro = mask_bytes, off_ids = off_ro + ((size_t)sh.num_sampled + 1 + 3) / 4 * 16;
+        const size_t off_pen = off_ids + (total_ids + 3) / 4 * 16, need = off_pen + ((size_t)sh.num_sampled + 3) / 4 * 16;
+        if (m->greedy_opts_bytes < need) {
+            if (m->greedy_opts_dev) (void)hipFree(m->greedy_opts_dev);
+            m->greedy_opts_dev = nullptr;
+            FH_CHECK_HIP(hipMalloc((void**)&m->greedy_opts_dev, need));
+            m->greedy_opts_bytes = need;
+        }
+        uint8_t* base = m->greedy_opts_dev;
+        if (opts->valid_token_mask) {
+            FH_REQUIRE(opts->mask_len > 0, "unified_forward: mask_len=%d", opts->mask_len);
+            FH_CHECK_HIP(hipMemcpyAsync(base, opts->valid_token_mask, (size_t)opts->mask_len, hipMemcpyHostToDevice, m->stream));
+            g.mask = base;
+            g.mask_len = opts->mask_len;
+        }
+        if (opts->penalty_row_offsets) {
+            FH_CHECK_HIP(hipMemcpyAsync(base + off_ro, opts->penalty_row_offsets, ((size_t)sh.num_sampled + 1) * 4, hipMemcpyHostToDevice, m->stream));
+            if (total_ids)
+                FH_CHECK_HIP(hipMemcpyAsync(base + off_ids, opts->penalty_token_ids, total_ids * 4, hipMemcpyHostToDevice, m->stream));
+            FH_CHECK_HIP(hipMemcpyAsync(base + off_pen, opts->penalties, (size_t)sh.num_sampled * 4, hipMemcpyHostToDevice, m->stream));
+            g.row_offsets = reinterpret_cast<const uint32_t*>(base + off_ro);
+            g.token_ids = reinterpret_cast<const uint32_t*>(base + off_ids);
+            g.penalties = reinterpret_cast<const float*>(base + off_pen);
+        }
+    }
+    if (int rc = enqueue_forward(m, sh, greedy != 0, &g)) return rc;
     if (sh.num_sampled > 0) {
         if (greedy && out_tokens)
             FH_CHECK_HIP(hipMemcpyAsync(out_tokens, m->out_tokens, (size_t)sh.num_sampled * 4, hipMemcpyDeviceToHost, m->stream));

@@ -29,6 +29,13 @@ class BatchItem(C.Structure):
                 ("pos_offset", C.c_int32), ("is_final_chunk", C.c_int32), ("_pad", C.c_int32)]
 
 
+class GreedyOptions(C.Structure):
+    """LogitsReturnPolicy::GreedyArgmax { token_mask, repetition_penalty } for one batch (model_executor.rs:109-150)."""
+    _fields_ = [("valid_token_mask", C.POINTER(C.c_uint8)), ("mask_len", C.c_int32), ("_pad", C.c_int32),
+                ("penalty_row_offsets", C.POINTER(C.c_uint32)), ("penalty_token_ids", C.POINTER(C.c_uint32)),
+                ("penalties", C.POINTER(C.c_float))]
+
+
 class KvSlotRequest(C.Structure):
     _fields_ = [("seq_id", C.c_uint64), ("target_len", C.c_int32), ("_pad", C.c_int32)]
 
@@ -233,9 +240,10 @@ class HipModel:
         return out
 
     # ── forward ──────────────────────────────────────────────────────────────
-    def unified_forward(self, items, greedy=True, want_logits=False):
+    def unified_forward(self, items, greedy=True, want_logits=False, token_mask=None, repetition_penalties=None):
         """items: [(seq_id, tokens, pos_offset, is_final_chunk)].  Returns (tokens|None, logits|None) for the
-        final-chunk items in order."""
+        final-chunk items in order.  token_mask: uint8 [mask_len] shared by all rows; repetition_penalties: per sampled
+        row (penalty, [de-duplicated token ids]) — the GreedyArgmax policy of the reference, applied on the device."""
         keep = [np.ascontiguousarray(t, dtype=np.uint32) for _, t, _, _ in items]
         arr = (BatchItem * len(items))()
         n_final = 0
@@ -244,8 +252,28 @@ class HipModel:
             n_final += int(bool(fin))
         toks = np.zeros(max(n_final, 1), np.uint32)
         logits = np.zeros((max(n_final, 1), self.cfg.vocab), np.float32) if want_logits else None
-        _check(self.lib.ferrum_hip_model_unified_forward(
-            self.h, arr, len(items), int(greedy), toks.ctypes.data_as(C.POINTER(C.c_uint32)),
+        opts, hold = None, []
+        if token_mask is not None or repetition_penalties is not None:
+            opts = GreedyOptions()
+            if token_mask is not None:
+                mk = np.ascontiguousarray(token_mask, np.uint8)
+                hold.append(mk)
+                opts.valid_token_mask, opts.mask_len = mk.ctypes.data_as(C.POINTER(C.c_uint8)), len(mk)
+            if repetition_penalties is not None:
+                assert len(repetition_penalties) == n_final
+                ro = np.zeros(n_final + 1, np.uint32)
+                ro[1:] = np.cumsum([len(ids) for _, ids in repetition_penalties])
+                ids = np.ascontiguousarray(np.concatenate([np.asarray(i_, np.uint32) for _, i_ in repetition_penalties] + [np.zeros(0, np.uint32)]), np.uint32)
+                if ids.size == 0:
+                    ids = np.zeros(1, np.uint32)
+                pen = np.ascontiguousarray([p for p, _ in repetition_penalties], np.float32)
+                hold += [ro, ids, pen]
+                opts.penalty_row_offsets = ro.ctypes.data_as(C.POINTER(C.c_uint32))
+                opts.penalty_token_ids = ids.ctypes.data_as(C.POINTER(C.c_uint32))
+                opts.penalties = pen.ctypes.data_as(C.POINTER(C.c_float))
+        _check(self.lib.ferrum_hip_model_unified_forward_ex(
+            self.h, arr, len(items), int(greedy), None if opts is None else C.byref(opts),
+            toks.ctypes.data_as(C.POINTER(C.c_uint32)),
             None if logits is None else logits.ctypes.data_as(C.POINTER(C.c_float))), "unified_forward")
         return (toks[:n_final] if greedy else None), (logits[:n_final] if logits is not None else None)
 

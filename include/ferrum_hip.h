@@ -423,6 +423,22 @@ int ferrum_hip_model_read_kv_f32(FerrumHipModel* model, uint64_t seq_id, int lay
  * returns FERRUM_HIP_INVALID if the pool is exhausted. */
 int ferrum_hip_model_unified_forward(FerrumHipModel* model, const FerrumHipBatchItem* items, int num_items,
                                      int greedy, uint32_t* out_tokens, float* logits_out);
+/* LogitsReturnPolicy::GreedyArgmax { token_mask, repetition_penalty } (model_executor.rs:109-150) for the whole batch, host
+ * pointers: valid_token_mask[mask_len] (0 = forbidden; ids ≥ mask_len forbidden; NULL = none) is shared by every sampled row
+ * like the reference's single device mask (llama_family_forward_batched.rs:2392-2410); the sparse repetition penalty follows
+ * argmax_rows_f16_sparse_repetition_penalty (traits.rs:1571-1591): sampled row r owns penalty_token_ids[penalty_row_offsets[r]
+ * .. penalty_row_offsets[r+1]) (de-duplicated by the caller) and penalties[r]; logit v → v / p if v > 0 else v · p.
+ * NULL arrays = no penalty.  Logits returned through logits_out are the penalised ones. */
+typedef struct {
+    const uint8_t* valid_token_mask;
+    int32_t mask_len;
+    int32_t _pad;
+    const uint32_t* penalty_row_offsets;   /* [num_sampled + 1] */
+    const uint32_t* penalty_token_ids;
+    const float* penalties;                /* [num_sampled] */
+} FerrumHipGreedyOptions;
+int ferrum_hip_model_unified_forward_ex(FerrumHipModel* model, const FerrumHipBatchItem* items, int num_items, int greedy,
+                                        const FerrumHipGreedyOptions* opts, uint32_t* out_tokens, float* logits_out);
 /* Steady-state decode: every listed sequence advances by one token (its last sampled token),
  * `steps` times, with device-side greedy sampling and hipGraph replay when available.
  * out_tokens [steps, n] (may be NULL). */

@@ -413,6 +413,43 @@ def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg):
     lib.ferrum_hip_tp_loopback_destroy(lb)
 
 
+def test_greedy_policy_with_token_mask_and_repetition_penalty(pkg):
+    """LogitsReturnPolicy::GreedyArgmax { token_mask, repetition_penalty } inside the unified forward (model_executor.rs:109-150;
+    device ops traits.rs:1534-1591): the picked ids equal the oracle sampler chain — sparse repetition penalty over the
+    de-duplicated ids (sampler.rs:327-345), forbidden ids masked, first maximum — applied to the runner's own raw logits."""
+    from tests import modelgen
+    from oracle import oracle as O
+    tm = modelgen.TinyModel(True, layers=2, seed=121)
+    hm = tm.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    rng = np.random.default_rng(122)
+    V = tm.cfg["vocab"]
+    prompts = [rng.integers(0, V, size=n).astype(np.uint32) for n in (11, 5, 20)]
+    _, raw = hm.unified_forward([(10 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    for i in range(3):
+        hm.release(10 + i)
+    mask = np.ones(V - 7, np.uint8)                              # ids ≥ mask_len are invalid
+    pens = []
+    for i, p in enumerate(prompts):
+        top = np.argsort(-raw[i])[:3]
+        mask[top[0]] = 0 if i == 0 else mask[top[0]]             # forbid row 0's raw winner
+        ids = np.unique(np.concatenate([p, top[:2] if i == 1 else top[:0]])).astype(np.uint32)   # row 1: penalise its top-2
+        pens.append((1.0 if i == 2 else 1.8, ids))               # row 2: penalty 1.0 = untouched
+    toks, lg = hm.unified_forward([(20 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True,
+                                  token_mask=mask, repetition_penalties=pens)
+    for i in range(3):
+        ref = raw[i].copy()
+        pen, ids = pens[i]
+        if pen != 1.0:
+            ref[ids] = np.where(ref[ids] > 0, ref[ids] / np.float32(pen), ref[ids] * np.float32(pen))
+        assert np.array_equal(lg[i], ref)                        # penalised logits come back bit-exact
+        masked = ref.copy()
+        masked[len(mask):] = -np.inf
+        masked[:len(mask)][mask == 0] = -np.inf
+        assert int(toks[i]) == int(O.argmax_rows(masked[None])[0])
+    assert int(toks[0]) != int(np.argmax(raw[0]))                # the mask changed row 0's pick
+    assert int(toks[2]) == int(np.argmax(raw[2])) or mask[int(np.argmax(raw[2]))] == 0
+
+
 def test_rccl_plumbing_selftest(pkg):
     """The tensor-parallel path needs ≥ 2 GPUs; what can be checked on one is that the RCCL entry points resolve and a
     1-rank fp16 sum all-reduce on a stream is the identity."""
