@@ -588,14 +588,15 @@ int ferrum_hip_checkpoint_model_config(const FerrumHipCheckpoint* ck, int max_se
     memset(cfg, 0, sizeof(*cfg));
     const std::string arch = architecture(ck);
     if (arch_out && arch_cap) snprintf(arch_out, arch_cap, "%s", arch.c_str());
-    enum { Llama, Qwen3, Qwen3Moe, Mistral, Gemma3 } fam;
+    enum { Llama, Qwen3, Qwen3Moe, Mistral, Gemma3, Qwen2 } fam;
     if (arch == "LlamaForCausalLM" || arch == "llama") fam = Llama;
     else if (arch == "Gemma3ForCausalLM" || arch == "Gemma3ForConditionalGeneration" || arch == "gemma3_text" || arch == "gemma3") fam = Gemma3;
     else if (arch == "Qwen3ForCausalLM" || arch == "qwen3") fam = Qwen3;
+    else if (arch == "Qwen2ForCausalLM" || arch == "qwen2") fam = Qwen2;      // structurally Llama + q/k/v biases, θ default 1e6
     else if (arch == "Qwen3MoeForCausalLM" || arch == "qwen3_moe") fam = Qwen3Moe;
     else if (arch == "MistralForCausalLM" || arch == "mistral") fam = Mistral;
     else {
-        set_error("checkpoint: architecture '%s' is not supported by the HIP runner (Llama, Mistral, Qwen3, Qwen3-MoE, Gemma-3)", arch.c_str());
+        set_error("checkpoint: architecture '%s' is not supported by the HIP runner (Llama, Mistral, Qwen2, Qwen3, Qwen3-MoE, Gemma-3)", arch.c_str());
         return FERRUM_HIP_UNSUPPORTED;
     }
     auto u = [&](const char* key, const char* alt, double dflt) {
@@ -732,8 +733,26 @@ int ferrum_hip_model_load_checkpoint(FerrumHipModel* model, const FerrumHipCheck
             if (int rc = dense_layer(2, "self_attn.q_norm.weight", (float)q_scale)) return rc;
             if (int rc = dense_layer(3, "self_attn.k_norm.weight", 1.0f)) return rc;
         }
-        FH_REQUIRE(!find(ck, p + "self_attn.q_proj.bias") && !find(ck, p + "self_attn.qkv_proj.bias"),
-                   "model_load_checkpoint: attention biases are not supported by the runner (layer %d)", li);
+        // cat_optional_biases (native_safetensors.rs:246-290): q|k|v biases are all-or-none and concatenate like the weights
+        {
+            const std::vector<std::string> bparts = find(ck, p + "self_attn.qkv_proj.bias")
+                ? std::vector<std::string>{p + "self_attn.qkv_proj.bias"}
+                : std::vector<std::string>{p + "self_attn.q_proj.bias", p + "self_attn.k_proj.bias", p + "self_attn.v_proj.bias"};
+            int present = 0;
+            for (const std::string& b : bparts) present += find(ck, b) != nullptr;
+            FH_REQUIRE(present == 0 || present == (int)bparts.size(),
+                       "dense fusion bias mix in layer %d: some of q/k/v carry a bias and others do not", li);
+            if (present) {
+                std::vector<float> fused, part;
+                for (const std::string& b : bparts) {
+                    if (int rc = read_f32(ck, b, part, nullptr)) return rc;
+                    fused.insert(fused.end(), part.begin(), part.end());
+                }
+                FH_REQUIRE((int)fused.size() == (c.num_heads + 2 * c.num_kv_heads) * c.head_dim,
+                           "dense fusion bias length %zu != qkv width (layer %d)", fused.size(), li);
+                if (int rc = ferrum_hip_model_set_layer_dense_f32(model, li, 7, fused.data())) return rc;
+            }
+        }
         if (int rc = gptq(li, 0, 0, linear_parts(ck, p + "self_attn.", "qkv_proj", {"q_proj", "k_proj", "v_proj"}))) return rc;
         if (int rc = gptq(li, 1, 0, {p + "self_attn.o_proj"})) return rc;
         if (c.num_experts > 0) {

@@ -20,6 +20,7 @@ struct LayerWeights {
     __half* router = nullptr;      // [E, H] fp16
     __half* post_attn_ln = nullptr;   // sandwich norms (Gemma 3); post_ln is then the pre-MLP norm
     __half* post_ffn_ln = nullptr;
+    __half* qkv_bias = nullptr;       // staged until finalize (then owned by qkv.bias)
     W4Device qkv, o, gate_up, down;
     W4Device exp_gate_up, exp_down;   // stacked experts
     std::vector<uint8_t> exp_loaded;   // per expert: bit0 gate_up, bit1 down

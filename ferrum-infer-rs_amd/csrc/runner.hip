@@ -312,7 +312,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
     if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
     if (m->graph) (void)hipGraphDestroy(m->graph);
     for (auto& L : m->layers) {
-        for (__half* p : {L.input_ln, L.post_ln, L.q_norm, L.k_norm, L.router, L.k_pool, L.v_pool, L.post_attn_ln, L.post_ffn_ln})
+        for (__half* p : {L.input_ln, L.post_ln, L.q_norm, L.k_norm, L.router, L.k_pool, L.v_pool, L.post_attn_ln, L.post_ffn_ln, L.qkv_bias})
             if (p) (void)hipFree(p);
         free_w4(L.qkv); free_w4(L.o); free_w4(L.gate_up); free_w4(L.down); free_w4(L.exp_gate_up); free_w4(L.exp_down);
     }
@@ -355,6 +355,8 @@ int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* m, int layer, int which
     case 4:
         FH_REQUIRE(m->cfg.num_experts > 0, "model_set_layer_dense: router on a dense model");
         return upload_f32_as_f16(data, (size_t)m->cfg.num_experts * m->cfg.hidden, &L.router);
+    case 7:   // fused q|k|v projection bias (Qwen2 family, gptq.rs:56): attached to the qkv GEMM at finalize
+        return upload_f32_as_f16(data, (size_t)qkv_dim(m->cfg), &L.qkv_bias);
     case 5: return upload_f32_as_f16(data, m->cfg.hidden, &L.post_attn_ln);
     case 6: return upload_f32_as_f16(data, m->cfg.hidden, &L.post_ffn_ln);
     }
@@ -487,6 +489,10 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         FH_REQUIRE(L.input_ln && L.post_ln && L.qkv.qw && L.o.qw, "model_finalize: layer %d attention weights missing", li);
         FH_REQUIRE(!c.has_qk_norm || (L.q_norm && L.k_norm), "model_finalize: layer %d q/k norm missing", li);
         FH_REQUIRE(!c.sandwich_norms || (L.post_attn_ln && L.post_ffn_ln), "model_finalize: layer %d sandwich norms missing", li);
+        if (m->layers[li].qkv_bias) {    // the GEMM epilogue / split-K reduce adds it (W4Device::bias owns it from here)
+            m->layers[li].qkv.bias = m->layers[li].qkv_bias;
+            m->layers[li].qkv_bias = nullptr;
+        }
         if (c.num_experts > 0) {
             FH_REQUIRE(L.router && L.exp_gate_up.qw && L.exp_down.qw, "model_finalize: layer %d MoE weights missing", li);
             for (int e = 0; e < c.num_experts; e++)

@@ -50,7 +50,8 @@ _DEFAULTS = dict(max_seq_len=512, has_qk_norm=0, activation=0, num_experts=0, to
                  max_seqs=32, max_tokens=512, rms_eps=1e-6, rope_theta=1e6, intermediate=0, tp_rank=0, tp_world=1)
 
 GLOBAL = {"embed": 0, "lm_head": 1, "final_norm": 2}
-LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4, "post_attn_ln": 5, "post_ffn_ln": 6}
+LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4, "post_attn_ln": 5, "post_ffn_ln": 6,
+               "qkv_bias": 7}
 GPTQ = {"qkv": 0, "o": 1, "gate_up": 2, "down": 3, "expert_gate_up": 4, "expert_down": 5}
 
 

@@ -347,7 +347,8 @@ int ferrum_hip_model_destroy(FerrumHipModel* model);
 /* Weight hand-over (host slices, copied/repacked to device).  which:
  *   global dense: 0 embed [V,H], 1 lm_head [V,H] (omit → tied to embed), 2 final_norm [H]
  *   layer dense : 0 input_ln [H], 1 post_ln [H] (sandwich: pre_feedforward_layernorm), 2 q_norm [hd], 3 k_norm [hd],
- *                 4 router [E,H], 5 post_attn_ln [H], 6 post_ffn_ln [H] (sandwich norms)
+ *                 4 router [E,H], 5 post_attn_ln [H], 6 post_ffn_ln [H] (sandwich norms),
+ *                 7 qkv_bias [nq·hd + 2·nkv·hd] (fused q|k|v projection bias, Qwen2 family)
  *   gptq        : 0 qkv, 1 o, 2 gate_up, 3 down, 4 expert gate_up, 5 expert down               */
 int ferrum_hip_model_set_global_f32(FerrumHipModel* model, int which, const float* data);
 int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* model, int layer, int which, const float* data);
@@ -378,7 +379,7 @@ int ferrum_hip_model_prefix_cache_stats(const FerrumHipModel* model, uint64_t* h
  *    canonicalised to 0x77777777 (:1242-1246) and g_idx validation (:1288-1324), quantize_config.json or config.json
  *    "quantization_config" (:1475-1530), config.json mapping (ferrum-models/src/definition.rs:225-375,
  *    models/llama_family.rs:596-680,733-810, moe_config.rs:91-130), tensor names (llama_family.rs:900-945,
- *    qwen3_moe/load.rs:178-260).  Architectures: Llama, Mistral, Qwen3, Qwen3-MoE, Gemma-3 (norm folds of
+ *    qwen3_moe/load.rs:178-260).  Architectures: Llama, Mistral, Qwen2 (fused q|k|v bias), Qwen3, Qwen3-MoE, Gemma-3 (norm folds of
  *    llama_family.rs:891-967 applied at load); others → FERRUM_HIP_UNSUPPORTED. ── */
 typedef struct FerrumHipCheckpoint FerrumHipCheckpoint;
 int ferrum_hip_checkpoint_open(FerrumHipCheckpoint** ck, const char* model_dir);

@@ -78,6 +78,7 @@ typedef struct {
 typedef struct {
     float *input_ln, *post_ln, *q_norm, *k_norm;
     float *post_attn_ln, *post_ffn_ln;   /* sandwich norms (Gemma 3); post_ln is then pre_feedforward_layernorm */
+    float *qkv_bias;                     /* [qkv_dim] fused projection bias (Qwen2 family) or NULL */
     float *qkv_w, *o_w;          /* [n,k] f32 */
     float *gate_up_w, *down_w;   /* dense MLP */
     float *router_w;             /* [E,H] */
@@ -138,7 +139,7 @@ FO_API void fo_model_free(fo_model *m) {
     for (int l = 0; l < m->cfg.num_layers; l++) {
         fo_layer *L = &m->layers[l];
         free(L->input_ln); free(L->post_ln); free(L->q_norm); free(L->k_norm);
-        free(L->post_attn_ln); free(L->post_ffn_ln);
+        free(L->post_attn_ln); free(L->post_ffn_ln); free(L->qkv_bias);
         free(L->qkv_w); free(L->o_w); free(L->gate_up_w); free(L->down_w);
         free(L->router_w); free(L->exp_gate_up_w); free(L->exp_down_w);
     }
@@ -157,7 +158,8 @@ FO_API void fo_model_set_global(fo_model *m, int which, const float *data) {
 }
 
 /* which: 0 input_ln [H], 1 post_ln [H] (sandwich: pre_feedforward_layernorm), 2 q_norm [hd], 3 k_norm [hd], 4 router [E,H],
- *        5 post_attn_ln [H], 6 post_ffn_ln [H] (sandwich norms) */
+ *        5 post_attn_ln [H], 6 post_ffn_ln [H] (sandwich norms), 7 qkv_bias [qkv_dim] (GptqLinear bias, gptq.rs:56,
+ *        added like Backend::add_bias, cpu.rs:2065-2078) */
 FO_API void fo_model_set_layer_dense(fo_model *m, int layer, int which, const float *data) {
     fo_layer *L = &m->layers[layer];
     int H = m->cfg.hidden, hd = m->cfg.head_dim;
@@ -169,6 +171,8 @@ FO_API void fo_model_set_layer_dense(fo_model *m, int layer, int which, const fl
     case 4: free(L->router_w); L->router_w = fo_dup(data, (long)m->cfg.num_experts * H); break;
     case 5: free(L->post_attn_ln); L->post_attn_ln = fo_dup(data, H); break;
     case 6: free(L->post_ffn_ln); L->post_ffn_ln = fo_dup(data, H); break;
+    case 7: free(L->qkv_bias);
+        L->qkv_bias = fo_dup(data, (long)(m->cfg.num_heads + 2 * m->cfg.num_kv_heads) * hd); break;
     }
 }
 
@@ -319,6 +323,9 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
 
         fo_rms_norm(residual, L->input_ln, g->rms_eps, norm_out, T, H);
         fo_gemm(norm_out, L->qkv_w, qkv, T, qkv_dim, H);
+        if (L->qkv_bias)
+            for (long t = 0; t < T; t++)
+                for (int j = 0; j < qkv_dim; j++) qkv[t * qkv_dim + j] += L->qkv_bias[j];
         /* kv_layer.rs:437-495 unfused contig_write chain */
         fo_split_qkv(qkv, q_buf, k_buf, v_buf, T, q_dim, kv_dim);
         fo_qk_norm_rope(q_buf, qn, cos_l, sin_l, q_hm, T, nh, hd, pos_offset, g->rms_eps, qk_mode);

@@ -476,7 +476,8 @@ class OracleModel:
     """CPU restatement of LlamaFamilyModel<CpuBackend> / Qwen3-MoE (see ferrum_oracle_model.c)."""
 
     GLOBAL = {"embed": 0, "lm_head": 1, "final_norm": 2}
-    LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4, "post_attn_ln": 5, "post_ffn_ln": 6}
+    LAYER_DENSE = {"input_ln": 0, "post_ln": 1, "q_norm": 2, "k_norm": 3, "router": 4, "post_attn_ln": 5, "post_ffn_ln": 6,
+                   "qkv_bias": 7}
     GPTQ = {"qkv": 0, "o": 1, "gate_up": 2, "down": 3, "expert_gate_up": 4, "expert_down": 5}
 
     def __init__(self, **kw):

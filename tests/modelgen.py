@@ -28,7 +28,8 @@ class TinyModel:
     def __init__(self, moe, layers=2, hidden=256, nq=4, nkv=2, hd=128, inter=256, vocab=512, experts=8, top_k=2,
                  expert_inter=128, qk_norm=True, seed=0, max_seq_len=256, activation=0, sliding_window=0,
                  rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False, sandwich=False,
-                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False):
+                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False,
+                 qkv_bias=False):
         self.cfg = dict(num_layers=layers, hidden=hidden, num_heads=nq, num_kv_heads=nkv, head_dim=hd,
                         intermediate=0 if moe else inter, vocab=vocab, max_seq_len=max_seq_len, has_qk_norm=int(qk_norm),
                         activation=activation, num_experts=experts if moe else 0, top_k=top_k if moe else 0,
@@ -48,6 +49,8 @@ class TinyModel:
         for li in range(layers):
             L = {"dense": {"input_ln": f16r(1.0 + 0.1 * rng.standard_normal(H)),
                            "post_ln": f16r(1.0 + 0.1 * rng.standard_normal(H))}, "gptq": {}, "experts": {}}
+            if qkv_bias:
+                L["dense"]["qkv_bias"] = f16r(0.5 * rng.standard_normal(qd + 2 * kvd))
             if sandwich:
                 L["dense"]["post_attn_ln"] = f16r(1.0 + 0.1 * rng.standard_normal(H))
                 L["dense"]["post_ffn_ln"] = f16r(1.0 + 0.1 * rng.standard_normal(H))
@@ -154,6 +157,10 @@ def write_checkpoint(tm, out_dir, arch, shards=1, fused_names=False, dense_dtype
     for li, L in enumerate(tm.layers):
         p = f"model.layers.{li}."
         for key, a in L["dense"].items():
+            if key == "qkv_bias":      # q|k|v biases, split like the weights
+                for stem, lo, hi in (("q_proj", 0, nq * hd), ("k_proj", nq * hd, (nq + nkv) * hd), ("v_proj", (nq + nkv) * hd, (nq + 2 * nkv) * hd)):
+                    dense(p + f"self_attn.{stem}.bias", a[lo:hi])
+                continue
             dense(p + names[key], a)
         k, n, qw, sc, qz = L["gptq"]["qkv"]
         if fused_names:

@@ -147,6 +147,7 @@ def test_g_idx_validation_cases(pkg, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("moe,arch,kw", [(True, "Qwen3MoeForCausalLM", {}),
+                                         (False, "Qwen2ForCausalLM", dict(qk_norm=False, qkv_bias=True)),
                                          (False, "LlamaForCausalLM", dict(qk_norm=False, rope_theta=500000.0, rope_scaling_kind=2,
                                                                           rope_p=(8.0, 1.0, 4.0, 64.0), tied=True))])
 def test_model_loaded_from_checkpoint_equals_direct_load(pkg, tmp_path, moe, arch, kw):

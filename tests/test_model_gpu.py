@@ -73,6 +73,15 @@ def test_unusual_model_shapes(pkg, kw):
     _assert_parity(res)
 
 
+@pytest.mark.parametrize("prompt_len", [9, 23, 70])
+def test_qkv_bias_model(pkg, prompt_len):
+    """Qwen2-family attention: fused q|k|v projection bias (gptq.rs:56, add_bias cpu.rs:2065) through every GEMM row regime."""
+    from tests import modelgen
+    res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=prompt_len, decode_steps=3, seed=131 + prompt_len,
+                                   qk_norm=False, qkv_bias=True)
+    _assert_parity(res)
+
+
 def test_gelu_activation_model(pkg):
     from tests import modelgen
     res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=9, decode_steps=2, seed=6, activation=1)
