@@ -270,6 +270,31 @@ int ferrum_hip_apply_repetition_penalties_sparse_f32(float* logits, const uint32
                                                      const uint32_t* token_ids, const float* penalties, int m,
                                                      int n, void* stream);
 
+/* ── host-side sampling chain (callers that take FullLogits): the C++ mirror of the reference's logits processors and
+ *    samplers (ferrum-interfaces/src/sampler.rs:186-467), operating on host f32 logits in place.  Order of
+ *    ferrum_hip_sampler_sample = the reference's priorities: repetition penalty (High), top-k, top-p (Normal), temperature
+ *    (Low — last), then GreedySampler (LAST maximum, `max_by`; the device argmax keeps the FIRST, traits.rs:1547) or
+ *    MultinomialSampler (threshold = random_u32 / u32::MAX in f32, first index whose running f32 sum reaches it). ── */
+typedef struct {
+    float temperature;            /* ≤ 0 or 1 → untouched */
+    int32_t top_k;                /* ≤ 0 → off */
+    float top_p;                  /* outside (0,1) → off */
+    float repetition_penalty;     /* 1 → off */
+    const uint32_t* previous_tokens;
+    int32_t num_previous_tokens;
+    int32_t greedy;               /* 1 → GreedySampler, 0 → MultinomialSampler */
+    uint32_t random_u32;          /* RngCore::next_u32() of the caller's generator */
+    uint32_t _pad;
+} FerrumHipSamplingParams;
+int ferrum_hip_sampler_apply_temperature(float* logits, int n, float temperature);
+int ferrum_hip_sampler_apply_top_k(float* logits, int n, int k);
+int ferrum_hip_sampler_apply_top_p(float* logits, int n, float p);
+int ferrum_hip_sampler_apply_repetition_penalty(float* logits, int n, const uint32_t* previous_tokens, int num_previous,
+                                                float penalty);
+int ferrum_hip_sampler_greedy(const float* logits, int n, uint32_t* token);
+int ferrum_hip_sampler_multinomial(const float* logits, int n, uint32_t random_u32, uint32_t* token);
+int ferrum_hip_sampler_sample(float* logits, int n, const FerrumHipSamplingParams* params, uint32_t* token);
+
 /* ── host-side KV block bookkeeping: BlockAllocator (ferrum-models/src/common/paged_pool.rs:106-365).
  *    Pure host code; reproduces block ids bit-exactly (ids from 0, LIFO, prefer-unhashed). ─────── */
 typedef struct FerrumHipBlockAllocator FerrumHipBlockAllocator;

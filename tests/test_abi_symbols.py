@@ -159,3 +159,50 @@ def test_native_operator_manifest_matches_the_binary(pkg, tmp_path):
     visible = set(line.split()[-1] for line in out.splitlines())
     assert "ferrum_native_op_init" in m["exports"] and "ferrum_native_op_descriptor" in m["exports"]
     assert all(e in visible for e in m["exports"])
+
+
+def test_host_sampler_chain_matches_restatement(pkg, oracle):
+    """sampler.rs:186-467 through the product's C ABI vs the independent restatement, bit for bit, on random logits with
+    ties, -inf entries, repeated previous tokens and the edge parameters (k ≥ n, p outside (0,1), penalty 1, T ≤ 0)."""
+    lib = pkg.load_library()
+    fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+
+    class Params(C.Structure):
+        _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float), ("repetition_penalty", C.c_float),
+                    ("previous_tokens", up), ("num_previous_tokens", C.c_int32), ("greedy", C.c_int32),
+                    ("random_u32", C.c_uint32), ("_pad", C.c_uint32)]
+    rng = np.random.default_rng(17)
+    for trial in range(60):
+        n = int(rng.choice([5, 64, 1000, 4096]))
+        logits = (rng.standard_normal(n) * 3).astype(np.float32)
+        logits[rng.integers(0, n, size=max(1, n // 10))] = np.float32(1.5)        # ties
+        if trial % 4 == 0:
+            logits[rng.integers(0, n, size=n // 3)] = -np.inf
+        prev = rng.integers(0, n + 3, size=int(rng.integers(0, 40))).astype(np.uint32)   # duplicates and out-of-range ids
+        temp = float(rng.choice([0.0, 1.0, 0.7, 1.3]))
+        k = int(rng.choice([0, 1, 5, n // 2, n, n + 7]))
+        p = float(rng.choice([0.0, 0.3, 0.9, 1.0, 1.5]))
+        pen = float(rng.choice([1.0, 1.2, 0.8]))
+        u = int(rng.integers(0, 2**32 - 1))
+        # reference order: penalty, top-k, top-p, temperature (lowest priority), then the sampler
+        ref = oracle.repetition_penalty(logits, prev, pen)
+        ref = oracle.top_k(ref, k) if k > 0 else ref
+        ref = oracle.top_p(ref, p)
+        ref = oracle.temperature(ref, temp)
+        for greedy in (1, 0):
+            work = logits.copy()
+            prm = Params(temp, k, p, pen, prev.ctypes.data_as(up), len(prev), greedy, u, 0)
+            tok = C.c_uint32()
+            rc = lib.ferrum_hip_sampler_sample(work.ctypes.data_as(fp), n, C.byref(prm), C.byref(tok))
+            assert np.array_equal(work, ref, equal_nan=True), trial
+            if greedy:
+                assert rc == 0 and tok.value == oracle.greedy_sample(ref)
+            elif np.isfinite(ref).any():
+                assert rc == 0 and tok.value == oracle.multinomial(ref, u), trial
+            else:
+                assert rc != 0                                                   # "No valid tokens for sampling"
+    # greedy = last maximum, device-style argmax = first (both reference behaviours)
+    tie = np.array([1.0, 7.0, 7.0, 3.0], np.float32)
+    tok = C.c_uint32()
+    assert lib.ferrum_hip_sampler_greedy(tie.ctypes.data_as(fp), 4, C.byref(tok)) == 0 and tok.value == 2
+    assert int(oracle.argmax_rows(tie[None])[0]) == 1
