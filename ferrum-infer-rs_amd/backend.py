@@ -267,6 +267,48 @@ class HipBackend:
     def supports_varlen_qkv():
         return True
 
+    # ── contiguous-KV lane (kv_layer.rs:370-513) ──────────────────────────────
+    @staticmethod
+    def split_qkv(ctx, qkv, q, k, v, tokens, q_dim, kv_dim):
+        _check(ctx.lib.ferrum_hip_split_qkv_f16(_ptr(qkv), _ptr(q), _ptr(k), _ptr(v), tokens, q_dim, kv_dim, ctx.stream), "split_qkv")
+
+    @staticmethod
+    def qk_norm_rope(ctx, inp, norm_w, cos, sin, out, tokens, heads, head_dim, pos_offset, eps, mode):
+        _check(ctx.lib.ferrum_hip_qk_norm_rope_f16(_ptr(inp), _ptr(norm_w), _ptr(cos), _ptr(sin), _ptr(out), tokens, heads,
+                                                   head_dim, pos_offset, C.c_float(eps), mode, ctx.stream), "qk_norm_rope")
+
+    @staticmethod
+    def kv_cache_append_head_major(ctx, cache_k, cache_v, cache_len, capacity, new_k, new_v, new_tokens, nkv, hd):
+        _check(ctx.lib.ferrum_hip_kv_cache_append_head_major_f16(_ptr(cache_k), _ptr(cache_v), cache_len, capacity, _ptr(new_k),
+                                                                 _ptr(new_v), new_tokens, nkv, hd, ctx.stream),
+               "kv_cache_append_head_major")
+
+    @staticmethod
+    def transpose_head_to_token(ctx, src, dst, tokens, heads, dim):
+        _check(ctx.lib.ferrum_hip_transpose_head_to_token_f16(_ptr(src), _ptr(dst), tokens, heads, dim, ctx.stream), "transpose_head_to_token")
+
+    @staticmethod
+    def transpose_token_to_head(ctx, src, dst, tokens, heads, dim):
+        _check(ctx.lib.ferrum_hip_transpose_token_to_head_f16(_ptr(src), _ptr(dst), tokens, heads, dim, ctx.stream), "transpose_token_to_head")
+
+    @staticmethod
+    def copy_slice(ctx, src, src_offset, dst, dst_offset, length):
+        _check(ctx.lib.ferrum_hip_copy_slice_f16(_ptr(src), C.c_size_t(src_offset), _ptr(dst), C.c_size_t(dst_offset),
+                                                 C.c_size_t(length), ctx.stream), "copy_slice")
+
+    @staticmethod
+    def scaled_add_inplace(ctx, dst, src, scale, length):
+        _check(ctx.lib.ferrum_hip_scaled_add_inplace_f16(_ptr(dst), _ptr(src), C.c_float(scale), C.c_size_t(length), ctx.stream),
+               "scaled_add_inplace")
+
+    @staticmethod
+    def flash_attention(ctx, q, k, v, out, batch, q_len, kv_len, pos_offset, num_heads, num_kv_heads, head_dim, causal=True,
+                        scale=None, kv_seq_stride=0, sliding_window=0):
+        sc = (1.0 / head_dim ** 0.5) if scale is None else scale
+        _check(ctx.lib.ferrum_hip_flash_attention_f16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), batch, q_len, kv_len, pos_offset,
+                                                      num_heads, num_kv_heads, head_dim, int(causal), C.c_float(sc), kv_seq_stride,
+                                                      sliding_window, ctx.stream), "flash_attention")
+
     @staticmethod
     def alloc_paged_pool(num_blocks, kv_heads, head_dim, device="cuda"):
         """Zero-initialised pool in the native tile layout (csrc/kv_layout.h)."""

@@ -351,6 +351,50 @@ int ferrum_hip_rms_norm_f32_to_f16(const float* x_f32, const int32_t* row_idx, c
     return rms_norm_f32_to_f16(x_f32, row_idx, CH(w), eps, H(out_f16), n_rows, dim, ST(stream));
 }
 
+// ── contiguous-KV lane of the core trait ─────────────────────────────────────
+int ferrum_hip_split_qkv_f16(const void* qkv, void* q, void* k, void* v, int tokens, int q_dim, int kv_dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (qkv && q && k && v), "split_qkv: null buffer");
+    return split_qkv_f16(CH(qkv), H(q), H(k), H(v), tokens, q_dim, kv_dim, ST(stream));
+}
+int ferrum_hip_qk_norm_rope_f16(const void* input, const void* norm_w, const float* cos_tab, const float* sin_tab, void* output,
+                                int tokens, int heads, int head_dim, int pos_offset, float eps, int mode, void* stream) {
+    FH_REQUIRE(tokens == 0 || (input && output), "qk_norm_rope: null buffer");
+    FH_REQUIRE(mode == 0 || (cos_tab && sin_tab), "qk_norm_rope: rope tables missing");
+    FH_REQUIRE(mode != 1 || norm_w, "qk_norm_rope: norm weights missing for mode 1");
+    return qk_norm_rope_f16(CH(input), CH(norm_w), cos_tab, sin_tab, H(output), tokens, heads, head_dim, pos_offset, eps, mode,
+                            ST(stream));
+}
+int ferrum_hip_kv_cache_append_head_major_f16(void* cache_k, void* cache_v, int cache_len, int cache_capacity, const void* new_k,
+                                              const void* new_v, int new_tokens, int nkv, int head_dim, void* stream) {
+    FH_REQUIRE(new_tokens == 0 || (cache_k && cache_v && new_k && new_v), "kv_cache_append_head_major: null buffer");
+    return kv_cache_append_head_major_f16(H(cache_k), H(cache_v), cache_len, cache_capacity, CH(new_k), CH(new_v), new_tokens, nkv,
+                                          head_dim, ST(stream));
+}
+int ferrum_hip_transpose_head_to_token_f16(const void* src, void* dst, int tokens, int heads, int dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (src && dst), "transpose_head_to_token: null buffer");
+    return transpose_head_to_token_f16(CH(src), H(dst), tokens, heads, dim, ST(stream));
+}
+int ferrum_hip_transpose_token_to_head_f16(const void* src, void* dst, int tokens, int heads, int dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (src && dst), "transpose_token_to_head: null buffer");
+    return transpose_token_to_head_f16(CH(src), H(dst), tokens, heads, dim, ST(stream));
+}
+int ferrum_hip_copy_slice_f16(const void* src, size_t src_offset, void* dst, size_t dst_offset, size_t len, void* stream) {
+    FH_REQUIRE(len == 0 || (src && dst), "copy_slice: null buffer");
+    return copy_slice_f16(CH(src), (long)src_offset, H(dst), (long)dst_offset, (long)len, ST(stream));
+}
+int ferrum_hip_scaled_add_inplace_f16(void* dst, const void* src, float scale, size_t len, void* stream) {
+    FH_REQUIRE(len == 0 || (src && dst), "scaled_add_inplace: null buffer");
+    return scaled_add_inplace_f16(H(dst), CH(src), scale, (long)len, ST(stream));
+}
+int ferrum_hip_flash_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int q_len, int kv_len,
+                                   int pos_offset, int num_heads, int num_kv_heads, int head_dim, int causal, float scale,
+                                   int kv_seq_stride, int sliding_window, void* stream) {
+    FH_REQUIRE(q && k && v && out, "flash_attention: null buffer");
+    if (batch != 1) { fh::set_error("flash_attention: batch=%d (the reference's CPU and decode paths use batch 1)", batch); return FERRUM_HIP_UNSUPPORTED; }
+    return flash_attention_contig_f16(CH(q), CH(k), CH(v), H(out), q_len, kv_len, causal, pos_offset, num_heads, num_kv_heads, head_dim,
+                                      scale, kv_seq_stride, sliding_window, ST(stream));
+}
+
 // ── paged KV ────────────────────────────────────────────────────────────────
 size_t ferrum_hip_paged_pool_bytes(int num_blocks, int kv_heads, int head_dim) {
     return (size_t)num_blocks * kv_heads * 16 * head_dim * 2;

@@ -83,6 +83,19 @@ int fused_gated_act_slabs_f16(const float* slabs, int S, long slab_stride, int l
                               hipStream_t s);
 int rms_norm_f32_to_f16(const float* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int n_rows, int dim,
                         hipStream_t s);
+// contiguous-KV lane (contig_ops.hip)
+int split_qkv_f16(const __half* qkv, __half* q, __half* k, __half* v, int tokens, int q_dim, int kv_dim, hipStream_t s);
+int qk_norm_rope_f16(const __half* input, const __half* norm_w, const float* cos_t, const float* sin_t, __half* output,
+                     int tokens, int heads, int head_dim, int pos_offset, float eps, int mode, hipStream_t s);
+int kv_cache_append_head_major_f16(__half* cache_k, __half* cache_v, int cache_len, int cache_capacity, const __half* new_k,
+                                   const __half* new_v, int new_tokens, int nkv, int hd, hipStream_t s);
+int transpose_head_to_token_f16(const __half* src, __half* dst, int tokens, int heads, int dim, hipStream_t s);
+int transpose_token_to_head_f16(const __half* src, __half* dst, int tokens, int heads, int dim, hipStream_t s);
+int copy_slice_f16(const __half* src, long src_offset, __half* dst, long dst_offset, long len, hipStream_t s);
+int scaled_add_inplace_f16(__half* dst, const __half* src, float scale, long len, hipStream_t s);
+int flash_attention_contig_f16(const __half* q, const __half* k, const __half* v, __half* out, int q_len, int kv_len, int causal,
+                               int pos_offset, int num_heads, int num_kv_heads, int head_dim, float scale, int kv_seq_stride,
+                               int sliding_window, hipStream_t s);
 int scale_inplace_f16(__half* buf, float scale, long len, hipStream_t s);
 int add_bias_f16(__half* data, const __half* bias, int rows, int cols, hipStream_t s);
 int gather_columns_f16(const __half* in, const int32_t* perm, __half* out, int rows, int cols, hipStream_t s);

@@ -148,6 +148,27 @@ int ferrum_hip_sandwich_add_rms_norm_f32(const void* branch_f16, const void* w_b
 int ferrum_hip_rms_norm_f32_to_f16(const float* x_f32, const int32_t* row_idx, const void* w, float eps, void* out_f16,
                                    int n_rows, int dim, void* stream);
 
+/* ── contiguous-KV lane of the core `Backend` trait (the non-paged path, kv_layer.rs:370-513): split_qkv (traits.rs:850) →
+ *    qk_norm_rope (traits.rs:897; token-major [T,heads,hd] → head-major [heads,T,hd]; mode 0 transpose only, 1 per-head
+ *    RMSNorm + half-split RoPE, 2 half-split RoPE, 3 interleaved RoPE; position = pos_offset + token) →
+ *    kv_cache_append_head_major (traits.rs:1266; cache [nkv, capacity, hd]) → flash_attention (traits.rs:225 with AttnConfig
+ *    {num_heads, num_kv_heads, head_dim, causal, scale, kv_seq_stride, sliding_window}; q/out [nq, q_len, hd]; batch must be 1;
+ *    attends keys [max(0, end − window), end) with end = min(pos_offset + i + 1, kv_len) when causal, cpu.rs:2179-2259) →
+ *    transpose_head_to_token (traits.rs:1281).  copy_slice (traits.rs:798) and scaled_add_inplace (traits.rs:1318) complete
+ *    the set.  Simple bandwidth-shaped kernels — the paged lane below is the fast path. ── */
+int ferrum_hip_split_qkv_f16(const void* qkv, void* q, void* k, void* v, int tokens, int q_dim, int kv_dim, void* stream);
+int ferrum_hip_qk_norm_rope_f16(const void* input, const void* norm_w, const float* cos_tab, const float* sin_tab, void* output,
+                                int tokens, int heads, int head_dim, int pos_offset, float eps, int mode, void* stream);
+int ferrum_hip_kv_cache_append_head_major_f16(void* cache_k, void* cache_v, int cache_len, int cache_capacity, const void* new_k,
+                                              const void* new_v, int new_tokens, int nkv, int head_dim, void* stream);
+int ferrum_hip_transpose_head_to_token_f16(const void* src, void* dst, int tokens, int heads, int dim, void* stream);
+int ferrum_hip_transpose_token_to_head_f16(const void* src, void* dst, int tokens, int heads, int dim, void* stream);
+int ferrum_hip_copy_slice_f16(const void* src, size_t src_offset, void* dst, size_t dst_offset, size_t len, void* stream);
+int ferrum_hip_scaled_add_inplace_f16(void* dst, const void* src, float scale, size_t len, void* stream);
+int ferrum_hip_flash_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int q_len, int kv_len,
+                                   int pos_offset, int num_heads, int num_kv_heads, int head_dim, int causal, float scale,
+                                   int kv_seq_stride, int sliding_window, void* stream);
+
 /* ── paged KV: BackendPagedKv (traits.rs:1622-1904).  Block tables and block ids are the
  *    reference's (ferrum-models/src/common/paged_pool.rs); the bytes inside a block use the native
  *    MFMA-shaped tile layout (csrc/kv_layout.h).  Pools: [num_blocks][kv_heads][16·head_dim] fp16,

@@ -253,6 +253,75 @@ def test_split_qkv_norm_rope_into_paged_cache_varlen(env, qk_mode, hd):
         assert bool(pool[blk].any()) == (blk in written)
 
 
+# ── contiguous-KV lane of the core trait (kv_layer.rs:370-513) ────────────────
+@pytest.mark.parametrize("nq,nkv,hd,mode,window", [(8, 2, 128, 1, 0), (4, 4, 64, 2, 0), (6, 2, 128, 3, 5), (2, 1, 256, 1, 3)])
+def test_contiguous_lane_prefill_then_decode(env, nq, nkv, hd, mode, window):
+    """split_qkv → qk_norm_rope (→ head-major) → kv_cache_append_head_major → flash_attention → transpose_head_to_token,
+    op by op against the CPU restatement (cpu.rs:1645-1783,1993-2060,2179-2259), for a 9-token prefill followed by a decode
+    token at position 9; plus copy_slice / scaled_add_inplace / transpose_token_to_head."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(nq * 7 + hd + mode)
+    cap = 32
+    cos, sin = _rope(O, hd, cap)
+    cosd, sind = torch.from_numpy(cos).cuda(), torch.from_numpy(sin).cuda()
+    qn, kn = f16r(1 + 0.1 * rng.standard_normal(hd)), f16r(1 + 0.1 * rng.standard_normal(hd))
+    q_dim, kv_dim = nq * hd, nkv * hd
+    ck = torch.zeros(nkv, cap, hd, dtype=torch.float16, device="cuda")
+    cv = torch.zeros_like(ck)
+    ck_ref, cv_ref = np.zeros((nkv, cap, hd), np.float32), np.zeros((nkv, cap, hd), np.float32)
+    cache_len = 0
+    for T in (9, 1):
+        qkv = f16r(rng.standard_normal((T, q_dim + 2 * kv_dim)))
+        qd, kd, vd = (torch.empty(T, n, dtype=torch.float16, device="cuda") for n in (q_dim, kv_dim, kv_dim))
+        B.split_qkv(ctx, dev16(torch, qkv), qd, kd, vd, T, q_dim, kv_dim)
+        ctx.sync()
+        q, k, v = O.split_qkv(qkv, q_dim, kv_dim)
+        assert np.array_equal(host(qd), q) and np.array_equal(host(kd), k) and np.array_equal(host(vd), v)
+        qh = torch.empty(nq, T, hd, dtype=torch.float16, device="cuda")
+        kh = torch.empty(nkv, T, hd, dtype=torch.float16, device="cuda")
+        vh = torch.empty(nkv, T, hd, dtype=torch.float16, device="cuda")
+        B.qk_norm_rope(ctx, qd, dev16(torch, qn), cosd, sind, qh, T, nq, hd, cache_len, 1e-6, mode)
+        B.qk_norm_rope(ctx, kd, dev16(torch, kn), cosd, sind, kh, T, nkv, hd, cache_len, 1e-6, mode)
+        B.qk_norm_rope(ctx, vd, dev16(torch, kn), cosd, sind, vh, T, nkv, hd, cache_len, 1e-6, 0)
+        ctx.sync()
+        q_ref = O.qk_norm_rope(q.reshape(T, nq, hd), qn, cos, sin, T, nq, hd, cache_len, 1e-6, mode)
+        k_ref = O.qk_norm_rope(k.reshape(T, nkv, hd), kn, cos, sin, T, nkv, hd, cache_len, 1e-6, mode)
+        v_ref = O.qk_norm_rope(v.reshape(T, nkv, hd), kn, cos, sin, T, nkv, hd, cache_len, 1e-6, 0)
+        assert nmse(q_ref, host(qh)) < NMSE_FP16_TOL and nmse(k_ref, host(kh)) < NMSE_FP16_TOL
+        assert np.array_equal(host(vh), v_ref)                                   # mode 0 = transpose only
+        B.kv_cache_append_head_major(ctx, ck, cv, cache_len, cap, kh, vh, T, nkv, hd)
+        ck_ref[:, cache_len:cache_len + T] = host(kh)
+        cv_ref[:, cache_len:cache_len + T] = host(vh)
+        kv_len = cache_len + T
+        out = torch.full((nq, T, hd), 3.0, dtype=torch.float16, device="cuda")
+        B.flash_attention(ctx, qh, ck, cv, out, 1, T, kv_len, cache_len, nq, nkv, hd, causal=True, kv_seq_stride=cap,
+                          sliding_window=window)
+        ctx.sync()
+        assert np.array_equal(host(ck), ck_ref) and np.array_equal(host(cv), cv_ref)
+        a_ref = O.cpu_attention(host(qh), ck_ref, cv_ref, T, kv_len, True, cache_len, nq, nkv, hd, sliding_window=window,
+                                kv_seq_stride=cap)
+        assert nmse(a_ref, host(out)) < 1e-5
+        tm_ = torch.empty(T, nq, hd, dtype=torch.float16, device="cuda")
+        B.transpose_head_to_token(ctx, out, tm_, T, nq, hd)
+        back = torch.empty_like(out)
+        B.transpose_token_to_head(ctx, tm_, back, T, nq, hd)
+        ctx.sync()
+        assert np.array_equal(host(tm_), host(out).transpose(1, 0, 2)) and torch.equal(back, out)
+        cache_len = kv_len
+    a = dev16(torch, rng.standard_normal(1000))
+    b = dev16(torch, rng.standard_normal(1000))
+    ref = host(a).copy()
+    ref[100:400] = f16r(ref[100:400] + np.float32(0.37) * host(b)[5:305])
+    B.scaled_add_inplace(ctx, a[100:], b[5:], 0.37, 300)
+    c = torch.zeros(64, dtype=torch.float16, device="cuda")
+    B.copy_slice(ctx, b, 17, c, 3, 40)
+    ctx.sync()
+    assert np.array_equal(host(a), ref)
+    exp = np.zeros(64, np.float32)
+    exp[3:43] = host(b)[17:57]
+    assert np.array_equal(host(c), exp)
+
+
 # ── paged attention ──────────────────────────────────────────────────────────
 def _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks):
     """Write per-sequence K/V [len,nkv,hd] into native pools through the product's own writer (mode 0)."""
