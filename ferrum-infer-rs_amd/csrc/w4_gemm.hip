@@ -167,9 +167,9 @@ __device__ __forceinline__ half8 splat_half8(float v) {
 // One quant group (128 k) of NT column tiles × MT row tiles.
 //   wq[nt]  : the lane's 4 packed dwords of tile nt          af[mt][s] : activation fragments, k-steps 0..3
 //   acc     : fp32 accumulators                              sbits/zbits: 4 packed fp16 scales / zeros
-// Nibble expansion costs 5 VALU per dword (1 shift + 4 v_and_or): a lo nibble masked in place is the exact
-// fp16 1024+q, a hi nibble is 1024+16q.  The hi k-steps use activations pre-multiplied by 1/16 (exact in
-// fp16), so  Σ_lo (1024+q)x + Σ_hi (1024+16q)(x/16) = Σ q·x + 1024·S_lo + 64·S_hi.  The offset (and the
+// Nibble expansion costs 5 VALU per dword (1 shift + 4 v_and_or): a lo nibble masked in place under 0x6400 is the
+// exact fp16 1024+q, a hi nibble (mantissa bits 4-7) under 0x5400 is the exact fp16 64+q, so
+//   Σ_lo (1024+q)x + Σ_hi (64+q)x = Σ q·x + 1024·S_lo + 64·S_hi.  The offset (and the
 // zero point: −zero·(S_lo+S_hi)) is removed with NO per-weight work: four extra MFMAs per group against a
 // constant B operand produce −(1024+zero)·S_lo − (64+zero)·S_hi per token row, and that is used as the
 // starting accumulator of every tile's MFMA chain.  The group scale multiplies the fp32 chain result.
@@ -177,9 +177,8 @@ template <int MT, int NT, bool HAS_ZP, bool ILV = true, typename WQ>
 __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned long long sbits,
                                                  unsigned long long zbits, int nt0, half8 (&af)[MT][4],
                                                  float4v (&acc)[MT][NT]) {
-    const uint32_t magic = opaque_vgpr(0x64006400u);
+    const uint32_t magic = opaque_vgpr(0x64006400u), magic_hi = opaque_vgpr(0x54005400u);
     const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
-    const half8 sixteenth = splat_half8(0.0625f);
     auto half_at = [](unsigned long long bits, int i) {
         union { uint16_t u; _Float16 h; } c;
         c.u = (uint16_t)(bits >> (16 * i));
@@ -188,18 +187,16 @@ __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned lo
     float4v neg_off[MT], s_sum[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
-        af[mt][1] = af[mt][1] * sixteenth;
-        af[mt][3] = af[mt][3] * sixteenth;
-        // symmetric: −1032·S_lo − 72·S_hi  (72·16 = 1152 against x/16);  asymmetric: −1024·S_lo − 64·S_hi
-        const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -1024.0f : -1152.0f);
+        // symmetric: −1032·S_lo − 72·S_hi;  asymmetric: −1024·S_lo − 64·S_hi
+        const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -64.0f : -72.0f);
         float4v t = {0.f, 0.f, 0.f, 0.f};
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0], b_lo, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][1], b_hi, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2], b_lo, t, 0, 0, 0);
         t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][3], b_hi, t, 0, 0, 0);
         neg_off[mt] = t;
-        if (HAS_ZP) {   // Σ x over the group (hi k-steps hold x/16 → ×16)
-            const half8 o_lo = splat_half8(1.0f), o_hi = splat_half8(16.0f);
+        if (HAS_ZP) {   // Σ x over the group
+            const half8 o_lo = splat_half8(1.0f), o_hi = o_lo;
             float4v u = {0.f, 0.f, 0.f, 0.f};
             u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][0], o_lo, u, 0, 0, 0);
             u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][1], o_hi, u, 0, 0, 0);
@@ -224,8 +221,8 @@ __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned lo
                 const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
                 const half8 lo = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic),
                                             and_or(d1s, m_lo, magic));
-                const half8 hi = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic),
-                                            and_or(d1s, m_hi, magic));
+                const half8 hi = pack_half8(and_or(d0, m_hi, magic_hi), and_or(d0s, m_hi, magic_hi), and_or(d1, m_hi, magic_hi),
+                                            and_or(d1s, m_hi, magic_hi));
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
                     t1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt][2 * pr], lo, t1[mt], 0, 0, 0);
@@ -257,7 +254,7 @@ __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned lo
             const uint32_t d0 = wq[nt][2 * pr], d1 = wq[nt][2 * pr + 1];
             const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
             lo[nt] = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic), and_or(d1s, m_lo, magic));
-            hi[nt] = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic), and_or(d1s, m_hi, magic));
+            hi[nt] = pack_half8(and_or(d0, m_hi, magic_hi), and_or(d0s, m_hi, magic_hi), and_or(d1, m_hi, magic_hi), and_or(d1s, m_hi, magic_hi));
         }
 #pragma unroll
         for (int nt = 0; nt < NT; nt++)
@@ -925,16 +922,17 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
         }
 }
 
-// ── prefill GEMM: 64-row tiles, activations through LDS, 4 waves × 64 columns ───────────────────────────────────
-// For M ≥ 64 (prefill chunks; MoE blocks of 64 sorted pairs) the skinny kernels re-fetch their A fragments from L2 for
-// every 64-column supertile and spend half their time on it.  Here a workgroup owns 64 rows × 256 columns: every 128-k
-// group's 64×128 activation tile is gathered once (dense rows, or MoE pair rows through sorted_token_ids) into a
-// double-buffered fragment-major LDS tile, each wave streams the INT4 group of ITS 64-column supertile straight to
-// registers, expands it once and runs it against all four 16-row tiles (80 MFMAs per 4 KiB of weights instead of 20).
-// MODE 0 dense (+bias), 1 MoE plain, 2 MoE gate_up with the fused silu·mul epilogue.  Same arithmetic as
-// w4_consume_group (exact integer-valued products, fp32 scale), restructured k-pair-major to hold 250 VGPRs.
+// ── MoE prefill grouped GEMM: 64-row tiles, activations through LDS, 4 waves × 64 columns ──────────────────────
+// For blocks of 64 sorted pairs the skinny kernels re-fetch their A fragments from L2 for every 64-column supertile and
+// spend half their time on it.  Here a workgroup owns 64 rows × 256 columns: every 128-k group's 64×128 activation tile is
+// gathered once (pair rows through sorted_token_ids) into a double-buffered fragment-major LDS tile, each wave streams
+// the INT4 group of ITS 64-column supertile straight to registers, expands it once and runs it against all four 16-row
+// tiles (80 MFMAs per 4 KiB of weights instead of 20).  MODE 1 plain, 2 gate_up with the fused silu·mul epilogue.  Same
+// arithmetic as w4_consume_group (exact integer-valued products, fp32 scale), restructured k-pair-major to hold 250 VGPRs.
+// (The dense M ≥ 64 GEMM uses the hand-pipelined w4_gemm_tilep_kernel below.)
 template <bool HAS_ZP, int MODE>
 __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
+    static_assert(MODE == 1 || MODE == 2, "grouped-GEMM modes only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][4 mt][4 s][64] half8 = 2 × 16 KiB
     constexpr int FR = 1024;
@@ -951,14 +949,7 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     // rows of this tile: fragment loads are split by wave (k-step s = wave), so every thread needs the 4 rows
     // mt·16 + b of its lane; the epilogue needs rows mt·16 + 4a + r
     int row_in[4], row_out_l[4];
-    if (MODE == 0) {
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            const int r = rb * 64 + mt * 16 + b;
-            row_out_l[mt] = r < p.M ? r : -1;
-            row_in[mt] = r < p.M ? r : p.M - 1;
-        }
-    } else {
+    {
         const int total = *p.total_post_pad;
         if (rb * 64 >= total) return;
         const int e = p.block_ids[rb];
@@ -1004,11 +995,12 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
 #pragma unroll
         for (int mt = 0; mt < 4; mt++) lds_a[buf * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];
     };
-    const uint32_t magic = opaque_vgpr(0x64006400u);
+    // low nibbles land in mantissa bits 0-3 of 0x6400 (1024 + n), high nibbles in bits 4-7 of 0x5400 (64 + n): both
+    // expansions are integer-valued, so no operand needs rescaling (the vector issue port is what bounds this kernel)
+    const uint32_t magic = opaque_vgpr(0x64006400u), magic_hi = opaque_vgpr(0x54005400u);
     const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
-    const half8 sixteenth = splat_half8(0.0625f);
-    const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -1024.0f : -1152.0f);
-    const half8 o_lo = splat_half8(1.0f), o_hi = splat_half8(16.0f);
+    const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -64.0f : -72.0f);
+    const half8 ones = splat_half8(1.0f);
     auto half_at = [](unsigned long long bits, int i) {
         union { uint16_t u; _Float16 h; } c;
         c.u = (uint16_t)(bits >> (16 * i));
@@ -1026,7 +1018,7 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
                 const uint32_t d0 = wq[slot][nt][2 * pr], d1 = wq[slot][nt][2 * pr + 1];
                 const uint32_t d0s = d0 >> 8, d1s = d1 >> 8;
                 lo[pr][nt] = pack_half8(and_or(d0, m_lo, magic), and_or(d0s, m_lo, magic), and_or(d1, m_lo, magic), and_or(d1s, m_lo, magic));
-                hi[pr][nt] = pack_half8(and_or(d0, m_hi, magic), and_or(d0s, m_hi, magic), and_or(d1, m_hi, magic), and_or(d1s, m_hi, magic));
+                hi[pr][nt] = pack_half8(and_or(d0, m_hi, magic_hi), and_or(d0s, m_hi, magic_hi), and_or(d1, m_hi, magic_hi), and_or(d1s, m_hi, magic_hi));
             }
         const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
         const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
@@ -1034,15 +1026,12 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
         for (int mt = 0; mt < 4; mt++) {
             half8 af[4];
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                af[s] = at[(mt * 4 + s) * 64 + lane];
-                if (s & 1) af[s] = af[s] * sixteenth;
-            }
+            for (int s = 0; s < 4; s++) af[s] = at[(mt * 4 + s) * 64 + lane];
             float4v t = {0.f, 0.f, 0.f, 0.f}, u = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], (s & 1) ? b_hi : b_lo, t, 0, 0, 0);
-                if (HAS_ZP) u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], (s & 1) ? o_hi : o_lo, u, 0, 0, 0);
+                if (HAS_ZP) u = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], ones, u, 0, 0, 0);
             }
             float4v tmp[4];
 #pragma unroll
@@ -1056,19 +1045,20 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
             }
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
-                const float s_f = (float)half_at(sb, nt);
-                const float z_f = HAS_ZP ? (float)half_at(zb, nt) : 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float v = HAS_ZP ? tmp[nt][r] - z_f * u[r] : tmp[nt][r];
-                    acc[mt][nt][r] += s_f * v;
+                const float s_f = (float)half_at(sb, nt);                  // packed fp32 FMAs: two accumulators per issue slot
+                const float4v s4 = {s_f, s_f, s_f, s_f};
+                if (HAS_ZP) {
+                    const float z_f = (float)half_at(zb, nt);
+                    const float4v nz4 = {-z_f, -z_f, -z_f, -z_f};
+                    acc[mt][nt] = __builtin_elementwise_fma(s4, __builtin_elementwise_fma(nz4, u, tmp[nt]), acc[mt][nt]);
+                } else {
+                    acc[mt][nt] = __builtin_elementwise_fma(s4, tmp[nt], acc[mt][nt]);
                 }
             }
         }
     };
 #define FH_PIN() __builtin_amdgcn_sched_barrier(0)
-    const int gz0 = MODE == 0 ? (int)((long)p.G * blockIdx.z / p.S) : 0;
-    const int gz1 = MODE == 0 ? (int)((long)p.G * (blockIdx.z + 1) / p.S) : p.G;
+    const int gz0 = 0, gz1 = p.G;
     {
         const int gl = gz1 - 1;
         issue_w(0, gz0);
@@ -1098,18 +1088,6 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     }
 #undef FH_PIN
     if (!st_ok) return;
-    if (MODE == 0 && p.partial) {                    // split-K: fp32 slab, summed by the reduce launch
-        float* slab = p.partial + (long)blockIdx.z * p.rows_pad * p.n_pad;
-#pragma unroll
-        for (int mt = 0; mt < 4; mt++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = rb * 64 + mt * 16 + 4 * a + r;
-#pragma unroll
-                for (int nt = 0; nt < 4; nt++) slab[(long)row * p.n_pad + st * 64 + nt * 16 + b] = acc[mt][nt][r];
-            }
-        return;
-    }
     // epilogue: D row 4a + r of tile mt ↔ tile row mt·16 + 4a + r, whose routing lives in lane (·, b = 4a + r)
 #pragma unroll
     for (int mt = 0; mt < 4; mt++)
@@ -1131,12 +1109,254 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
                     const int col = st * 64 + nt * 16 + b;
                     if (col < p.N) {
                         float v = acc[mt][nt][r];
-                        if (MODE == 0 && p.bias) v += __half2float(p.bias[col]);
                         p.out[(long)orow * p.ldo + col] = __float2half(v);
                     }
                 }
             }
         }
+}
+
+// ── dense prefill GEMM (M ≥ 64): 64-row tiles, software-pipelined by hand ──────────────────────────────────────────
+// Same tile as the MoE kernel above (64 rows × 256 columns per workgroup, activations through a double-buffered
+// fragment-major LDS tile, each wave streaming the INT4 group of its own 64-column supertile), but every phase of a wave is
+// interleaved with its MFMA stream explicitly instead of running as separate phases (SQ_VALU_MFMA_BUSY_CYCLES of the phased
+// kernel: ≈ 45 % of wall):
+//   * a quant group is consumed as two k-halves; while the MFMAs of one half run, the OTHER half's B operands are expanded,
+//     two VALU behind each MFMA (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles);
+//   * one "step" = one 16-row tile × one k-half (2 offset + 8 product MFMAs).  The A fragments of step i+1 are read from LDS
+//     during step i; the chain result of step i−1 is folded into the accumulators (fp32 FMA with the group scale) just
+//     before step i overwrites the chain registers;
+//   * activation staging (global → registers → LDS, one group ahead) and the weight loads (two groups ahead) are issued one
+//     instruction per step; every global address is a scalar base + a 32-bit lane offset (no 64-bit address registers —
+//     a spill inside this loop costs a vmcnt(0) drain of the prefetches).
+// Same arithmetic as w4_consume_group except that the fp32 scale is applied per k-half (two roundings per group instead of
+// one).  Measured against the phased kernel (tools/exp_prefill_gemm.py): 4096→28672 at M = 8192 745 → 937 TFLOP/s,
+// 4096→6144 at M = 2048 746 → 806, 2048→5120 at M = 2048 636 → 676; M = 64…512 +3…8 %.  A 128-row variant (one wave per
+// SIMD, 128 accumulators) was tried and rejected: the fp32 fold needs the accumulators in arch VGPRs, the compiler shuttles
+// them through AGPRs (≈ 840 v_accvgpr moves per two groups) and it ran at 264–471 TFLOP/s.  The MoE modes gain nothing
+// from this schedule at K = 2048 / 768 (158.6 → 157.1 µs, 101.2 → 103.4 µs at 2048 tokens: padding and the short K bound
+// them), so the grouped GEMM keeps the phased kernel.
+template <bool HAS_ZP>
+__global__ __launch_bounds__(256, 2) void w4_gemm_tilep_kernel(W4Args p) {
+    constexpr int MTN = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][MTN mt][4 s][64] half8 = 2 × MTN·4 KiB
+    constexpr int FR = MTN * 256, ROWS = MTN * 16;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // wave-uniform: scalar bases
+    const int a = lane >> 4, b = lane & 15;
+    const int st_raw = blockIdx.x * 4 + wave;
+    const bool st_ok = st_raw < p.n64;
+    const int st = st_ok ? st_raw : p.n64 - 1;
+    const int rb = blockIdx.y;
+
+    const uint32_t* qw = p.qw;
+    const __half* sc = p.sc;
+    const __half* zp = p.zp;
+    uint32_t aoff[MTN];                                        // BYTE offset of this thread's staging rows (mt·16 + b): scalar base + 32-bit lane offset
+#pragma unroll
+    for (int mt = 0; mt < MTN; mt++) {
+        const int r = rb * ROWS + mt * 16 + b;
+        aoff[mt] = ((uint32_t)(r < p.M ? r : p.M - 1) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
+    }
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const char* qw_wave = reinterpret_cast<const char*>(qw) + ((long)st * p.G * 4) * 64 * 16;     // scalar
+    const char* sc_wave = reinterpret_cast<const char*>(sc) + ((long)st * p.G) * 16 * 8;
+    const char* zp_wave = HAS_ZP ? reinterpret_cast<const char*>(zp) + ((long)st * p.G) * 16 * 8 : nullptr;
+    const char* x_base = reinterpret_cast<const char*>(p.x);
+    const uint32_t lane16 = lane * 16, b8 = b * 8;
+
+    float4v acc[MTN][4];
+#pragma unroll
+    for (int mt = 0; mt < MTN; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    u32x4g wq[2][4];                 // raw words, groups of parity 0 / 1
+    uint2 scv[2], zpv[2];
+    half8 areg[MTN];                  // activation staging
+    u32x4g bw[2][4][2];              // expanded B operands [k-half][column tile][lo, hi]
+    half8 af[2][2];                  // A fragments of the current / next step
+    float4v tmp[4], usum[2];         // chain results: folded into acc just before the next step overwrites them
+    float sf[2][4], zf[2][4];
+
+    const uint32_t magic = opaque_vgpr(0x64006400u), magic_hi = opaque_vgpr(0x54005400u);
+    const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
+    const half8 b_lo = splat_half8(HAS_ZP ? -1024.0f : -1032.0f), b_hi = splat_half8(HAS_ZP ? -64.0f : -72.0f);
+    const half8 ones = splat_half8(1.0f);
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto half_at = [](uint2 v, int i) {
+        union { uint16_t u; _Float16 h; } c;
+        c.u = (uint16_t)((i < 2 ? v.x : v.y) >> (16 * (i & 1)));
+        return c.h;
+    };
+    const int gz0 = (int)((long)p.G * blockIdx.z / p.S), gz1 = (int)((long)p.G * (blockIdx.z + 1) / p.S);
+    const int gl = gz1 - 1;
+    auto issue_w = [&](int sl, int nt, int g) __attribute__((always_inline)) {
+        wq[sl][nt] = *reinterpret_cast<const u32x4g*>(qw_wave + ((uint32_t)g * 4096u + lane16) + nt * 1024);   // scalar base + 32-bit offset
+    };
+    auto issue_s = [&](int sl, int g) __attribute__((always_inline)) {
+        scv[sl] = *reinterpret_cast<const uint2*>(sc_wave + ((uint32_t)g * 128u + b8));
+        if (HAS_ZP) zpv[sl] = *reinterpret_cast<const uint2*>(zp_wave + ((uint32_t)g * 128u + b8));
+    };
+    auto issue_a = [&](int mt, int g) __attribute__((always_inline)) {
+        areg[mt] = *reinterpret_cast<const half8*>(x_base + (aoff[mt] + (uint32_t)g * 256u));
+    };
+    // expansion of column tile nt of k-half pr_t from words (2·pr_t, 2·pr_t + 1) of wq[sl_src][nt]: lo (6 VALU) or hi (6)
+    auto expand = [&](int pr_t, int sl_src, int nt, int part, int piece) __attribute__((always_inline)) {
+        const uint32_t d0 = wq[sl_src][nt][2 * pr_t], d1 = wq[sl_src][nt][2 * pr_t + 1];
+        const uint32_t ml = part == 0 ? m_lo : m_hi, mg = part == 0 ? magic : magic_hi;
+        u32x4g& dst = bw[pr_t][nt][part];
+        if (piece == 0) { dst[0] = and_or(d0, ml, mg); dst[1] = and_or(d0 >> 8, ml, mg); }
+        else { dst[2] = and_or(d1, ml, mg); dst[3] = and_or(d1 >> 8, ml, mg); }
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    // fold the chain result of the previous step (row tile pm, scales of group parity psl) into the accumulators
+    auto fold = [&](int pp, int pm, int psl, int nt) __attribute__((always_inline)) {   // pp: parity of usum
+        const float s_f = sf[psl][nt];
+        const float4v s4 = {s_f, s_f, s_f, s_f};
+        if (HAS_ZP) {
+            const float z_f = zf[psl][nt];
+            const float4v nz4 = {-z_f, -z_f, -z_f, -z_f};
+            acc[pm][nt] = __builtin_elementwise_fma(s4, __builtin_elementwise_fma(nz4, usum[pp], tmp[nt]), acc[pm][nt]);
+        } else {
+            acc[pm][nt] = __builtin_elementwise_fma(s4, tmp[nt], acc[pm][nt]);
+        }
+    };
+    // one step: row tile mt × k-half pr of group g (register/LDS parity sl)
+    auto step = [&](int pr, int mt, int sl, int g) __attribute__((always_inline)) {
+        const int cp = mt & 1, np = cp ^ 1;
+        const half8* at = lds_a + sl * FR;
+        // next step's A fragments (after the group's barrier when they belong to the next group)
+        if (pr == 1 && mt == MTN - 1) {
+            __syncthreads();
+            const half8* atn = lds_a + (sl ^ 1) * FR;
+            af[np][0] = atn[lane];
+            af[np][1] = atn[64 + lane];
+        } else {
+            const int nmt = (mt + 1) % MTN, npr = mt == MTN - 1 ? 1 : pr;
+            af[np][0] = at[(nmt * 4 + 2 * npr) * 64 + lane];
+            af[np][1] = at[(nmt * 4 + 2 * npr + 1) * 64 + lane];
+        }
+        if (pr == 0) {                       // activations: A(g+1) → LDS, A(g+2) requested
+            lds_a[(sl ^ 1) * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];
+            issue_a(mt, min(g + 2, gl));
+        } else if (mt < 4) {                 // weights of group g+2 into the words this group has consumed
+            issue_w(sl, mt, min(g + 2, gl));
+        }
+        if (pr == 0 && mt == 0) {            // this group's scales; their words are then free for group g+2
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                sf[sl][nt] = (float)half_at(scv[sl], nt);
+                if (HAS_ZP) zf[sl][nt] = (float)half_at(zpv[sl], nt);
+            }
+        }
+        if (pr == 0 && mt == 1) issue_s(sl, min(g + 2, gl));
+        float4v t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cp][0], b_lo, zero4, 0, 0, 0);
+        FH_PIN();
+        t = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cp][1], b_hi, t, 0, 0, 0);
+        FH_PIN();
+        if (HAS_ZP) {
+            float4v u1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cp][0], ones, zero4, 0, 0, 0);
+            usum[cp] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cp][1], ones, u1, 0, 0, 0);
+            FH_PIN();
+        }
+        const int pm = (mt + MTN - 1) % MTN, psl = (pr == 0 && mt == 0) ? (sl ^ 1) : sl;
+        const int xpr = pr ^ 1, xsl = pr == 0 ? sl : (sl ^ 1);
+        constexpr int PPS = 16 / MTN;          // expansion pieces (2 VALU each) per step
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            fold(np, pm, psl, nt);
+            tmp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cp][0], __builtin_bit_cast(half8, bw[pr][nt][0]), t, 0, 0, 0);
+            FH_PIN();
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            if (nt < PPS) { const int pc = mt * PPS + nt; expand(xpr, xsl, pc >> 2, (pc >> 1) & 1, pc & 1); }
+            tmp[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[cp][1], __builtin_bit_cast(half8, bw[pr][nt][1]), tmp[nt], 0, 0, 0);
+            FH_PIN();
+        }
+    };
+    auto group = [&](int sl, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++)
+#pragma unroll
+            for (int mt = 0; mt < MTN; mt++) step(pr, mt, sl, g);
+    };
+    // prologue: weights of the first two groups, A(gz0) staged, B operands of (gz0, k-half 0), an empty "previous step"
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) { issue_w(0, nt, gz0); issue_w(1, nt, min(gz0 + 1, gl)); }
+    issue_s(0, gz0);
+    issue_s(1, min(gz0 + 1, gl));
+#pragma unroll
+    for (int mt = 0; mt < MTN; mt++) issue_a(mt, gz0);
+#pragma unroll
+    for (int mt = 0; mt < MTN; mt++) lds_a[(mt * 4 + wave) * 64 + lane] = areg[mt];
+#pragma unroll
+    for (int mt = 0; mt < MTN; mt++) issue_a(mt, min(gz0 + 1, gl));
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) {
+        expand(0, 0, nt, 0, 0); expand(0, 0, nt, 0, 1); expand(0, 0, nt, 1, 0); expand(0, 0, nt, 1, 1);
+        tmp[nt] = zero4;
+        sf[1][nt] = 0.f;
+        zf[1][nt] = 0.f;
+    }
+    usum[1] = zero4;
+    __syncthreads();
+    af[0][0] = lds_a[lane];
+    af[0][1] = lds_a[64 + lane];
+    FH_PIN();
+    int g = gz0;
+    for (; g + 2 <= gz1; g += 2) {
+        group(0, g);
+        group(1, g + 1);
+    }
+    int lsl = 1;
+    if (g < gz1) { group(0, g); lsl = 0; }
+#undef FH_PIN
+    // the last step's chain result is still pending
+    if (lsl == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) fold(1, MTN - 1, 0, nt);
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) fold(1, MTN - 1, 1, nt);
+    }
+    if (!st_ok) return;
+    if (p.partial) {                                 // split-K: fp32 slab, summed by the reduce launch
+        float* slab = p.partial + (long)blockIdx.z * p.rows_pad * p.n_pad;
+#pragma unroll
+        for (int mt = 0; mt < MTN; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * ROWS + mt * 16 + 4 * a + r;
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) slab[(long)row * p.n_pad + st * 64 + nt * 16 + b] = acc[mt][nt][r];
+            }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MTN; mt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = rb * ROWS + mt * 16 + 4 * a + r;
+            if (row >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const int col = st * 64 + nt * 16 + b;
+                if (col < p.N) {
+                    float v = acc[mt][nt][r];
+                    if (p.bias) v += __half2float(p.bias[col]);
+                    p.out[(long)row * p.ldo + col] = __float2half(v);
+                }
+            }
+        }
+}
+
+static int launch_tilep(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)2 * 1024 * 16;
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_tilep_kernel<true>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_tilep_kernel<false>), grid, dim3(256), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
 }
 
 template <int MODE>
@@ -1206,7 +1426,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // the one-launch intra-workgroup split below (tools/exp_dense.py): down 14336→4096 31.3 → 18.4 µs (S = 8),
     // gate_up 4096→28672 25.7 → 23.2 µs (S = 2); the small projections (qkv, o) tie, so they keep the single launch.
     static const int tile_min_m = getenv("FERRUM_HIP_W4_TILE_MIN_M") ? atoi(getenv("FERRUM_HIP_W4_TILE_MIN_M")) : 64;
-    if (m >= tile_min_m && w.perm == nullptr) {   // prefill: 64-row LDS tiles (w4_gemm_tile_kernel)
+    if (m >= tile_min_m && w.perm == nullptr) {   // prefill: 64-row pipelined tiles (w4_gemm_tilep_kernel)
         // too few tiles to cover the chip (narrow N or few rows): split K over grid.z into fp32 slabs + one reduce launch,
         // keeping ≥ 8 quant groups per split
         static const int tile_wgs = getenv("FERRUM_HIP_W4_TILE_WGS") ? atoi(getenv("FERRUM_HIP_W4_TILE_WGS")) : 256;
@@ -1218,7 +1438,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
         a.S = S;
         a.rows_pad = rows_pad; a.n_pad = n_pad;
         a.partial = S > 1 ? workspace : nullptr;
-        if (int rc = launch_tile<0>(a, w.zp != nullptr, dim3(cols, rts, S), stream)) return rc;
+        if (int rc = launch_tilep(a, w.zp != nullptr, dim3(cols, rts, S), stream)) return rc;
         if (S == 1) return 0;
         hipLaunchKernelGGL(splitk_reduce_bias_kernel, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, w.bias, S, m,
                            w.n, rows_pad, n_pad, w.n);

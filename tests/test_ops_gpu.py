@@ -134,10 +134,13 @@ def test_gptq_asymmetric_and_act_order(env, k, n, m):
 
 
 @pytest.mark.parametrize("k,n,ms,sym", [
-    # row-count boundaries of the three dense kernels (≤16 wgsplit, 17–32 LDS-A / wgsplit, ≥64 tile + split-K, 33–63 wgsplit)
+    # row-count boundaries of the three dense kernels (≤16 wgsplit, 17–32 LDS-A / wgsplit, ≥64 pipelined tile + split-K, 33–63 wgsplit)
     # on shapes that select each path: deep-K narrow-N (LDS-A with slabs), wide-N, tiny, N not a multiple of 64, asymmetric
     (8192, 2048, (16, 17, 32, 33), True), (1024, 16384, (17, 32, 64, 65), True), (256, 64, (1, 16, 31, 63, 64, 127, 128, 200), True),
-    (1536, 1000, (5, 20, 64, 130), True), (2048, 640, (24, 64, 96), False), (14336, 512, (32, 64), True)])
+    (1536, 1000, (5, 20, 64, 130), True), (2048, 640, (24, 64, 96), False), (14336, 512, (32, 64), True),
+    # many row tiles through the pipelined tile kernel — ragged last tile, odd group count (K = 640: 5 groups), split-K
+    # (narrow N), columns not a multiple of 256, asymmetric + bias
+    (640, 320, (1024, 1100), True), (2048, 512, (1024,), True), (1024, 1000, (1153,), True), (768, 640, (1025,), False)])
 def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym):
     pkg, B, ctx, O, torch = env
     qw, sc, qz = O.make_synthetic_gptq(k, n, 128, k * 7 + n, symmetric=sym)
