@@ -17,7 +17,11 @@
 //    xor-shuffles; Oᵀ = Vᵀ·Pᵀ keeps the same column ↔ row map, so no cross-lane traffic for the
 //    rescale and P feeds the second MFMA straight from the accumulator registers;
 //  * the 4 waves of a workgroup split the KV range, and grid.z splits it further for long
-//    contexts (flash-decode); partial (m, l, O) are merged in fixed order (deterministic).
+//    contexts (flash-decode); partial (m, l, O) are merged in fixed order (deterministic);
+//  * prefill (RS, ≥ 4 row tiles per sequence): the waves of a workgroup take 4 CONSECUTIVE row tiles instead and each
+//    walks its whole KV range — no cross-wave merge, a loop long enough to amortise the prologue (at 256-token prompts
+//    the KV-split form gives a wave 1–2 block pairs), and the four waves request the same K/V lines at about the same
+//    time (L1 hits instead of 4× the L2 traffic).
 #include "common.h"
 #include "kernels.h"
 #include "kv_layout.h"
@@ -55,8 +59,9 @@ struct AttnArgs {
 // float operations in the same order (bit-identical fp16 results).  The split that owns the last KV block
 // writes the new K/V into the paged cache and every wave patches the new token's slot into the fragments it
 // loaded from that block, so nothing depends on the visibility of the cache store inside the launch.
-template <int HD, bool FUSED_QKV, int NW>
+template <int HD, bool FUSED_QKV, int NW, bool RS = false>
 __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
+    static_assert(!(RS && FUSED_QKV), "row-split is the prefill form");
     constexpr int DT = HD / 16;      // output d-tiles
     constexpr int KS = HD / 32;      // QKᵀ k-steps (= 1-KiB loads per K tile = per V tile)
     constexpr int OSTRIDE = HD + 4;  // padded LDS row (floats)
@@ -65,8 +70,9 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int seq = blockIdx.x / p.tiles_per_seq, tile = blockIdx.x % p.tiles_per_seq;
-    const int kvh = blockIdx.y, z = blockIdx.z;
+    const int tpw = RS ? (p.tiles_per_seq + NW - 1) / NW : p.tiles_per_seq;      // workgroups per sequence
+    const int seq = blockIdx.x / tpw, tile = RS ? (blockIdx.x % tpw) * NW + wave : blockIdx.x % tpw;
+    const int kvh = blockIdx.y, z = RS ? 0 : blockIdx.z;
     const int G = p.nq / p.nkv;
 
     const int tok0 = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq] : seq;
@@ -92,9 +98,11 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
     const int pair_lo = (kv_begin / KV_BLOCK) / 2;
     const int pair_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;       // exclusive
     const int npairs = pair_hi - pair_lo;
-    const int per_split = (npairs + p.nsplit - 1) / p.nsplit;
+    const int per_split = RS ? npairs : (npairs + p.nsplit - 1) / p.nsplit;
     const int my_lo = pair_lo + z * per_split;
     const int my_hi = min(pair_hi, my_lo + per_split);
+    constexpr int STEP = RS ? 1 : NW;                   // RS: every wave walks the whole range of ITS tile
+    const int first = my_lo + (RS ? 0 : wave);
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
 
     // Block-table entries of this split are fetched once (64 per wave, re-fetched every 32 pairs) and the K/V
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
         }
     };
     Frags cur, nxt;
-    if (my_lo + wave < my_hi) issue(my_lo + wave, cur);
+    if (first < my_hi) issue(first, cur);
 
     half8 qf[KS];
     __shared__ __attribute__((aligned(16))) __half lds_q[FUSED_QKV ? 16 * HD : 8];
@@ -186,10 +194,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
     for (int dt = 0; dt < DT; dt++) o_acc[dt] = (float4v){0.f, 0.f, 0.f, 0.f};
 
 
-    for (int pr = my_lo + wave; pr < my_hi; pr += NW) {
+    for (int pr = first; pr < my_hi; pr += STEP) {
         const int blk0 = 2 * pr, blk1 = 2 * pr + 1;
         const bool has1 = blk1 < nblocks;
-        if (pr + NW < my_hi) issue(pr + NW, nxt);
+        if (pr + STEP < my_hi) issue(pr + STEP, nxt);
         __builtin_amdgcn_sched_barrier(0);               // keep the prefetch ahead of this pair's MFMAs
         half8 (&kf0)[KS] = cur.k0, (&kf1)[KS] = cur.k1, (&vf0)[KS] = cur.v0, (&vf1)[KS] = cur.v1;
         if (FUSED_QKV && (blk0 == last_blk || blk1 == last_blk)) {
@@ -266,6 +274,27 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
         cur = nxt;
     }
 
+    if (RS) {
+        // wave-private transposition through LDS (Oᵀ[d][row] → rows of 64-byte pieces); LDS ops of one wave execute in order
+        float* lo = lds_o + wave * 16 * OSTRIDE;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) *reinterpret_cast<float4v*>(&lo[b * OSTRIDE + dt * 16 + 4 * a]) = o_acc[dt];
+        const int row = lane >> 2, dl = lane & 3;
+        const float l_row = __shfl(l_run, row, 64);       // lane `row` (a = 0, b = row) holds that row's sum
+        const int rho_o = tile * 16 + row;
+        if (rho_o >= rows_total) return;
+        const float inv = l_row > 0.f ? 1.0f / l_row : 0.f;
+        constexpr int DPL = HD / 4;
+        __half* o = p.out + ((long)(tok0 + rho_o / G) * p.nq + kvh * G + rho_o % G) * HD + dl * DPL;
+#pragma unroll
+        for (int i = 0; i < DPL; i += 8) {
+            half8 h;
+#pragma unroll
+            for (int j = 0; j < 8; j++) h[j] = (_Float16)(lo[row * OSTRIDE + dl * DPL + i + j] * inv);
+            *reinterpret_cast<half8*>(o + i) = h;
+        }
+        return;
+    }
     // merge the NW waves' partial states through LDS
     if (a == 0) {
         lds_m[wave * 16 + b] = m_run;
@@ -398,11 +427,17 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
         a.k_pool_w = fq->k_pool_w; a.v_pool_w = fq->v_pool_w; a.eps = fq->eps; a.qk_mode = fq->qk_mode;
     }
     dim3 grid(tiles, num_kv_heads, nsplit);
+    // prefill (≥ 4 row tiles per sequence, no KV split): the waves of a workgroup take consecutive row tiles
+    // (only when that still leaves ≥ 2 workgroups per CU: a single 256-token prompt is faster KV-split, 7.5 vs 7.85 ms TTFT)
+    const bool rs = !fq && nsplit == 1 && a.tiles_per_seq >= 4 && (long)num_seqs * cdiv(a.tiles_per_seq, 4) * num_kv_heads >= 512 &&
+                    !(getenv("FERRUM_HIP_ATTN_NO_RS") && atoi(getenv("FERRUM_HIP_ATTN_NO_RS")));
+    if (rs) grid = dim3(num_seqs * cdiv(a.tiles_per_seq, 4), num_kv_heads, 1);
     // decode with ≥ 8 block pairs per split: 8 waves per workgroup (more loads in flight per CU)
     const bool wide = max_q_len == 1 && cdiv(cdiv(max_kv_len, KV_BLOCK), 2) / nsplit >= 8 && !(getenv("FERRUM_HIP_ATTN_NARROW") && atoi(getenv("FERRUM_HIP_ATTN_NARROW")));
 #define FH_ATTN(HDV)                                                                              \
     if (fq && wide) hipLaunchKernelGGL((paged_attn_kernel<HDV, true, 8>), grid, dim3(512), 0, s, a);       \
     else if (fq) hipLaunchKernelGGL((paged_attn_kernel<HDV, true, 4>), grid, dim3(256), 0, s, a);          \
+    else if (rs) hipLaunchKernelGGL((paged_attn_kernel<HDV, false, 4, true>), grid, dim3(256), 0, s, a);   \
     else if (wide) hipLaunchKernelGGL((paged_attn_kernel<HDV, false, 8>), grid, dim3(512), 0, s, a);       \
     else hipLaunchKernelGGL((paged_attn_kernel<HDV, false, 4>), grid, dim3(256), 0, s, a);                 \
     FH_CHECK_LAUNCH();                                                                            \
