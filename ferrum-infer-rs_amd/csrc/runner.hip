@@ -1266,7 +1266,7 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     FH_CHECK_HIP(hipEventCreate(&e1));
     int blocks = 0;
     const int P = T * std::max(c.top_k, 1), E = c.num_experts;
-    if (E > 0) {
+    if (E > 0 && which < 2) {
         FH_REQUIRE(P <= 1024, "time_kernel: MoE timing uses the decode (inline-align) path, pairs=%d > 1024", P);
         std::vector<int32_t> ids(P);
         FH_CHECK_HIP(hipMemcpyAsync(ids.data(), m->expert_ids, (size_t)P * 4, hipMemcpyDeviceToHost, s));
@@ -1276,6 +1276,7 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
         for (int e = 0; e < E; e++) blocks += (cnt[e] + 15) / 16;
     }
     if (moe_blocks) *moe_blocks = blocks;
+    FH_REQUIRE(T <= c.max_tokens, "time_kernel: %d rows > max_tokens %d", T, c.max_tokens);
     const int max_blocks = E > 0 ? std::min((P + E * 16) / 16, P / 16 + std::min(P, E)) : 0;
     int launches = 0, rc = 0;
     auto one = [&](int li) -> int {
