@@ -429,7 +429,8 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     dim3 grid(tiles, num_kv_heads, nsplit);
     // prefill (≥ 4 row tiles per sequence, no KV split): the waves of a workgroup take consecutive row tiles
     // (only when that still leaves ≥ 2 workgroups per CU: a single 256-token prompt is faster KV-split, 7.5 vs 7.85 ms TTFT)
-    const bool rs = !fq && nsplit == 1 && a.tiles_per_seq >= 4 && (long)num_seqs * cdiv(a.tiles_per_seq, 4) * num_kv_heads >= 512 &&
+    const long rs_min_wgs = getenv("FERRUM_HIP_ATTN_RS_MIN_WGS") ? atol(getenv("FERRUM_HIP_ATTN_RS_MIN_WGS")) : 512;   // tests lower it
+    const bool rs = !fq && nsplit == 1 && a.tiles_per_seq >= 4 && (long)num_seqs * cdiv(a.tiles_per_seq, 4) * num_kv_heads >= rs_min_wgs &&
                     !(getenv("FERRUM_HIP_ATTN_NO_RS") && atoi(getenv("FERRUM_HIP_ATTN_NO_RS")));
     if (rs) grid = dim3(num_seqs * cdiv(a.tiles_per_seq, 4), num_kv_heads, 1);
     // decode with ≥ 8 block pairs per split: 8 waves per workgroup (more loads in flight per CU)

@@ -277,7 +277,7 @@ def run_parity_case(pkg, moe, layers=2, prompt_len=19, decode_steps=4, seed=0, *
     same argmax AND cosine > 0.999 at every step; ids are only required to match where the oracle's
     top-1/top-2 margin exceeds the fp16-storage noise (documented in DESIGN.md)."""
     tm = TinyModel(moe, layers=layers, seed=seed, **model_kw)
-    om, hm = tm.oracle_model(), tm.hip_model(pkg)
+    om, hm = tm.oracle_model(), tm.hip_model(pkg, max_tokens=max(256, prompt_len))
     rng = np.random.default_rng(seed + 1)
     vocab = tm.cfg["vocab"]
     prompt = rng.integers(0, vocab, size=prompt_len).astype(np.uint32)

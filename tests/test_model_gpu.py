@@ -41,6 +41,16 @@ def test_prefill_and_decode_match_oracle(pkg, moe):
     assert blocks == [0, 1, 2]                                   # BlockAllocator hands out 0,1,2,… (paged_pool.rs:466-472)
 
 
+@pytest.mark.parametrize("moe", [False, True])
+def test_long_prompt_prefill_row_tiles(pkg, moe, monkeypatch):
+    """A 300-token prompt: five 64-row tiles through the pipelined dense GEMM (ragged last tile), 64-pair MoE blocks through
+    the grouped tile kernel (75 pairs per expert), 38 attention row tiles through the row-split prefill form."""
+    from tests import modelgen
+    monkeypatch.setenv("FERRUM_HIP_ATTN_RS_MIN_WGS", "1")
+    res = modelgen.run_parity_case(pkg, moe=moe, layers=2, prompt_len=300, decode_steps=2, seed=17, max_seq_len=512)
+    _assert_parity(res)
+
+
 def test_llama_style_no_qk_norm_rope_scaling_and_tied_head(pkg):
     from tests import modelgen
     res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=21, decode_steps=3, seed=5, qk_norm=False,
