@@ -278,7 +278,7 @@ def main():
         tp = os.path.join(ROOT, "profiles", "pmc_traffic_gate_up.json")
         if moe and c == 32 and os.path.exists(tp):
             traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
-        extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_kernel<1,false,2> (MoE gate_up INT4 grouped GEMM + silu*mul)" if moe
+        extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_moe_em_kernel<false,2> (MoE gate_up INT4 grouped GEMM + silu*mul, expert-major)" if moe
                              else "w4_gemm dense gate_up INT4 GEMM",
                              "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -138,6 +138,12 @@ class ExpertStack(GptqLinear):
                "moe_gemm_phase_inline_align")
 
 
+    def gemm_phase_expert_major(self, ctx, inp, expert_ids_per_pair, output, prob_m, num_experts, top_k, fused_silu_mul=False):
+        _check(ctx.lib.ferrum_hip_moe_gemm_phase_expert_major_f16(self.handle, _ptr(inp), _ptr(expert_ids_per_pair),
+                                                                  _ptr(output), prob_m, num_experts, top_k,
+                                                                  int(fused_silu_mul), ctx.stream),
+               "moe_gemm_phase_expert_major")
+
     def gemm_phase_merge_route(self, ctx, inp, cand, stats, output, tokens, num_parts, top_k, norm_topk_prob, num_experts,
                                max_blocks, expert_ids_out, expert_weights_out, sorted_out, block_ids_out, total_out,
                                fused_silu_mul=False):

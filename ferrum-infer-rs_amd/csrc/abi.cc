@@ -339,6 +339,18 @@ int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const
                                     top_k, fused_silu_mul, nullptr, nullptr, nullptr, ST(stream));
 }
 
+int ferrum_hip_moe_gemm_phase_expert_major_f16(const FerrumHipGptq* stack, const void* input,
+                                               const int32_t* expert_ids_per_pair, void* output, int prob_m,
+                                               int num_experts, int top_k, int fused_silu_mul, void* stream) {
+    FH_REQUIRE(stack && input && expert_ids_per_pair && output, "moe_gemm_phase_expert_major: null argument");
+    FH_REQUIRE(top_k >= 1 && num_experts >= 1, "moe_gemm_phase_expert_major: top_k=%d num_experts=%d", top_k, num_experts);
+    FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase_expert_major: fused epilogue needs a stack loaded with fuse_gate_up");
+    FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase_expert_major: stack was loaded with fuse_gate_up; plain output is column-permuted");
+    if (prob_m > 1024) { fh::set_error("moe_gemm_phase_expert_major: prob_m=%d > 1024 (use moe_align_block_size + moe_gemm_phase)", prob_m); return FERRUM_HIP_UNSUPPORTED; }
+    return w4_gemm_moe_expert_major(stack->dev, CH(input), H(output), expert_ids_per_pair, num_experts, prob_m, top_k,
+                                    fused_silu_mul, ST(stream));
+}
+
 int ferrum_hip_sandwich_add_rms_norm_f32(const void* branch_f16, const void* w_branch, float* residual_f32, const void* w_next,
                                          float eps, void* norm_out_f16, int tokens, int dim, void* stream) {
     FH_REQUIRE(tokens == 0 || (branch_f16 && w_branch && residual_f32 && (!w_next || norm_out_f16)), "sandwich_add_rms_norm_f32: null buffer");

@@ -44,6 +44,8 @@ int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, si
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
                 const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs,
                 int max_blocks, int top_k, int fused_silu, hipStream_t stream);
+int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids, int num_experts,
+                             int num_valid_pairs, int top_k, int fused_silu, hipStream_t stream);
 int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
                              int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
                              int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream);

@@ -303,6 +303,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_DENSE_SLABS")) m->dense_slabs = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_ROUTE_GEMM_TOKENS")) m->route_gemm_min_tokens = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
     *model = m;
     return 0;
 }
@@ -796,6 +797,20 @@ T* idx(FerrumHipModel* m, size_t off) { return reinterpret_cast<T*>(m->idx_dev +
 
 // Dense projection of the runner: act-order (desc_act) weights were repacked with their rows sorted by group, so the
 // input columns are gathered with the same permutation first (like the op-level ferrum_hip_gptq_linear_forward_f16).
+// gate_up (+silu·mul) and down grouped GEMMs of a decode-sized batch (P ≤ 1024 pairs) straight from expert_ids:
+// expert-major when most experts are routed to (no align at all), else block-major with the align computed inside gate_up.
+static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_blocks, hipStream_t s) {
+    const FerrumHipModelConfig& c = m->cfg;
+    const int E = c.num_experts, K = c.top_k;
+    if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * E) {
+        if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, K, 1, s)) return rc;
+        return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, m->expert_ids, E, P, 1, 0, s);
+    }
+    if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
+                                          m->sorted_ids, m->block_ids, m->total_post_pad, s)) return rc;
+    return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
+}
+
 int dense_linear(FerrumHipModel* m, const W4Device& w, const __half* x, __half* out, int T, hipStream_t s) {
     if (w.perm) {
         FH_REQUIRE(m->gather_scratch, "dense_linear: act-order weights but no gather scratch");
@@ -897,20 +912,14 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                                                            n_pad, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K, Q,
                                                            m->route_cand, m->route_stats, m->route_arrive, c.norm_topk_prob,
                                                            m->expert_ids, m->expert_w, nullptr, T, H, s));
-                    RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
-                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s));
-                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                    max_blocks, 1, 0, s));
+                    RUN(moe_decode_gemms(m, L, P, max_blocks, s));
                     RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps,
                                                      m->norm_out, T, K, H, s));
                 } else {
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, m->o_out, slabs, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
                                                            c.rms_eps, m->norm_out, L.router, E, K, c.norm_topk_prob, m->expert_ids,
                                                            m->expert_w, nullptr, T, H, s));
-                    RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
-                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s));
-                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                    max_blocks, 1, 0, s));
+                    RUN(moe_decode_gemms(m, L, P, max_blocks, s));
                     RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
                                                      m->norm_out, T, K, H, s));
                 }
@@ -929,10 +938,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                                                      c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
                 }
                 if (P <= 1024) {
-                    RUN(w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
-                                                 m->sorted_ids, m->block_ids, m->total_post_pad, s));
-                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                    max_blocks, 1, 0, s));
+                    RUN(moe_decode_gemms(m, L, P, max_blocks, s));
                 } else if (P >= m->moe_tile_min_pairs_per_expert * E) {
                     // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
                     const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
@@ -1279,14 +1285,18 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     FH_REQUIRE(T <= c.max_tokens, "time_kernel: %d rows > max_tokens %d", T, c.max_tokens);
     const int max_blocks = E > 0 ? std::min((P + E * 16) / 16, P / 16 + std::min(P, E)) : 0;
     int launches = 0, rc = 0;
+    const bool em = E > 0 && m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * E;   // as moe_decode_gemms
     auto one = [&](int li) -> int {
         LayerWeights& L = m->layers[li];
         switch (which) {
         case 0: {
+            if (em) return w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, c.top_k, 1, s);
             return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
                                             m->sorted_ids, m->block_ids, m->total_post_pad, s);
         }
-        case 1: return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
+        case 1:
+            if (em) return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, m->expert_ids, E, P, 1, 0, s);
+            return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
         case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),
                                                           idx<uint32_t>(m, m->il.kv_lens), T, max_kv_len, c.num_heads, c.num_kv_heads,
                                                           c.head_dim, KV_BLOCK, m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s);

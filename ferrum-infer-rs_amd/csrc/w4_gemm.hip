@@ -658,6 +658,117 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
         }
 }
 
+// ── MoE grouped GEMM, expert-major (decode batches where most experts are routed to) ───────────────────────────
+// w4_gemm_kernel's MoE modes are block-major: a wave must finish the align (LDS histogram, scan, compaction ≈ 2 µs) before
+// it knows WHICH expert's weights to stream, and every wave of the launch pays that with nothing in flight.  Here the grid
+// is (64-column supertile, expert): the wave requests its expert's first weight group at once, finds the expert's pairs
+// meanwhile (ballot compaction of pair_expert_ids == e, ascending pair id — the order moe_align_block_size produces), and
+// leaves if there are none.  More than 16 pairs of one expert (rare at P ≤ 8·E) take further passes over the weights (L2).
+// Same per-row arithmetic as the block-major kernel (w4_consume_group, one 16-row tile): bit-identical outputs.
+template <bool HAS_ZP, int MODE>
+__global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
+    static_assert(MODE == 1 || MODE == 2, "grouped-GEMM modes only");
+    const int lane = threadIdx.x;
+    const int a = lane >> 4, b = lane & 15;
+    const int st = blockIdx.x, e = blockIdx.y;
+    __shared__ int s_rows[1024];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4* qw_lane = reinterpret_cast<const u32x4*>(p.qw + (long)e * p.expert_stride_qw) + ((long)st * p.G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc + (long)e * p.expert_stride_sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp + (long)e * p.expert_stride_sc) + ((long)st * p.G) * 16 + b : nullptr;
+    u32x4 wq[2][4];
+    uint2 scv[2], zpv[2];
+    half8 af[2][1][4];
+    auto issue_w = [&](int buf, int g) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[buf][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[buf] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[buf] = zp_lane[(long)g * 16];
+    };
+    // the routing and the first weight group are requested together
+    int ids[16];
+    const int P = p.M, chunks = (P + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) ids[i] = (i < chunks && i * 64 + lane < P) ? p.pair_expert_ids[i * 64 + lane] : -1;
+    issue_w(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    int n_e = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i < chunks) {
+            const bool mine = ids[i] == e;
+            const unsigned long long bal = __ballot(mine);
+            if (mine) s_rows[n_e + __popcll(bal & ((1ull << lane) - 1ull))] = i * 64 + lane;
+            n_e += __popcll(bal);
+        }
+    }
+    if (n_e == 0) return;
+    __syncthreads();
+    for (int j = 0; j * 16 < n_e; j++) {
+        const int id = j * 16 + b < n_e ? s_rows[j * 16 + b] : P;
+        const bool row_ok = id < P;
+        const __half* xrow = p.x + (long)(row_ok ? id / p.top_k : 0) * p.K + 8 * a;
+        auto issue_a = [&](int buf, int g) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) af[buf][0][s] = *reinterpret_cast<const half8*>(xrow + g * 128 + 32 * s);
+        };
+        float4v acc[1][4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[0][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+        auto consume = [&](int buf) {
+            const unsigned long long sb = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
+            const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
+            w4_consume_group<1, 4, HAS_ZP>(wq[buf], sb, zb, 0, af[buf], acc);
+        };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+        if (j > 0) issue_w(0, 0);                    // further passes re-stream the expert (L2)
+        issue_a(0, 0);
+        FH_PIN();
+        int g = 0;
+        const int g1 = p.G;
+        for (; g + 2 <= g1 - 1; g += 2) {            // two groups per trip keeps buffer indices static
+            issue_w(1, g + 1); issue_a(1, g + 1);
+            FH_PIN();
+            consume(0);
+            FH_PIN();
+            issue_w(0, g + 2); issue_a(0, g + 2);
+            FH_PIN();
+            consume(1);
+            FH_PIN();
+        }
+        if (g + 1 < g1) {
+            issue_w(1, g + 1); issue_a(1, g + 1);
+            FH_PIN();
+            consume(0);
+            consume(1);
+        } else {
+            consume(0);
+        }
+#undef FH_PIN
+        // D row 4a + r ↔ block row 4a + r, whose pair id lives in lane (·, b = 4a + r)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int orow = __shfl(id, 4 * a + r, 64);
+            if (orow >= P) continue;
+            if (MODE == 2) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const float gt = acc[0][jj][r], up = acc[0][2 + jj][r];
+                    const float v = (gt / (1.0f + __expf(-gt))) * up;
+                    const int col = st * 32 + jj * 16 + b;
+                    if (col < p.ldo) p.out[(long)orow * p.ldo + col] = __float2half(v);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const int col = st * 64 + nt * 16 + b;
+                    if (col < p.N) p.out[(long)orow * p.ldo + col] = __float2half(acc[0][nt][r]);
+                }
+            }
+        }
+    }
+}
+
 // Sum S fp32 slabs in fixed order → fp16 [M, N] (optionally gathering padded MoE rows).
 template <typename OutT>
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, OutT* __restrict__ out, int S,
@@ -1517,6 +1628,35 @@ int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, co
     dim3 grid(w.n64, max_blocks, 1);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
+}
+
+// Expert-major grouped GEMM straight from the per-pair expert ids (no align arrays at all): out row = pair id,
+// in row = pair id / top_k.  For decode batches with P ≤ 1024 pairs where most experts are active.
+int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids, int num_experts,
+                             int num_valid_pairs, int top_k, int fused_silu, hipStream_t stream) {
+    if (num_valid_pairs <= 0) return 0;
+    FH_REQUIRE(num_valid_pairs <= 1024 && num_experts <= 65535, "expert-major grouped GEMM: pairs=%d experts=%d out of range",
+               num_valid_pairs, num_experts);
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
+    a.expert_stride_sc = (long)w.n64 * w.G * 16 * 4;
+    a.x = x; a.out = out; a.M = num_valid_pairs; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64;
+    a.ldo = fused_silu ? w.n / 2 : w.n;
+    a.S = 1;
+    a.pair_expert_ids = pair_expert_ids; a.num_experts = num_experts;
+    a.top_k = top_k;
+    const dim3 grid(w.n64, num_experts, 1);
+    const bool zp = w.zp != nullptr;
+    if (fused_silu) {
+        if (zp) hipLaunchKernelGGL((w4_gemm_moe_em_kernel<true, 2>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((w4_gemm_moe_em_kernel<false, 2>), grid, dim3(64), 0, stream, a);
+    } else {
+        if (zp) hipLaunchKernelGGL((w4_gemm_moe_em_kernel<true, 1>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((w4_gemm_moe_em_kernel<false, 1>), grid, dim3(64), 0, stream, a);
+    }
+    FH_CHECK_LAUNCH();
+    return 0;
 }
 
 // gate_up phase of a decode step: routing is taken from the Q candidate lists written by

@@ -139,6 +139,14 @@ int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const
                                                int num_experts, int top_k, int max_blocks, int fused_silu_mul,
                                                void* stream);
 
+/* Same GEMM again, expert-major: the grid is (column tile, expert), every wave requests its expert's weights at once and
+ * finds the expert's pairs (ascending pair id, the order ferrum_hip_moe_align_block_size produces) meanwhile — no align
+ * arrays at all.  Same outputs bit for bit; for decode-sized batches (prob_m ≤ 1024) in which most experts are routed to
+ * (an expert without pairs costs one wasted 4-KiB weight request per column tile). */
+int ferrum_hip_moe_gemm_phase_expert_major_f16(const FerrumHipGptq* stack, const void* input,
+                                               const int32_t* expert_ids_per_pair, void* output, int prob_m,
+                                               int num_experts, int top_k, int fused_silu_mul, void* stream);
+
 /* Sandwich-norm residual update on an fp32 residual stream (Gemma 3): `rms_norm_activation_add_to_f32` +
  * `rms_norm_f32_to_activation` of the reference's device path (llama_family.rs:3381-3421) in one launch:
  * residual_f32 += rms_norm(branch, w_branch);  norm_out = f16(rms_norm(residual_f32, w_next))  (w_next NULL → skipped). */

@@ -614,7 +614,7 @@ def test_moe_align_block_size_bit_exact(env, tokens, ne, k):
     assert np.array_equal(bd.cpu().numpy()[:len(rb)], rb)
 
 
-@pytest.mark.parametrize("tokens,E,K,H,I", [(1, 8, 2, 256, 128), (9, 8, 2, 256, 128), (32, 16, 4, 512, 256),
+@pytest.mark.parametrize("tokens,E,K,H,I", [(1, 8, 2, 256, 128), (9, 8, 2, 256, 128), (32, 16, 4, 512, 256), (64, 8, 2, 256, 128),
                                             (32, 128, 8, 2048, 768), (96, 128, 8, 2048, 768)])   # Qwen3-30B-A3B expert dims
 def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
     # whole expert MLP path vs moe_forward_cpu (dispatch.rs:2208-2288), plain and fused-silu stacks
@@ -673,6 +673,22 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
             ctx.sync()
             assert torch.equal(act64, act)                       # per-row sums are independent of the block shape
             assert nmse(ref, host(out64)) < 3e-6
+        # expert-major grid straight from the raw expert ids (no align arrays): bit-identical outputs; experts with more
+        # than 16 pairs (the 64-token / 8-expert case) take further passes, experts without pairs leave early
+        down3 = torch.zeros(P, H, dtype=torch.float16, device="cuda")
+        if fused:
+            act3 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
+            stack.gemm_phase_expert_major(ctx, xd, ids_d, act3, P, E, K, fused_silu_mul=True)
+            ctx.sync()
+            assert torch.equal(act, act3)
+        else:
+            gup3 = torch.zeros(P, 2 * I, dtype=torch.float16, device="cuda")
+            stack.gemm_phase_expert_major(ctx, xd, ids_d, gup3, P, E, K)
+            ctx.sync()
+            assert torch.equal(gup, gup3)
+        down_stack.gemm_phase_expert_major(ctx, act, ids_d, down3, P, E, 1)
+        ctx.sync()
+        assert torch.equal(down, down3)
         if fused:
             # align computed inside the GEMM from the raw expert ids: bit-identical outputs
             act2 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
