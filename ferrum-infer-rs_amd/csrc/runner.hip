@@ -1311,12 +1311,13 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     };
     FH_REQUIRE(which >= 2 || E > 0, "time_kernel: MoE kernel on a dense model");
     FH_REQUIRE(which < 6 || E == 0, "time_kernel: dense MLP kernel on a MoE model");
+    const bool same_layer = getenv("FERRUM_HIP_TIME_SAME_LAYER") != nullptr;   // experiment: weights resident in the Infinity Cache
     // warm-up round (code objects, TLBs), then the timed rounds
     for (int li = 0; li < c.num_layers && !rc; li++) rc = one(li);
     if (rc) return rc;
     FH_CHECK_HIP(hipEventRecord(e0, s));
     for (int r = 0; r < reps && !rc; r++)
-        for (int li = 0; li < c.num_layers && !rc; li++) { rc = one(which == 5 ? 0 : li); launches++; }
+        for (int li = 0; li < c.num_layers && !rc; li++) { rc = one(which == 5 || same_layer ? 0 : li); launches++; }
     FH_CHECK_HIP(hipEventRecord(e1, s));
     FH_CHECK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
