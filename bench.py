@@ -330,6 +330,17 @@ def main():
             extra["prefill_ms_all_prompts"] = {str(k): round(v, 2) for k, v in sorted(prefill_ms.items())}
             # p50 time-to-first-token when all c prompts arrive together (BASELINE.md quotes the reference's per-c TTFT)
             extra["ttft_ms_p50_by_c"] = {str(k): round(v, 2) for k, v in sorted(ttft_by_c.items())}
+        if not args.no_sweep and world == 1 and args.model in ("qwen3-30b-a3b", "llama31-8b") and not args.layers:
+            # the reference's own measurement shape (`ferrum bench-serve`: closed loop, 96 requests, 256-in/128-out, c in
+            # flight) driven by the C++ continuous-batching loop over the C ABI (csrc/serve_loop.cc) in its own process
+            exe = os.path.join(ROOT, "ferrum-infer-rs_amd", "bin", "ferrum_hip_serve")
+            import subprocess
+            cmd = [exe, "--requests", "96", "--concurrency", str(c), "--prompt-len", str(PL), "--out-len", "128",
+                   "--max-batched-tokens", str(chunk)] + (["--dense"] if args.model == "llama31-8b" else [])
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            if p.returncode != 0:
+                raise RuntimeError(f"ferrum_hip_serve failed: {p.stderr[-500:]}")
+            extra["serve_closed_loop"] = json.loads(p.stdout.strip().splitlines()[0])
         if not args.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline(cfg)
 
