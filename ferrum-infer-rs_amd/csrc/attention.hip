@@ -40,6 +40,7 @@ struct AttnArgs {
     const int32_t* block_tables;    // [num_seqs, max_blocks]
     float* partial;         // [tiles][nsplit][16][hd+2] when nsplit > 1
     int num_seqs, nq, nkv, tiles_per_seq, max_blocks, sliding_window, nsplit;
+    int compact;            // grid.x enumerates real work units of a ragged batch (see the kernel), not num_seqs × tiles_per_seq
     float scale;
     // fused decode form (FUSED_QKV): q / new K / new V come straight from the qkv projection output
     const __half* qkv;      // [num_seqs, (nq + 2·nkv)·hd]
@@ -70,14 +71,53 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int tpw = RS ? (p.tiles_per_seq + NW - 1) / NW : p.tiles_per_seq;      // workgroups per sequence
-    const int seq = blockIdx.x / tpw, tile = RS ? (blockIdx.x % tpw) * NW + wave : blockIdx.x % tpw;
     const int kvh = blockIdx.y, z = RS ? 0 : blockIdx.z;
     const int G = p.nq / p.nkv;
-
+    int seq, unit;                   // unit: row tile (KV-split form) or group of NW row tiles (row-split form) in the sequence
+    if (p.compact) {
+        // ragged batches (31 decode tokens + one 256-token prompt): a grid of num_seqs × max tiles launches thousands of
+        // workgroups that only find out they are empty (≈ 15 ns each, 70 µs per layer); here grid.x is an upper bound of
+        // the REAL work units and every wave finds its (sequence, unit) by a scan of cu_seqlens_q, 64 sequences per pass
+        const int w = blockIdx.x;
+        int base = 0;
+        seq = -1;
+        unit = 0;
+        for (int s0 = 0; s0 < p.num_seqs; s0 += 64) {
+            const int s = s0 + lane;
+            int units = 0;
+            if (s < p.num_seqs) {
+                const int tiles = ((int)(p.cu_seqlens_q[s + 1] - p.cu_seqlens_q[s]) * G + 15) >> 4;
+                units = RS ? (tiles <= 1 ? tiles : (tiles + NW - 1) / NW) : tiles;
+            }
+            int incl = units;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (w < base + total) {
+                const unsigned long long hit = __ballot(w < base + incl);      // first lane whose inclusive sum passes w
+                const int src = __ffsll((long long)hit) - 1;
+                seq = s0 + src;
+                unit = w - (base + __shfl(incl - units, src, 64));
+                break;
+            }
+            base += total;
+        }
+        if (seq < 0) return;
+    } else {
+        const int tpw = RS ? (p.tiles_per_seq + NW - 1) / NW : p.tiles_per_seq;      // workgroups per sequence
+        seq = blockIdx.x / tpw;
+        unit = blockIdx.x % tpw;
+    }
     const int tok0 = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq] : seq;
     const int q_len = p.cu_seqlens_q ? (int)p.cu_seqlens_q[seq + 1] - tok0 : 1;
     const int rows_total = q_len * G;
+    // a row-split launch still serves its single-tile sequences (the decode tokens of a mixed batch) KV-split: one wave
+    // alone would walk the whole context
+    const bool rs = RS && rows_total > 16;
+    const int tile = rs ? unit * NW + wave : unit;
     if (tile * 16 >= rows_total) return;
     const int pos0 = p.kv_lens ? (int)p.kv_lens[seq] - 1 : (int)p.pos_offsets[seq];
 
@@ -98,11 +138,11 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
     const int pair_lo = (kv_begin / KV_BLOCK) / 2;
     const int pair_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;       // exclusive
     const int npairs = pair_hi - pair_lo;
-    const int per_split = RS ? npairs : (npairs + p.nsplit - 1) / p.nsplit;
+    const int per_split = RS ? npairs : (npairs + p.nsplit - 1) / p.nsplit;      // (a row-split launch has nsplit = 1)
     const int my_lo = pair_lo + z * per_split;
     const int my_hi = min(pair_hi, my_lo + per_split);
-    constexpr int STEP = RS ? 1 : NW;                   // RS: every wave walks the whole range of ITS tile
-    const int first = my_lo + (RS ? 0 : wave);
+    const int STEP = rs ? 1 : NW;                       // row-split: every wave walks the whole range of ITS tile
+    const int first = my_lo + (rs ? 0 : wave);
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
 
     // Block-table entries of this split are fetched once (64 per wave, re-fetched every 32 pairs) and the K/V
@@ -274,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
         cur = nxt;
     }
 
-    if (RS) {
+    if (rs) {
         // wave-private transposition through LDS (Oᵀ[d][row] → rows of 64-byte pieces); LDS ops of one wave execute in order
         float* lo = lds_o + wave * 16 * OSTRIDE;
 #pragma unroll
@@ -433,6 +473,15 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     const bool rs = !fq && nsplit == 1 && a.tiles_per_seq >= 4 && (long)num_seqs * cdiv(a.tiles_per_seq, 4) * num_kv_heads >= rs_min_wgs &&
                     !(getenv("FERRUM_HIP_ATTN_NO_RS") && atoi(getenv("FERRUM_HIP_ATTN_NO_RS")));
     if (rs) grid = dim3(num_seqs * cdiv(a.tiles_per_seq, 4), num_kv_heads, 1);
+    // ragged batch without a KV split: enumerate only the real work units (upper bound from the token count)
+    if (cu_seqlens_q && nsplit == 1 && a.tiles_per_seq > 1) {
+        const long tiles_bound = ((long)total_q_tokens * G) / 16 + num_seqs;
+        const long units = rs ? cdiv(tiles_bound, 4) + num_seqs : tiles_bound;
+        if (units < (long)grid.x) {
+            a.compact = 1;
+            grid.x = (unsigned)units;
+        }
+    }
     // decode with ≥ 8 block pairs per split: 8 waves per workgroup (more loads in flight per CU)
     const bool wide = max_q_len == 1 && cdiv(cdiv(max_kv_len, KV_BLOCK), 2) / nsplit >= 8 && !(getenv("FERRUM_HIP_ATTN_NARROW") && atoi(getenv("FERRUM_HIP_ATTN_NARROW")));
 #define FH_ATTN(HDV)                                                                              \

@@ -33,6 +33,7 @@ struct Request {
     int prefilled = 0;        // prompt tokens already in the KV cache
     int generated = 0;        // output tokens sampled so far
     uint32_t last_token = 0;  // most recent output token (input of the next decode step)
+    int out_len = 0;          // output tokens this request asks for
     double t_submit = 0, t_first = 0;
     std::vector<uint32_t> out;
 };
@@ -76,10 +77,11 @@ int main(int argc, char** argv) {
     const int PL = arg_int(argc, argv, "--prompt-len", 256);
     const int OL = arg_int(argc, argv, "--out-len", 128);
     const int budget = arg_int(argc, argv, "--max-batched-tokens", 8192);
+    const int jitter = arg_int(argc, argv, "--out-len-jitter", 0);   // output lengths uniform in [OL − jitter, OL + jitter]: staggers retirements
     const int dense = arg_flag(argc, argv, "--dense");          // Llama-3.1-8B dims instead of Qwen3-30B-A3B
     const bool dump = arg_flag(argc, argv, "--dump-tokens");
     uint64_t seed = (uint64_t)arg_int(argc, argv, "--seed", 9271);
-    if (conc < 1 || PL < 1 || OL < 1 || budget < conc || num_requests < 1) {
+    if (conc < 1 || PL < 1 || OL < 1 || budget < conc || num_requests < 1 || jitter < 0 || jitter >= OL) {
         std::fprintf(stderr, "bad arguments\n");
         return 2;
     }
@@ -96,7 +98,7 @@ int main(int argc, char** argv) {
         cfg.vocab = 151936; cfg.has_qk_norm = 1; cfg.num_experts = 128; cfg.top_k = 8; cfg.expert_inter = 768;
         cfg.norm_topk_prob = 1; cfg.rope_theta = 1000000.0;
     }
-    const int seq_cap = ((PL + OL + 15) / 16) * 16;
+    const int seq_cap = ((PL + OL + jitter + 15) / 16) * 16;
     cfg.max_seq_len = seq_cap;
     cfg.group_size = 128;
     cfg.kv_num_blocks = (conc + 2) * (seq_cap / 16);
@@ -116,11 +118,12 @@ int main(int argc, char** argv) {
         r.id = 1 + (uint64_t)i;
         r.prompt.resize(PL);
         for (int t = 0; t < PL; t++) r.prompt[t] = 256u + (uint32_t)(splitmix(seed) % (uint64_t)(cfg.vocab - 256));
+        r.out_len = jitter ? OL - jitter + (int)(splitmix(seed) % (uint64_t)(2 * jitter + 1)) : OL;
         pending.push_back(std::move(r));
     }
     std::vector<Request> running, finished;
     std::vector<FerrumHipBatchItem> items;
-    std::vector<uint32_t> sampled((size_t)conc * std::max(OL, 1));
+    std::vector<uint32_t> sampled((size_t)conc * (size_t)(OL + jitter));
     std::vector<uint64_t> ids;
     std::vector<uint32_t> toks;
     long iterations = 0, graph_steps = 0, mixed_iterations = 0, out_tokens = 0;
@@ -129,7 +132,7 @@ int main(int argc, char** argv) {
     while (!pending.empty() || !running.empty()) {
         // admission: closed loop — a client submits as soon as a slot AND the KV footprint of a whole request are free
         while ((int)running.size() < conc && !pending.empty()) {
-            FerrumHipKvSlotRequest rq{pending.front().id, PL + OL, 0};
+            FerrumHipKvSlotRequest rq{pending.front().id, PL + pending.front().out_len, 0};
             FerrumHipKvSlotReservation rs;
             if (ferrum_hip_model_reserve_kv_slots(model, &rq, 1, &rs) != 0) break;      // pool full: retry after a retirement
             pending.front().t_submit = now_s();
@@ -146,8 +149,8 @@ int main(int argc, char** argv) {
         if (!any_prefill) {
             // pure decode: hipGraph replay for as many steps as nothing can change the batch (no retirement before the
             // shortest remaining output is done; admission only follows a retirement)
-            int steps = OL;
-            for (const Request& r : running) steps = std::min(steps, OL - r.generated);
+            int steps = OL + jitter;
+            for (const Request& r : running) steps = std::min(steps, r.out_len - r.generated);
             ids.clear(); toks.clear();
             for (const Request& r : running) { ids.push_back(r.id); toks.push_back(r.last_token); }
             const int n = (int)running.size();
@@ -205,7 +208,7 @@ int main(int argc, char** argv) {
         }
         // retirement
         for (size_t i = 0; i < running.size();) {
-            if (running[i].generated >= OL) {
+            if (running[i].generated >= running[i].out_len) {
                 CHECK(ferrum_hip_model_release(model, running[i].id));
                 finished.push_back(std::move(running[i]));
                 running.erase(running.begin() + (long)i);
@@ -222,10 +225,10 @@ int main(int argc, char** argv) {
     FerrumHipKvSlotReservation cap;
     CHECK(ferrum_hip_model_kv_capacity_snapshot(model, &cap));
     std::printf("{\"driver\": \"ferrum_hip_serve (C++ over the C ABI)\", \"model\": \"%s\", \"layers\": %d, \"requests\": %d, "
-                "\"concurrency\": %d, \"prompt_len\": %d, \"out_len\": %d, \"max_batched_tokens\": %d, \"output_tokens\": %ld, "
+                "\"concurrency\": %d, \"prompt_len\": %d, \"out_len\": %d, \"max_batched_tokens\": %d, \"out_len_jitter\": %d, \"output_tokens\": %ld, "
                 "\"wall_s\": %.4f, \"output_tok_s\": %.1f, \"ttft_ms_p50\": %.2f, \"ttft_ms_p99\": %.2f, \"iterations\": %ld, "
                 "\"mixed_iterations\": %ld, \"graph_decode_steps\": %ld, \"kv_blocks_total\": %d, \"kv_blocks_free_at_exit\": %d}\n",
-                dense ? "llama31-8b" : "qwen3-30b-a3b", layers, num_requests, conc, PL, OL, budget, out_tokens, wall,
+                dense ? "llama31-8b" : "qwen3-30b-a3b", layers, num_requests, conc, PL, OL, budget, jitter, out_tokens, wall,
                 (double)out_tokens / wall, ttft[ttft.size() / 2], ttft[std::min(ttft.size() - 1, ttft.size() * 99 / 100)],
                 iterations, mixed_iterations, graph_steps, cap.total_blocks, cap.free_blocks_after);
     if (dump) {

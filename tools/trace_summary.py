@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel summary of the largest forward in a rocprofv3 --kernel-trace sqlite/csv output (development aid).
-Usage: trace_summary.py <results.db> [min_launches]"""
+Usage: trace_summary.py <results.db> [min_launches] [segment_index]"""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1]); c = db.cursor()
 tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
@@ -13,7 +13,8 @@ for r in rows[1:]:
 segs.append(cur)
 minl = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 big = [s for s in segs if len(s) > minl]
-s = big[min(2, len(big) - 1)]
+print('segments (launches, wall us):', [(len(x), round((x[-1][2] - x[0][1]) / 1e3)) for x in big])
+s = big[int(sys.argv[3])] if len(sys.argv) > 3 else big[min(2, len(big) - 1)]
 agg = {}
 for r in s:
     n = re.sub(r'\(.*', '', r[0]).replace('void ', '')
