@@ -442,7 +442,10 @@ __device__ __forceinline__ bool inline_align_block(const int* s_ids, int P, int 
 // cover the chip and each streams its 64 KiB at one group per memory round trip; with KW = 4 every wave takes a quarter
 // of K (all its groups in flight) and the partial sums meet in LDS — c=1 gate_up 11.8 → ≈6 µs.  Each wave runs the
 // (cheap) routing prologue on its own LDS slice, so no cross-wave protocol is needed before the reduce.
-template <int MT, bool HAS_ZP, int MODE, int KW = 1>
+// RT (MoE only): the routing prologue (candidate merge / align) runs inside the launch and owns ≈ 12 KiB of LDS per
+// workgroup; with explicit align arrays (RT = false) no LDS is allocated, so 25 one-wave workgroups per CU stay resident
+// instead of 13 (prefill-side batches of a few hundred tokens launch ≈ 6500 of them).
+template <int MT, bool HAS_ZP, int MODE, int KW = 1, bool RT = true>
 __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Args p) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
@@ -470,14 +473,14 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
     } else {
         // MoE: one 16-row block of sorted pair ids, all of one expert.
         // LDS: raw[0..8K) holds the route candidates during the merge, then (first 2 KB) the histogram
-        __shared__ __attribute__((aligned(16))) unsigned char s_raw_all[KW][KW == 1 ? 8192 : 2048];
-        __shared__ int s_ids_all[KW][KW == 1 ? 1024 : 64], s_rows_all[KW][16];
-        unsigned char* s_raw = s_raw_all[KW == 1 ? 0 : wave];
-        int* s_ids = s_ids_all[KW == 1 ? 0 : wave];
-        int* s_rows = s_rows_all[KW == 1 ? 0 : wave];
-        int* s_cnt = reinterpret_cast<int*>(s_raw);
         int e, id;
-        if (p.cand || p.pair_expert_ids) {
+        if constexpr (RT) {
+            __shared__ __attribute__((aligned(16))) unsigned char s_raw_all[KW][KW == 1 ? 8192 : 2048];
+            __shared__ int s_ids_all[KW][KW == 1 ? 1024 : 64], s_rows_all[KW][16];
+            unsigned char* s_raw = s_raw_all[KW == 1 ? 0 : wave];
+            int* s_ids = s_ids_all[KW == 1 ? 0 : wave];
+            int* s_rows = s_rows_all[KW == 1 ? 0 : wave];
+            int* s_cnt = reinterpret_cast<int*>(s_raw);
             const bool publisher = blockIdx.x == 0 && rb == 0 && wave == 0;
             if (KW == 1 && p.cand) {
                 merge_route_candidates(p.cand, p.stats, p.route_T, p.route_Q, p.route_K, p.norm_topk,
@@ -1506,10 +1509,15 @@ static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_
     if constexpr (MODE != 0) {
         // few pairs (decode at c ≤ 8): 4 waves per workgroup split K (see KW); the candidate-merge prologue keeps KW = 1
         static const int kw_pairs = getenv("FERRUM_HIP_MOE_KW_PAIRS") ? atoi(getenv("FERRUM_HIP_MOE_KW_PAIRS")) : 8;   // measured: c=1 +10 %, c ≥ 4 slightly slower
-        if (a.M <= kw_pairs && a.cand == nullptr && a.G >= 4) {
-            if (has_zp) hipLaunchKernelGGL((w4_gemm_kernel<1, true, MODE, 4>), grid, dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((w4_gemm_kernel<1, false, MODE, 4>), grid, dim3(256), 0, stream, a);
-        } else if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false);
+        const bool rt = a.cand != nullptr || a.pair_expert_ids != nullptr;      // routing prologue inside the launch (owns LDS)
+        const bool kw4 = a.M <= kw_pairs && a.cand == nullptr && a.G >= 4;
+#define FH_W4_MOE(ZPV, KWV, RTV) hipLaunchKernelGGL((w4_gemm_kernel<1, ZPV, MODE, KWV, RTV>), grid, dim3(64 * KWV), 0, stream, a)
+#define FH_W4_MOE_ZP(ZPV)                                                                    \
+        if (kw4) { if (rt) FH_W4_MOE(ZPV, 4, true); else FH_W4_MOE(ZPV, 4, false); }         \
+        else { if (rt) FH_W4_MOE(ZPV, 1, true); else FH_W4_MOE(ZPV, 1, false); }
+        if (has_zp) { FH_W4_MOE_ZP(true) } else { FH_W4_MOE_ZP(false) }
+#undef FH_W4_MOE_ZP
+#undef FH_W4_MOE
     } else {
         if (mt == 1) { if (has_zp) FH_W4_CASE(1, true); else FH_W4_CASE(1, false); }
         else if (mt == 2) { if (has_zp) FH_W4_CASE(2, true); else FH_W4_CASE(2, false); }
