@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
     const int PL = arg_int(argc, argv, "--prompt-len", 256);
     const int OL = arg_int(argc, argv, "--out-len", 128);
     const int budget = arg_int(argc, argv, "--max-batched-tokens", 8192);
+    const int kv_blocks = arg_int(argc, argv, "--kv-blocks", 0);      // 0: room for concurrency + 2 whole requests; smaller pools make admission wait
     const int jitter = arg_int(argc, argv, "--out-len-jitter", 0);   // output lengths uniform in [OL − jitter, OL + jitter]: staggers retirements
     const int dense = arg_flag(argc, argv, "--dense");          // Llama-3.1-8B dims instead of Qwen3-30B-A3B
     const bool dump = arg_flag(argc, argv, "--dump-tokens");
@@ -101,7 +102,7 @@ int main(int argc, char** argv) {
     const int seq_cap = ((PL + OL + jitter + 15) / 16) * 16;
     cfg.max_seq_len = seq_cap;
     cfg.group_size = 128;
-    cfg.kv_num_blocks = (conc + 2) * (seq_cap / 16);
+    cfg.kv_num_blocks = kv_blocks > 0 ? kv_blocks : (conc + 2) * (seq_cap / 16);
     cfg.max_seqs = conc;
     cfg.max_tokens = budget;
     cfg.rms_eps = 1e-6f;

@@ -43,3 +43,11 @@ def test_bench_serve_shape_quick():
     r, _ = _run("--layers", 4, "--requests", 64, "--concurrency", 32)
     assert r["output_tokens"] == 64 * 128 and r["kv_blocks_free_at_exit"] == r["kv_blocks_total"]
     assert r["graph_decode_steps"] >= 2 * 127
+
+
+def test_admission_waits_for_kv_blocks():
+    """A KV pool with room for 3 whole requests under concurrency 8: reserve_kv_slots refuses (atomically) until a request
+    retires; the loop must still finish everything and hand all blocks back."""
+    # 40 + 6 tokens → 3 blocks per request; 10 blocks ⇒ at most 3 requests in flight
+    r, _ = _run("--layers", 2, "--requests", 9, "--concurrency", 8, "--prompt-len", 40, "--out-len", 6, "--kv-blocks", 10)
+    assert r["output_tokens"] == 9 * 6 and r["kv_blocks_total"] == 10 and r["kv_blocks_free_at_exit"] == 10
