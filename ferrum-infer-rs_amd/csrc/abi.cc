@@ -312,16 +312,16 @@ int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input,
                                   void* stream) {
     FH_REQUIRE(stack && input && sorted_token_ids && expert_ids && num_tokens_past_padded && output,
                "moe_gemm_phase: null argument");
-    if (moe_block_size != 16 && moe_block_size != 64) {
-        fh::set_error("moe_gemm_phase: moe_block_size=%d unsupported (16 or 64)", moe_block_size);
+    if (moe_block_size != 16 && moe_block_size != 32 && moe_block_size != 64) {
+        fh::set_error("moe_gemm_phase: moe_block_size=%d unsupported (16, 32 or 64)", moe_block_size);
         return FERRUM_HIP_UNSUPPORTED;
     }
     FH_REQUIRE(top_k >= 1, "moe_gemm_phase: top_k=%d", top_k);
     FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase: fused epilogue needs a stack loaded with fuse_gate_up");
     FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase: stack was loaded with fuse_gate_up; plain output is column-permuted");
-    if (moe_block_size == 64)   // prefill-sized batches: 64-row LDS tiles
+    if (moe_block_size == 64 || moe_block_size == 32)   // prefill-sized batches: 64- or 32-row LDS tiles
         return w4_gemm_moe_tile(stack->dev, CH(input), H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
-                                max_blocks, top_k, fused_silu_mul, ST(stream));
+                                max_blocks, moe_block_size, top_k, fused_silu_mul, ST(stream));
     return w4_gemm_moe(stack->dev, CH(input), H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
                        max_blocks, top_k, fused_silu_mul, ST(stream));
 }

@@ -36,11 +36,12 @@ int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* q
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream);
 int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids, const int32_t* block_ids,
-                     const int32_t* total_post_pad, int num_valid_pairs, int max_blocks64, int top_k, int fused_silu,
+                     const int32_t* total_post_pad, int num_valid_pairs, int max_blocks, int block_rows, int top_k, int fused_silu,
                      hipStream_t stream);
 int w4_gemm_dense_lds_splits(const W4Device& w, int m);
 int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_inout,
                             int* rows_pad_out, int* n_pad_out, hipStream_t stream);
+
 int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids,
                 const int32_t* block_ids, const int32_t* total_post_pad, int num_valid_pairs,
                 int max_blocks, int top_k, int fused_silu, hipStream_t stream);

@@ -304,6 +304,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_ROUTE_GEMM_TOKENS")) m->route_gemm_min_tokens = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_MOE_TILE32_PAIRS")) m->moe_tile32_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
     return 0;
 }
@@ -944,9 +945,19 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
                     RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
                     RUN(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                         max_blocks64, K, 1, s));
+                                         max_blocks64, 64, K, 1, s));
                     RUN(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                         max_blocks64, 1, 0, s));
+                                         max_blocks64, 64, 1, 0, s));
+                } else if (P >= m->moe_tile32_min_pairs_per_expert * E) {
+                    // a few hundred tokens (a fresh prompt riding along with the decode batch, a lone short prefill: 8–31 pairs
+                    // per expert): 32-row blocks through the LDS-tiled kernel — every expert's weights about once instead of
+                    // once per 16 pairs
+                    const int sorted_max32 = P + E * 32, max_blocks32 = std::min(sorted_max32 / 32, P / 32 + std::min(P, E));
+                    RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 32, sorted_max32, s));
+                    RUN(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                         max_blocks32, 32, K, 1, s));
+                    RUN(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                         max_blocks32, 32, 1, 0, s));
                 } else {
                     RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
                     RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,

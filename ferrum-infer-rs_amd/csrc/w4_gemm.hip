@@ -1044,12 +1044,15 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
 // tiles (80 MFMAs per 4 KiB of weights instead of 20).  MODE 1 plain, 2 gate_up with the fused silu·mul epilogue.  Same
 // arithmetic as w4_consume_group (exact integer-valued products, fp32 scale), restructured k-pair-major to hold 250 VGPRs.
 // (The dense M ≥ 64 GEMM uses the hand-pipelined w4_gemm_tilep_kernel below.)
-template <bool HAS_ZP, int MODE>
+// MTN = 16-row tiles per block: 4 (64-pair align blocks, ≥ 32 pairs per expert) or 2 (32-pair blocks: a few hundred
+// tokens, e.g. a fresh prompt riding along with the decode batch — half the MFMA padding and the LDS traffic per block).
+template <bool HAS_ZP, int MODE, int MTN = 4>
 __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
+    constexpr int ROWS = 16 * MTN;
     static_assert(MODE == 1 || MODE == 2, "grouped-GEMM modes only");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][4 mt][4 s][64] half8 = 2 × 16 KiB
-    constexpr int FR = 1024;
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][MTN mt][4 s][64] half8 = 2 × MTN·4 KiB
+    constexpr int FR = MTN * 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
     const int st_raw = blockIdx.x * 4 + wave;
@@ -1062,39 +1065,39 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     const __half* zp = p.zp;
     // rows of this tile: fragment loads are split by wave (k-step s = wave), so every thread needs the 4 rows
     // mt·16 + b of its lane; the epilogue needs rows mt·16 + 4a + r
-    int row_in[4], row_out_l[4];
+    int row_in[MTN], row_out_l[MTN];
     {
         const int total = *p.total_post_pad;
-        if (rb * 64 >= total) return;
+        if (rb * ROWS >= total) return;
         const int e = p.block_ids[rb];
         qw += (long)e * p.expert_stride_qw;
         sc += (long)e * p.expert_stride_sc;
         if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
-            const int id = p.sorted_token_ids[rb * 64 + mt * 16 + b];
+        for (int mt = 0; mt < MTN; mt++) {
+            const int id = p.sorted_token_ids[rb * ROWS + mt * 16 + b];
             row_out_l[mt] = id < p.M ? id : -1;
             row_in[mt] = id < p.M ? id / p.top_k : 0;
         }
     }
-    const __half* asrc[4];
+    const __half* asrc[MTN];
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++) asrc[mt] = p.x + (long)row_in[mt] * p.K + 32 * wave + 8 * a;
+    for (int mt = 0; mt < MTN; mt++) asrc[mt] = p.x + (long)row_in[mt] * p.K + 32 * wave + 8 * a;
 
     typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
     const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(qw) + ((long)st * p.G * 4) * 64 + lane;
     const uint2* sc_lane = reinterpret_cast<const uint2*>(sc) + ((long)st * p.G) * 16 + b;
     const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(zp) + ((long)st * p.G) * 16 + b : nullptr;
 
-    float4v acc[4][4];
+    float4v acc[MTN][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int mt = 0; mt < MTN; mt++)
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
 
     u32x4g wq[2][4];
     uint2 scv[2], zpv[2];
-    half8 areg[4];
+    half8 areg[MTN];
     auto issue_w = [&](int slot, int g) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
@@ -1103,11 +1106,11 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     };
     auto issue_a = [&](int g) {
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) areg[mt] = *reinterpret_cast<const half8*>(asrc[mt] + (long)g * 128);
+        for (int mt = 0; mt < MTN; mt++) areg[mt] = *reinterpret_cast<const half8*>(asrc[mt] + (long)g * 128);
     };
     auto store_a = [&](int buf) {   // fragment (mt, s = wave, lane)
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) lds_a[buf * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];
+        for (int mt = 0; mt < MTN; mt++) lds_a[buf * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];
     };
     // low nibbles land in mantissa bits 0-3 of 0x6400 (1024 + n), high nibbles in bits 4-7 of 0x5400 (64 + n): both
     // expansions are integer-valued, so no operand needs rescaling (the vector issue port is what bounds this kernel)
@@ -1137,7 +1140,7 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
         const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
         const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
 #pragma unroll
-        for (int mt = 0; mt < 4; mt++) {
+        for (int mt = 0; mt < MTN; mt++) {
             half8 af[4];
 #pragma unroll
             for (int s = 0; s < 4; s++) af[s] = at[(mt * 4 + s) * 64 + lane];
@@ -1204,7 +1207,7 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     if (!st_ok) return;
     // epilogue: D row 4a + r of tile mt ↔ tile row mt·16 + 4a + r, whose routing lives in lane (·, b = 4a + r)
 #pragma unroll
-    for (int mt = 0; mt < 4; mt++)
+    for (int mt = 0; mt < MTN; mt++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int orow = __shfl(row_out_l[mt], 4 * a + r, 64);
@@ -1473,11 +1476,11 @@ static int launch_tilep(const W4Args& a, bool has_zp, dim3 grid, hipStream_t str
     return 0;
 }
 
-template <int MODE>
+template <int MODE, int MTN>
 static int launch_tile(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
-    const size_t lds = (size_t)2 * 1024 * 16;
-    if (has_zp) hipLaunchKernelGGL((w4_gemm_tile_kernel<true, MODE>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((w4_gemm_tile_kernel<false, MODE>), grid, dim3(256), lds, stream, a);
+    const size_t lds = (size_t)2 * MTN * 256 * 16;
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_tile_kernel<true, MODE, MTN>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_tile_kernel<false, MODE, MTN>), grid, dim3(256), lds, stream, a);
     FH_CHECK_LAUNCH();
     return 0;
 }
@@ -1776,9 +1779,10 @@ int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* 
 // MoE grouped GEMM over 64-row blocks (moe_align_block_size with block 64): prefill-sized batches, where an expert sees
 // tens to hundreds of pairs and the 16-row kernel would re-stream its weights once per 16 pairs.
 int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids, const int32_t* block_ids,
-                     const int32_t* total_post_pad, int num_valid_pairs, int max_blocks64, int top_k, int fused_silu,
+                     const int32_t* total_post_pad, int num_valid_pairs, int max_blocks, int block_rows, int top_k, int fused_silu,
                      hipStream_t stream) {
-    if (num_valid_pairs <= 0 || max_blocks64 <= 0) return 0;
+    if (num_valid_pairs <= 0 || max_blocks <= 0) return 0;
+    FH_REQUIRE(block_rows == 64 || block_rows == 32, "w4_gemm_moe_tile: block_rows=%d (64 or 32)", block_rows);
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
     a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
@@ -1788,9 +1792,10 @@ int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int3
     a.S = 1;
     a.sorted_token_ids = sorted_token_ids; a.block_ids = block_ids; a.total_post_pad = total_post_pad;
     a.top_k = top_k;
-    dim3 grid(cdiv(w.n64, 4), max_blocks64, 1);
-    if (fused_silu) return launch_tile<2>(a, w.zp != nullptr, grid, stream);
-    return launch_tile<1>(a, w.zp != nullptr, grid, stream);
+    dim3 grid(cdiv(w.n64, 4), max_blocks, 1);
+    const bool zp = w.zp != nullptr;
+    if (block_rows == 64) return fused_silu ? launch_tile<2, 4>(a, zp, grid, stream) : launch_tile<1, 4>(a, zp, grid, stream);
+    return fused_silu ? launch_tile<2, 2>(a, zp, grid, stream) : launch_tile<1, 2>(a, zp, grid, stream);
 }
 
 // ───────────────────────── fp16 skinny GEMM (router, lm_head) ───────────────

@@ -657,22 +657,22 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
         B.moe_combine(ctx, down, wd, out, tokens, K, H)
         ctx.sync()
         assert nmse(ref, host(out)) < 3e-6, fused            # three fp16 roundings (act, down, out)
-        if fused and P >= 64:
-            # 64-row blocks through the prefill tile kernel: same maths, different block shape
-            sd64 = torch.empty(P + E * 64, dtype=torch.int32, device="cuda")
-            bd64 = torch.empty((P + E * 64) // 64 + 1, dtype=torch.int32, device="cuda")
-            td64 = torch.zeros(1, dtype=torch.int32, device="cuda")
-            B.moe_align_block_size_pair_ids(ctx, ids_d, sd64, bd64, td64, P, E, 64, P + E * 64)
-            mb64 = (P + E * 64) // 64
-            act64 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
-            down64 = torch.zeros(P, H, dtype=torch.float16, device="cuda")
-            stack.gemm_phase_vllm(ctx, xd, sd64, bd64, td64, act64, P, 64, K, mb64, fused_silu_mul=True)
-            down_stack.gemm_phase_vllm(ctx, act64, sd64, bd64, td64, down64, P, 64, 1, mb64)
-            out64 = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
-            B.moe_combine(ctx, down64, wd, out64, tokens, K, H)
+        for blk in ((64, 32) if fused and P >= 64 else ()):
+            # 64- and 32-row blocks through the prefill tile kernel: same maths, different block shape
+            sdb = torch.empty(P + E * blk, dtype=torch.int32, device="cuda")
+            bdb = torch.empty((P + E * blk) // blk + 1, dtype=torch.int32, device="cuda")
+            tdb = torch.zeros(1, dtype=torch.int32, device="cuda")
+            B.moe_align_block_size_pair_ids(ctx, ids_d, sdb, bdb, tdb, P, E, blk, P + E * blk)
+            mbb = (P + E * blk) // blk
+            actb = torch.zeros(P, I, dtype=torch.float16, device="cuda")
+            downb = torch.zeros(P, H, dtype=torch.float16, device="cuda")
+            stack.gemm_phase_vllm(ctx, xd, sdb, bdb, tdb, actb, P, blk, K, mbb, fused_silu_mul=True)
+            down_stack.gemm_phase_vllm(ctx, actb, sdb, bdb, tdb, downb, P, blk, 1, mbb)
+            outb = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+            B.moe_combine(ctx, downb, wd, outb, tokens, K, H)
             ctx.sync()
-            assert torch.equal(act64, act)                       # per-row sums are independent of the block shape
-            assert nmse(ref, host(out64)) < 3e-6
+            assert torch.equal(actb, act), blk                   # per-row sums are independent of the block shape
+            assert nmse(ref, host(outb)) < 3e-6, blk
         # expert-major grid straight from the raw expert ids (no align arrays): bit-identical outputs; experts with more
         # than 16 pairs (the 64-token / 8-expert case) take further passes, experts without pairs leave early
         down3 = torch.zeros(P, H, dtype=torch.float16, device="cuda")
