@@ -38,6 +38,8 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
 int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids, const int32_t* block_ids,
                      const int32_t* total_post_pad, int num_valid_pairs, int max_blocks, int block_rows, int top_k, int fused_silu,
                      hipStream_t stream);
+int w4_gemm_dense_slabs_tile(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_out,
+                             int* rows_pad_out, int* n_pad_out, hipStream_t stream);
 int w4_gemm_dense_lds_splits(const W4Device& w, int m);
 int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_inout,
                             int* rows_pad_out, int* n_pad_out, hipStream_t stream);

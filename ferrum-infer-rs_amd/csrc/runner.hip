@@ -812,6 +812,43 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
     return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
 }
 
+// gate_up (+silu·mul) and down grouped GEMMs for any batch size, straight from expert_ids: decode-sized batches (≤ 1024
+// pairs) without a separate align launch, else align + the block shape that fits the pairs per expert.
+#define FH_TRY(call) do { if (int rc_ = (call)) return rc_; } while (0)
+static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted_max, int max_blocks, hipStream_t s) {
+    const FerrumHipModelConfig& c = m->cfg;
+    const int E = c.num_experts, K = c.top_k;
+    if (P <= 1024) {
+        FH_TRY(moe_decode_gemms(m, L, P, max_blocks, s));
+    } else if (P >= m->moe_tile_min_pairs_per_expert * E) {
+        // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
+        const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
+        FH_TRY(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
+        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks64, 64, K, 1, s));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks64, 64, 1, 0, s));
+    } else if (P >= m->moe_tile32_min_pairs_per_expert * E) {
+        // a few hundred tokens (a fresh prompt riding along with the decode batch, a lone short prefill: 8–31 pairs
+        // per expert): 32-row blocks through the LDS-tiled kernel — every expert's weights about once instead of
+        // once per 16 pairs
+        const int sorted_max32 = P + E * 32, max_blocks32 = std::min(sorted_max32 / 32, P / 32 + std::min(P, E));
+        FH_TRY(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 32, sorted_max32, s));
+        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks32, 32, K, 1, s));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks32, 32, 1, 0, s));
+    } else {
+        FH_TRY(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
+        FH_TRY(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                        max_blocks, K, 1, s));
+        FH_TRY(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                        max_blocks, 1, 0, s));
+    }
+    return 0;
+}
+#undef FH_TRY
+
 int dense_linear(FerrumHipModel* m, const W4Device& w, const __half* x, __half* out, int T, hipStream_t s) {
     if (w.perm) {
         FH_REQUIRE(m->gather_scratch, "dense_linear: act-order weights but no gather scratch");
@@ -924,6 +961,17 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
                                                      m->norm_out, T, K, H, s));
                 }
+            } else if (T >= 64 && T < m->route_gemm_min_tokens && c.tp_world == 1 && !L.o.perm && !L.o.bias && m->o_slabs > 0) {
+                // short prefill / a prompt riding along with the decode batch: o_proj as fp32 split-K slabs straight into the
+                // add + norm + route kernel (no reduce launch)
+                int S = 1, rows_pad = 0, n_pad = 0;
+                RUN(w4_gemm_dense_slabs_tile(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+                RUN(fused_add_rms_norm_route_slabs_f16(m->residual, m->o_out, m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
+                                                       c.rms_eps, m->norm_out, L.router, E, K, c.norm_topk_prob, m->expert_ids,
+                                                       m->expert_w, nullptr, T, H, s));
+                RUN(moe_batch_gemms(m, L, P, sorted_max, max_blocks, s));
+                RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
+                                                 m->norm_out, T, K, H, s));
             } else {
                 RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
                 RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
@@ -938,33 +986,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
                                                      c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
                 }
-                if (P <= 1024) {
-                    RUN(moe_decode_gemms(m, L, P, max_blocks, s));
-                } else if (P >= m->moe_tile_min_pairs_per_expert * E) {
-                    // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
-                    const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
-                    RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
-                    RUN(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                         max_blocks64, 64, K, 1, s));
-                    RUN(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                         max_blocks64, 64, 1, 0, s));
-                } else if (P >= m->moe_tile32_min_pairs_per_expert * E) {
-                    // a few hundred tokens (a fresh prompt riding along with the decode batch, a lone short prefill: 8–31 pairs
-                    // per expert): 32-row blocks through the LDS-tiled kernel — every expert's weights about once instead of
-                    // once per 16 pairs
-                    const int sorted_max32 = P + E * 32, max_blocks32 = std::min(sorted_max32 / 32, P / 32 + std::min(P, E));
-                    RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 32, sorted_max32, s));
-                    RUN(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                         max_blocks32, 32, K, 1, s));
-                    RUN(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                         max_blocks32, 32, 1, 0, s));
-                } else {
-                    RUN(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
-                    RUN(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                    max_blocks, K, 1, s));
-                    RUN(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
-                                    max_blocks, 1, 0, s));
-                }
+                RUN(moe_batch_gemms(m, L, P, sorted_max, max_blocks, s));
                 RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
                                                  m->norm_out, T, K, H, s));
             }

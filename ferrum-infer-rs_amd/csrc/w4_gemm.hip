@@ -1719,6 +1719,30 @@ int w4_gemm_dense_slabs(const W4Device& w, const __half* x, float* slabs, size_t
     return launch_w4_slabs(a, mt, w.zp != nullptr, dim3(cdiv(w.n64, 4), row_blocks, S), stream);
 }
 
+// Dense projection for ≥ 64 rows as S fp32 slabs through the pipelined tile kernel (S as w4_gemm_dense would pick it); the
+// consumer kernel sums the slabs in order, so the reduce launch disappears (short prefills: o_proj → add + norm + route).
+int w4_gemm_dense_slabs_tile(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_out,
+                             int* rows_pad_out, int* n_pad_out, hipStream_t stream) {
+    if (m <= 0) return 0;
+    FH_REQUIRE(m >= 64 && w.perm == nullptr && w.bias == nullptr, "w4_gemm_dense_slabs_tile: m=%d / act-order / bias use the direct path", m);
+    W4Args a{};
+    a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
+    a.x = x; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n;
+    const int cols = cdiv(w.n64, 4), rts = cdiv(m, 64);
+    int S = 1;
+    while ((long)cols * rts * S < 256 && w.G / (S * 2) >= 8) S *= 2;
+    a.rows_pad = rts * 64;
+    a.n_pad = w.n64 * 64;
+    while (S > 1 && (size_t)S * a.rows_pad * a.n_pad * sizeof(float) > slab_bytes) S /= 2;
+    FH_REQUIRE((size_t)S * a.rows_pad * a.n_pad * sizeof(float) <= slab_bytes, "w4_gemm_dense_slabs_tile: workspace too small");
+    a.S = S;
+    a.partial = slabs;
+    *S_out = S;
+    *rows_pad_out = a.rows_pad;
+    *n_pad_out = a.n_pad;
+    return launch_tilep(a, w.zp != nullptr, dim3(cols, rts, S), stream);
+}
+
 // Split count the LDS-shared-activation kernel wants for this shape (tools/exp_dense.py sweeps): enough workgroups to
 // cover the chip (≥ 128–256 of 4 waves) while every split keeps ≥ 8 quant groups.
 int w4_gemm_dense_lds_splits(const W4Device& w, int m) {
