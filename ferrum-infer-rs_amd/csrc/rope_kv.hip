@@ -30,9 +30,16 @@ __global__ __launch_bounds__(64) void split_qkv_norm_rope_paged_kernel(
     const int q_dim = q_heads * HD, kv_dim = kv_heads * HD;
     const __half* row = qkv + (long)tok * (q_dim + 2 * kv_dim);
 
-    // locate the sequence (cu_seqlens_q is a short prefix sum; same scan as the reference kernel)
+    // locate the sequence: the last s with cu_seqlens_q[s] ≤ tok (what the reference kernel's linear scan returns), found
+    // 64 sequences per memory round trip — a serial scan costs the tokens of the 32nd prompt 31 dependent loads
     int seq = 0;
-    while (seq + 1 < num_seqs && (uint32_t)tok >= cu_seqlens_q[seq + 1]) seq++;
+    for (int s0 = 0; s0 < num_seqs; s0 += 64) {
+        const int s = s0 + lane;
+        const unsigned long long le = __ballot(s < num_seqs && cu_seqlens_q[s] <= (uint32_t)tok);
+        if (le == 0) break;
+        seq = s0 + 63 - __clzll((long long)le);
+        if (le != ~0ull) break;
+    }
     const int pos = (int)pos_offsets[seq] + (tok - (int)cu_seqlens_q[seq]);
 
     const bool is_q = head < q_heads;
