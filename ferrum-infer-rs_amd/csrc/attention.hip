@@ -280,8 +280,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
             sc[4 + r] = ok1 ? s1[r] * p.scale : -INFINITY;
             mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_reduce_max(mx);
         const float m_new = fmaxf(m_run, mx);
         const float m_safe = m_new == -INFINITY ? 0.f : m_new;
         const float alpha = __expf(m_run - m_safe);      // m_run = -inf → 0
@@ -293,8 +292,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
             psum += pv;
             pf[j] = (_Float16)pv;
         }
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
+        psum = rows_reduce_sum(psum);
         l_run = l_run * alpha + psum;
         m_run = m_new;
         // Oᵀ[d][row] += Vᵀ[d][key]·Pᵀ[key][row]; contraction index (a,j): j<4 block0 key 4a+j, else block1
@@ -383,6 +381,242 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
     for (int i = 0; i < DPT; i++) o[i] = __float2half(ov[i] * inv);
 }
 
+// ── prefill attention with the K/V tiles of a block pair staged ONCE per workgroup in LDS (flash form) ───────────────────
+// The forms above pull every K/V fragment from L2 once per 16-row tile: at long prompts that is the whole cost (one 8192-token
+// prompt: 2.6 ms per layer, ≈ 210 TFLOP/s).  Here a workgroup owns NW·MT = 8 (HD ≤ 128) consecutive row tiles of one sequence
+// and one kv head — 128 query rows, i.e. 16 tokens × 8 heads of the GQA group — and walks their common key range pair by pair:
+// wave w copies tile w of the pair (K block 0, K block 1, V block 0, V block 1: one 16·HD-element tile each, the same
+// fragment-shaped bytes the other forms load) into a double-buffered LDS stage while the previous pair is consumed; every wave
+// then reads the fragments with ds_read_b128 and runs them against ITS MT row tiles (the per-row arithmetic is the KV-split
+// form's: Sᵀ = K·Qᵀ, lane-local online softmax, Oᵀ += Vᵀ·Pᵀ).  One barrier per pair; L2 traffic per query row ÷ 8.
+template <int HD, int MT>
+__global__ __launch_bounds__(256, HD <= 128 ? 2 : 1) void paged_prefill_attn_kernel(AttnArgs p) {
+    constexpr int NW = 4, DT = HD / 16, KS = HD / 32, TILE = 16 * HD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half* lds_kv = reinterpret_cast<__half*>(smem);          // [2 stages][K0, K1, V0, V1][TILE]; reused by the epilogue
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int kvh = blockIdx.y;
+    const int G = p.nq / p.nkv;
+    // (sequence, unit of NW·MT row tiles) of this workgroup: scan of cu_seqlens_q, 64 sequences per pass
+    int seq = -1, unit = 0;
+    {
+        const int w = blockIdx.x;
+        int base = 0;
+        for (int s0 = 0; s0 < p.num_seqs; s0 += 64) {
+            const int s = s0 + lane;
+            int units = 0;
+            if (s < p.num_seqs) {
+                const int tiles = ((int)(p.cu_seqlens_q[s + 1] - p.cu_seqlens_q[s]) * G + 15) >> 4;
+                units = (tiles + NW * MT - 1) / (NW * MT);
+            }
+            int incl = units;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (w < base + total) {
+                const unsigned long long hit = __ballot(w < base + incl);
+                const int src = __ffsll((long long)hit) - 1;
+                seq = s0 + src;
+                unit = w - (base + __shfl(incl - units, src, 64));
+                break;
+            }
+            base += total;
+        }
+        if (seq < 0) return;                       // whole workgroup (the scan is wave-uniform and identical in every wave)
+    }
+    const int tok0 = (int)p.cu_seqlens_q[seq];
+    const int q_len = (int)p.cu_seqlens_q[seq + 1] - tok0;
+    const int rows_total = q_len * G, tiles_s = (rows_total + 15) >> 4;
+    const int pos0 = (int)p.pos_offsets[seq];
+
+    // this wave's MT row tiles; lane column b ↔ query row
+    int row_pos[MT], win_lo[MT];
+    bool row_ok[MT];
+    int vis_hi[MT], vis_lo[MT];      // keys in [vis_lo, vis_hi] are visible to EVERY row of the tile (−1: never take the fast path)
+    half8 qf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int tile = (unit * NW + wave) * MT + mt;
+        const bool full = tile * 16 + 15 < rows_total;
+        const int tmin = pos0 + (tile * 16) / G, tmax = pos0 + (tile * 16 + 15) / G;     // first / last token position of the tile
+        vis_hi[mt] = full ? tmin : -1;
+        vis_lo[mt] = p.sliding_window > 0 ? max(0, tmax + 1 - p.sliding_window) : 0;
+        const int rho = tile * 16 + b;
+        row_ok[mt] = rho < rows_total;
+        const int t_local = row_ok[mt] ? rho / G : 0, g = row_ok[mt] ? rho % G : 0;
+        row_pos[mt] = pos0 + t_local;
+        win_lo[mt] = p.sliding_window > 0 ? max(0, row_pos[mt] + 1 - p.sliding_window) : 0;
+        const long q_off = ((long)(tok0 + t_local) * p.nq + kvh * G + g) * HD;
+#pragma unroll
+        for (int s = 0; s < KS; s++) qf[mt][s] = *reinterpret_cast<const half8*>(p.q + q_off + 32 * s + 8 * a);
+    }
+    // key range common to the workgroup's rows
+    const int tile_first = unit * NW * MT, tile_last = min(tile_first + NW * MT, tiles_s) - 1;
+    const int t_first = (tile_first * 16) / G, t_last = min(q_len - 1, (tile_last * 16 + 15) / G);
+    const int kv_end = pos0 + t_last + 1;
+    const int kv_begin = p.sliding_window > 0 ? max(0, pos0 + t_first + 1 - p.sliding_window) : 0;
+    const int pair_lo = (kv_begin / KV_BLOCK) / 2, pair_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;
+    const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
+
+    // staging: wave w moves tile w of a pair (0: K block 0, 1: K block 1, 2: V block 0, 3: V block 1)
+    const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
+    int bt_lo = 2 * pair_lo;
+    int btv = bt[min(bt_lo + lane, p.max_blocks - 1)];
+    const __half* pool = wave < 2 ? p.k_pool : p.v_pool;
+    half8 st[KS];
+    auto issue = [&](int pr) {
+        int blk = 2 * pr + (wave & 1);
+        if (blk >= nblocks) blk = 2 * pr;                // odd tail: a copy of block 0, masked below
+        if (2 * pr + 1 - bt_lo >= 64) {                  // wave-uniform: next chunk of the table
+            bt_lo = 2 * pr;
+            btv = bt[min(bt_lo + lane, p.max_blocks - 1)];
+        }
+        const long phys = __builtin_amdgcn_readlane(btv, blk - bt_lo);
+        const __half* src = pool + (phys * p.nkv + kvh) * (long)TILE + lane * 8;
+#pragma unroll
+        for (int s = 0; s < KS; s++) st[s] = *reinterpret_cast<const half8*>(src + s * 512);
+    };
+    auto stash = [&](int stage) {
+        __half* dst = lds_kv + (stage * 4 + wave) * TILE + lane * 8;
+#pragma unroll
+        for (int s = 0; s < KS; s++) *reinterpret_cast<half8*>(dst + s * 512) = st[s];
+    };
+
+    const float sl2 = p.scale * 1.4426950408889634f;
+    float m_run[MT], l_run[MT];            // running maximum (log2 units) and sum per row
+    float4v o_acc[MT][DT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        m_run[mt] = -INFINITY;
+        l_run[mt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) o_acc[mt][dt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    }
+    if (pair_lo < pair_hi) {
+        issue(pair_lo);
+        stash(0);
+    }
+    __syncthreads();
+    for (int pr = pair_lo; pr < pair_hi; pr++) {
+        const int cur = (pr - pair_lo) & 1;
+        const bool more = pr + 1 < pair_hi;
+        if (more) issue(pr + 1);
+        __builtin_amdgcn_sched_barrier(0);               // keep the global requests ahead of this pair's work
+        const __half* kb = lds_kv + (cur * 4) * TILE + lane * 8;
+        const int blk0 = 2 * pr, blk1 = 2 * pr + 1;
+        const bool has1 = blk1 < nblocks;
+        // Sᵀ[key][row] of both blocks for every row tile; K fragments are read once per k-step
+        float4v s0[MT], s1[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) { s0[mt] = (float4v){0.f, 0.f, 0.f, 0.f}; s1[mt] = (float4v){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const half8 k0 = *reinterpret_cast<const half8*>(kb + s * 512);
+            const half8 k1 = *reinterpret_cast<const half8*>(kb + TILE + s * 512);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                s0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k0, qf[mt][s], s0[mt], 0, 0, 0);
+                s1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(k1, qf[mt][s], s1[mt], 0, 0, 0);
+            }
+        }
+        half8 pf[MT];
+        float alpha[MT];
+        bool rescale[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            // scores in log2 units (scale·log2 e folded into one multiply; exp2 is the native instruction)
+            float sc[8];
+            float mx = -INFINITY;
+            if (blk1 * KV_BLOCK + KV_BLOCK - 1 <= vis_hi[mt] && blk0 * KV_BLOCK >= vis_lo[mt]) {
+                // both blocks lie below the causal diagonal (and inside the window) of every row of the tile: no masks
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    sc[r] = s0[mt][r] * sl2;
+                    sc[4 + r] = s1[mt][r] * sl2;
+                    mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kp0 = blk0 * KV_BLOCK + 4 * a + r, kp1 = blk1 * KV_BLOCK + 4 * a + r;
+                    const bool ok0 = row_ok[mt] && kp0 <= row_pos[mt] && kp0 >= win_lo[mt];
+                    const bool ok1 = row_ok[mt] && has1 && kp1 <= row_pos[mt] && kp1 >= win_lo[mt];
+                    sc[r] = ok0 ? s0[mt][r] * sl2 : -INFINITY;
+                    sc[4 + r] = ok1 ? s1[mt][r] * sl2 : -INFINITY;
+                    mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
+                }
+            }
+            mx = rows_reduce_max(mx);
+            const float m_new = fmaxf(m_run[mt], mx);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            alpha[mt] = __builtin_amdgcn_exp2f(m_run[mt] - m_safe);
+            rescale[mt] = __ballot(m_new != m_run[mt]) != 0;     // wave-uniform: some row's maximum moved
+            float psum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float pv = __builtin_amdgcn_exp2f(sc[j] - m_safe);
+                psum += pv;
+                pf[mt][j] = (_Float16)pv;
+            }
+            psum = rows_reduce_sum(psum);
+            l_run[mt] = l_run[mt] * alpha[mt] + psum;
+            m_run[mt] = m_new;
+        }
+        // Oᵀ[d][row] += Vᵀ[d][key]·Pᵀ[key][row]; V fragments are read once per d-tile pair
+#pragma unroll
+        for (int ld = 0; ld < KS; ld++) {
+            const half8 v0 = *reinterpret_cast<const half8*>(kb + 2 * TILE + ld * 512);
+            const half8 v1 = *reinterpret_cast<const half8*>(kb + 3 * TILE + ld * 512);
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                half8 vfrag;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    vfrag[j] = v0[4 * sub + j];
+                    vfrag[4 + j] = has1 ? v1[4 * sub + j] : (_Float16)0.f;
+                }
+                const int dt = 2 * ld + sub;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    if (rescale[mt]) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o_acc[mt][dt][r] *= alpha[mt];
+                    }
+                    o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf[mt], o_acc[mt][dt], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+    }
+    // epilogue: wave-private transposition through the (now idle) stage memory — HD floats per row, 16 rows per wave
+    float* lo = reinterpret_cast<float*>(smem) + wave * 16 * HD;
+    const int row = lane >> 2, dl = lane & 3;
+    constexpr int DPL = HD / 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) *reinterpret_cast<float4v*>(&lo[b * HD + dt * 16 + 4 * a]) = o_acc[mt][dt];
+        const float l_row = __shfl(l_run[mt], row, 64);
+        const int rho_o = ((unit * NW + wave) * MT + mt) * 16 + row;
+        if (rho_o < rows_total) {
+            const float inv = l_row > 0.f ? 1.0f / l_row : 0.f;
+            __half* o = p.out + ((long)(tok0 + rho_o / G) * p.nq + kvh * G + rho_o % G) * HD + dl * DPL;
+#pragma unroll
+            for (int i = 0; i < DPL; i += 8) {
+                half8 h;
+#pragma unroll
+                for (int j = 0; j < 8; j++) h[j] = (_Float16)(lo[row * HD + dl * DPL + i + j] * inv);
+                *reinterpret_cast<half8*>(o + i) = h;
+            }
+        }
+    }
+}
+
 // merge grid.z partials: one thread per (row, dim)
 template <int HD>
 __global__ void paged_attn_reduce_kernel(AttnArgs p) {
@@ -455,6 +689,31 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     a.tiles_per_seq = cdiv((long)max_q_len * G, 16);
     a.max_blocks = max_blocks_per_seq; a.sliding_window = sliding_window;
     a.scale = 1.0f / sqrtf((float)head_dim);
+    // prefill-like batches (most sequences bring many rows): LDS-shared K/V form.  The token count bounds the work units.
+    const bool flash_off = getenv("FERRUM_HIP_ATTN_NO_FLASH") && atoi(getenv("FERRUM_HIP_ATTN_NO_FLASH"));
+    const long flash_min_rows = getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS") ? atol(getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS")) : 512;   // tests lower it
+    if (!fq && cu_seqlens_q && !flash_off && (long)max_q_len * G >= flash_min_rows &&
+        (long)total_q_tokens * 2 >= (long)num_seqs * max_q_len) {
+        const int mt = head_dim == 256 ? 1 : 2, unit_tiles = 4 * mt;
+        const long tiles_bound = ((long)total_q_tokens * G) / 16 + num_seqs;
+        const long units = cdiv(tiles_bound, (long)unit_tiles) + num_seqs;
+        const dim3 grid((unsigned)units, num_kv_heads, 1);
+        const size_t lds = (size_t)2 * 4 * 16 * head_dim * 2;      // two stages × four tiles
+#define FH_FLASH(HDV, MTV)                                                                                             \
+        {                                                                                                              \
+            static bool attr_set = false;                                                                              \
+            if (!attr_set && lds > 65536) {                                                                            \
+                FH_CHECK_HIP(hipFuncSetAttribute((const void*)paged_prefill_attn_kernel<HDV, MTV>,                     \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+                attr_set = true;                                                                                       \
+            }                                                                                                          \
+            hipLaunchKernelGGL((paged_prefill_attn_kernel<HDV, MTV>), grid, dim3(256), lds, s, a);                     \
+        }
+        if (head_dim == 128) FH_FLASH(128, 2) else if (head_dim == 64) FH_FLASH(64, 2) else FH_FLASH(256, 1)
+#undef FH_FLASH
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
     const int tiles = num_seqs * a.tiles_per_seq;
     int nsplit = choose_splits(tiles, num_kv_heads, max_kv_len);
     if (const char* e = getenv("FERRUM_HIP_ATTN_SPLITS")) nsplit = atoi(e);   // tuning override (development)

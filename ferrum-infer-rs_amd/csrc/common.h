@@ -47,6 +47,21 @@ typedef float float4v __attribute__((ext_vector_type(4)));
 
 constexpr int WAVE = 64;
 
+// Reductions over the four 16-lane rows of a wave (lanes L, L^16, L^32, L^48 — the MFMA 16×16 accumulator's key groups) with the
+// gfx950 row/half swaps: v_permlane16_swap / v_permlane32_swap are VALU instructions, where __shfl_xor(·, 16 | 32) is a
+// ds_bpermute round trip through the LDS crossbar.  Same pairing order as shfl_xor 16 then 32, so sums are bit-identical.
+__device__ __forceinline__ float rows_reduce_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows_reduce_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float wave_reduce_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

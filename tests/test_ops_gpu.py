@@ -448,10 +448,11 @@ def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd, monkeypatc
 
 
 @pytest.mark.parametrize("window", [0, 50])
-def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window):
+def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window, monkeypatch):
     """24 prompts × 200 tokens (GQA group 2 ⇒ 25 row tiles each): enough workgroups for the row-split prefill form on its own
     heuristic; every sequence against the CPU restatement."""
     pkg, B, ctx, O, torch = env
+    monkeypatch.setenv("FERRUM_HIP_ATTN_NO_FLASH", "1")            # the flash form has its own test below
     rng = np.random.default_rng(77 + window)
     nq, nkv, hd, S, T = 8, 4, 128, 24, 200
     q_lens, pos_offs = [T] * S, [0] * (S - 2) + [48, 5]            # two of them continue an existing context
@@ -477,6 +478,44 @@ def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window):
                              m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
     ctx.sync()
     got = host(out)
+    for s in range(S):
+        ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
+        assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
+
+
+@pytest.mark.parametrize("window,nq,nkv,hd", [(0, 8, 2, 128), (24, 8, 2, 128), (0, 14, 2, 128), (40, 32, 4, 128), (0, 4, 4, 64),
+                                              (17, 6, 6, 64), (0, 4, 1, 256), (33, 32, 16, 128), (1, 8, 2, 128)])
+def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, monkeypatch):
+    """The flash form (K/V of a block pair staged once per workgroup in LDS, 8 row tiles per workgroup): ragged prefill batch —
+    fresh prompts, chunks that continue a context, a sequence shorter than one workgroup unit, odd block counts."""
+    pkg, B, ctx, O, torch = env
+    monkeypatch.setenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", "1")
+    rng = np.random.default_rng(5 + window + nq + hd)
+    q_lens, pos_offs = [70, 33, 64, 17, 49], [0, 90, 20, 5, 300]
+    S = len(q_lens)
+    kv_lens = [p + t for p, t in zip(pos_offs, q_lens)]
+    max_blocks = (max(kv_lens) + 15) // 16
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 1
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used, K, V = 0, [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    m_total = sum(q_lens)
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    q = f16r(rng.standard_normal((m_total, nq, hd)))
+    out = torch.full((m_total + 1, nq, hd), 9.0, dtype=torch.float16, device="cuda")      # guard row
+    B.paged_varlen_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(cu).cuda(),
+                             torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
+                             m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
+    ctx.sync()
+    got = host(out)
+    assert np.all(got[m_total] == 9.0)
     for s in range(S):
         ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
         assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
