@@ -77,6 +77,7 @@ struct FerrumHipModel {
     int route_gemm_min_tokens = 512;          // from this many tokens the router runs as a GEMM + top-k (3 launches)
     int moe_tile_min_pairs_per_expert = 32;   // average pairs per expert from which MoE GEMMs use 64-row LDS tiles
     int moe_tile32_min_pairs_per_expert = 8;  // … from which (below the 64-row threshold) they use 32-row LDS tiles
+    int attn_flash_min_rows = 512;            // query rows (tokens × GQA group) per prompt from which attention takes the LDS-shared K/V form
     int moe_em_min_pairs_per_expert = 2;      // decode (P ≤ 1024): average pairs per expert from which the grouped GEMMs run expert-major (0 = never)
     bool dense_slabs = true;              // dense MLP block at 17–32 rows: slab GEMMs reduced by their consumers
     int o_slabs = 8;                      // split-K slabs of the o projection on the decode path (0 = direct)

@@ -304,6 +304,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_ROUTE_GEMM_TOKENS")) m->route_gemm_min_tokens = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS")) m->attn_flash_min_rows = std::max(1, atoi(e));   // as the launcher reads it
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE32_PAIRS")) m->moe_tile32_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
     return 0;
@@ -791,6 +792,8 @@ struct StepShape {
     int m_total, num_seqs, max_q_len, max_kv_len, num_sampled;
     bool pure_decode;        // every item is one token AND the model has no uniform sliding window (full-attention decode)
     bool all_single_token;   // every item is one token (windowed layers included): the fused decode attention applies
+    int single_prefix;       // leading items that bring exactly one token (the decode rows of a mixed batch) …
+    int rest_min_q;          // … and the fewest tokens any item after them brings (0 when there is none)
 };
 
 template <typename T>
@@ -917,6 +920,19 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 RUN(paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, bt, kvl, sh.num_seqs,
                                                        sh.max_kv_len, nq, nkv, hd, KV_BLOCK, m->max_blocks_per_seq,
                                                        m->workspace, m->workspace_bytes, s));
+            } else if (sh.single_prefix > 0 && sh.single_prefix < sh.num_seqs && (long)sh.rest_min_q * (nq / nkv) >= 16L * m->attn_flash_min_rows) {
+                // decode rows first, LONG prompts after them (≥ 1024 tokens at a GQA group of 8; for a 256-token prompt the
+                // second launch costs more than the form saves: 9.7 → 10.2 ms per iteration): two launches, so that the
+                // prompts take the LDS-shared K/V form and the decode rows the KV-split form (q/out are indexed by the
+                // absolute token offsets in cu_seqlens_q, so sub-ranges of the sequence arrays are enough)
+                const int n1 = sh.single_prefix;
+                RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu, pos, bt, n1, n1, 1, sh.max_kv_len, nq,
+                                               nkv, hd, layer_window, KV_BLOCK, m->max_blocks_per_seq, m->workspace,
+                                               m->workspace_bytes, s));
+                RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu + n1, pos + n1,
+                                               bt + (size_t)n1 * m->max_blocks_per_seq, sh.num_seqs - n1, T - n1, sh.max_q_len,
+                                               sh.max_kv_len, nq, nkv, hd, layer_window, KV_BLOCK, m->max_blocks_per_seq,
+                                               m->workspace, m->workspace_bytes, s));
             } else {
                 RUN(paged_varlen_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, cu, pos, bt, sh.num_seqs, T,
                                                sh.max_q_len, sh.max_kv_len, nq, nkv, hd, layer_window, KV_BLOCK,
@@ -1144,6 +1160,11 @@ int ferrum_hip_model_unified_forward_ex(FerrumHipModel* m, const FerrumHipBatchI
         for (int b = 0; b < m->max_blocks_per_seq; b++) row[b] = b < (int)st.blocks.size() ? (int32_t)st.blocks[b] : 0;   // padded with 0 (paged_pool.rs:438-440)
     }
     h_cu[num_items] = (uint32_t)t;
+    sh.single_prefix = 0;
+    while (sh.single_prefix < num_items && items[sh.single_prefix].num_q_tokens == 1) sh.single_prefix++;
+    sh.rest_min_q = 0;
+    for (int i = sh.single_prefix; i < num_items; i++)
+        sh.rest_min_q = i == sh.single_prefix ? items[i].num_q_tokens : std::min(sh.rest_min_q, items[i].num_q_tokens);
     // only the used prefix of the block-table region needs to travel
     size_t used = m->il.block_tables + (size_t)num_items * m->max_blocks_per_seq * 4;
     FH_CHECK_HIP(hipMemcpyAsync(m->idx_dev, m->idx_host, used, hipMemcpyHostToDevice, m->stream));

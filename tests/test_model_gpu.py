@@ -153,6 +153,30 @@ def test_mixed_batch_chunked_prefill_matches_per_sequence_oracle(pkg):
             assert modelgen.nmse(om.read_kv(oc, 1, is_v), hm.read_kv(sid, 1, is_v)) < 3e-3
 
 
+def test_mixed_batch_decode_rows_then_prompts_two_attention_launches(pkg, monkeypatch):
+    """A continuous-batching iteration in the order the C++ driver builds it — decode rows first, fresh prompts after them:
+    attention runs as two launches (KV-split for the decode rows, LDS-shared K/V form for the prompts; thresholds lowered so
+    that 30-token prompts qualify).  Every sampled row against the per-sequence oracle."""
+    from tests import modelgen
+    monkeypatch.setenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", "2")       # runner: two launches from 16 × 2 rows per prompt
+    tm = modelgen.TinyModel(False, layers=2, seed=23)
+    om, hm = tm.oracle_model(), tm.hip_model(pkg, kv_num_blocks=64, max_seqs=8, max_tokens=256)
+    rng = np.random.default_rng(24)
+    V = tm.cfg["vocab"]
+    pa, pb, pc, pd = (rng.integers(0, V, size=n).astype(np.uint32) for n in (19, 33, 41, 30))
+    first, _ = hm.unified_forward([(1, pa, 0, True), (2, pb, 0, True)], greedy=True)
+    oa, ob = om.forward(0, pa, 0), om.forward(1, pb, 0)
+    ta, tb = int(np.argmax(oa)), int(np.argmax(ob))
+    toks, lg = hm.unified_forward([(1, [ta], 19, True), (2, [tb], 33, True), (3, pc, 0, True), (4, pd, 0, True)], greedy=True,
+                                  want_logits=True)
+    refs = [om.forward(0, np.array([ta], np.uint32), 19), om.forward(1, np.array([tb], np.uint32), 33), om.forward(2, pc, 0),
+            om.forward(3, pd, 0)]
+    for j, r in enumerate(refs):
+        assert modelgen.cosine(r, lg[j]) > 0.999, j
+        if modelgen.margin(r) > 4 * np.max(np.abs(r - lg[j])):
+            assert int(toks[j]) == int(np.argmax(r))
+
+
 def test_decode_steps_graph_equals_eager_and_oracle(pkg, monkeypatch):
     """The hipGraph-replayed decode loop must produce the same ids as step-by-step unified_forward."""
     from tests import modelgen
