@@ -107,6 +107,40 @@ def attention_long_ctx(pkg, cfg, c, kv_len):
             "peak": HBM_PEAK_GBS, "frac": round(byts / us / 1e3 / HBM_PEAK_GBS, 4)}
 
 
+def attention_prefill_long_prompt(pkg, cfg, q_len):
+    """Prefill paged attention alone (paged_varlen_attention through the C ABI) on one fresh q_len-token prompt with the
+    model's head geometry: HIP-event time per launch and achieved TFLOP/s (4·nq·hd flops per causal query-key pair)."""
+    import torch
+    B = pkg.HipBackend
+    ctx = B.new_context()
+    nq, nkv, hd = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"]
+    nb = (q_len + 15) // 16
+    k = torch.randn(nb * nkv * 16 * hd, device="cuda").half()
+    v = torch.randn(nb * nkv * 16 * hd, device="cuda").half()
+    tables = torch.arange(nb, dtype=torch.int32, device="cuda").reshape(1, nb)
+    cu = torch.tensor([0, q_len], dtype=torch.int32, device="cuda")
+    po = torch.zeros(1, dtype=torch.int32, device="cuda")
+    q = torch.randn(q_len, nq, hd, device="cuda").half()
+    out = torch.empty_like(q)
+
+    def run():
+        B.paged_varlen_attention(ctx, q, k, v, out, cu, po, tables, 1, q_len, q_len, nq, nkv, hd, 0, 16, nb, q_len)
+    for _ in range(2):
+        run()
+    ctx.sync()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()
+    for _ in range(n):
+        run()
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / n
+    fl = 4.0 * nq * hd * q_len * (q_len + 1) / 2
+    return {"prompt_len": q_len, "avg_us": round(us, 1), "tflops": round(fl / us / 1e6, 1), "peak_tflops": MFMA_PEAK_TFLOPS,
+            "frac": round(fl / us / 1e6 / MFMA_PEAK_TFLOPS, 4)}
+
+
 def moe_gemm_bytes(cfg, blocks, tokens, which):
     """Algorithmic HBM bytes of one MoE grouped-GEMM launch: every routed expert's INT4
     weights + fp16 group scales once, plus the fp16 activations in and out."""
@@ -306,6 +340,7 @@ def main():
             if os.path.exists(mp):
                 ns["int4_gemm_prefill"]["mfma_busy_pmc"] = json.load(open(mp))
         ns["attention_decode_long_ctx"] = attention_long_ctx(pkg, cfg, c, 4096)
+        ns["attention_prefill_long_prompt"] = attention_prefill_long_prompt(pkg, cfg, 4096)
         extra["north_star_kernels"] = ns
         for sid in range(c):
             model.release(sid)
