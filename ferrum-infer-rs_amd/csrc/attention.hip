@@ -296,15 +296,14 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
         l_run = l_run * alpha + psum;
         m_run = m_new;
         // Oᵀ[d][row] += Vᵀ[d][key]·Pᵀ[key][row]; contraction index (a,j): j<4 block0 key 4a+j, else block1
+        typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int dt = 0; dt < DT; dt++) {
-            const int ld = dt >> 1, sub = (dt & 1) * 4;
-            half8 vfrag;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                vfrag[j] = vf0[ld][sub + j];
-                vfrag[4 + j] = has1 ? vf1[ld][sub + j] : (_Float16)0.f;
-            }
+            // 8-byte half `dt & 1` of the lane's V fragment of block 0, then of block 1 (whole dwords: register selection, no
+            // element moves); a missing block 1 is a copy of block 0 whose P is 0
+            const int ld = dt >> 1, sub = (dt & 1) * 2;
+            const u32x4a w0 = __builtin_bit_cast(u32x4a, vf0[ld]), w1 = __builtin_bit_cast(u32x4a, vf1[ld]);
+            const half8 vfrag = __builtin_bit_cast(half8, (u32x4a){w0[sub], w0[sub + 1], w1[sub], w1[sub + 1]});
 #pragma unroll
             for (int r = 0; r < 4; r++) o_acc[dt][r] *= alpha;
             o_acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf, o_acc[dt], 0, 0, 0);
@@ -567,18 +566,16 @@ __global__ __launch_bounds__(256, HD <= 128 ? 2 : 1) void paged_prefill_attn_ker
             m_run[mt] = m_new;
         }
         // Oᵀ[d][row] += Vᵀ[d][key]·Pᵀ[key][row]; V fragments are read once per d-tile pair
+        // (the A operand of d-tile 2·ld + sub is the 8-byte half `sub` of the lane's V fragment of block 0 followed by the same
+        // half of block 1: two ds_read_b64 straight into the operand registers, no element moves; a missing block 1 has P = 0)
+        typedef uint32_t u32x4a __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int ld = 0; ld < KS; ld++) {
-            const half8 v0 = *reinterpret_cast<const half8*>(kb + 2 * TILE + ld * 512);
-            const half8 v1 = *reinterpret_cast<const half8*>(kb + 3 * TILE + ld * 512);
 #pragma unroll
             for (int sub = 0; sub < 2; sub++) {
-                half8 vfrag;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    vfrag[j] = v0[4 * sub + j];
-                    vfrag[4 + j] = has1 ? v1[4 * sub + j] : (_Float16)0.f;
-                }
+                const uint2 v0 = *reinterpret_cast<const uint2*>(kb + 2 * TILE + ld * 512 + 4 * sub);
+                const uint2 v1 = *reinterpret_cast<const uint2*>(kb + 3 * TILE + ld * 512 + 4 * sub);
+                const half8 vfrag = __builtin_bit_cast(half8, (u32x4a){v0.x, v0.y, v1.x, v1.y});
                 const int dt = 2 * ld + sub;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) {
