@@ -527,27 +527,30 @@ __global__ __launch_bounds__(256, HD <= 128 ? 2 : 1) void paged_prefill_attn_ker
         bool rescale[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            // scores in log2 units (scale·log2 e folded into one multiply; exp2 is the native instruction)
+            // probabilities as exp2(s·scale·log₂e − m): one FMA per score feeds the native exp2
+            const bool clear = blk1 * KV_BLOCK + KV_BLOCK - 1 <= vis_hi[mt] && blk0 * KV_BLOCK >= vis_lo[mt];
             float sc[8];
             float mx = -INFINITY;
-            if (blk1 * KV_BLOCK + KV_BLOCK - 1 <= vis_hi[mt] && blk0 * KV_BLOCK >= vis_lo[mt]) {
+            if (clear) {
                 // both blocks lie below the causal diagonal (and inside the window) of every row of the tile: no masks
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    sc[r] = s0[mt][r] * sl2;
-                    sc[4 + r] = s1[mt][r] * sl2;
+                    sc[r] = s0[mt][r];
+                    sc[4 + r] = s1[mt][r];
                     mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
                 }
+                mx *= sl2;                                   // sl2 > 0: the maximum commutes with the scaling
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int kp0 = blk0 * KV_BLOCK + 4 * a + r, kp1 = blk1 * KV_BLOCK + 4 * a + r;
                     const bool ok0 = row_ok[mt] && kp0 <= row_pos[mt] && kp0 >= win_lo[mt];
                     const bool ok1 = row_ok[mt] && has1 && kp1 <= row_pos[mt] && kp1 >= win_lo[mt];
-                    sc[r] = ok0 ? s0[mt][r] * sl2 : -INFINITY;
-                    sc[4 + r] = ok1 ? s1[mt][r] * sl2 : -INFINITY;
+                    sc[r] = ok0 ? s0[mt][r] : -INFINITY;
+                    sc[4 + r] = ok1 ? s1[mt][r] : -INFINITY;
                     mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
                 }
+                mx *= sl2;
             }
             mx = rows_reduce_max(mx);
             const float m_new = fmaxf(m_run[mt], mx);
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(256, HD <= 128 ? 2 : 1) void paged_prefill_attn_ker
             float psum = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const float pv = __builtin_amdgcn_exp2f(sc[j] - m_safe);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], sl2, -m_safe));      // masked: −inf·sl2 − m = −inf → 0
                 psum += pv;
                 pf[mt][j] = (_Float16)pv;
             }
