@@ -1055,10 +1055,15 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     constexpr int FR = MTN * 256;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int st_raw = blockIdx.x * 4 + wave;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin by launch index; here each XCD walks a contiguous
+    // range of (column tile, row block) with the row block fastest, so the row blocks of one expert meet its weight slice in
+    // ONE XCD's L2 instead of four
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = lin & 7, virt = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);      // XCD x owns nwg/8 (+1 if x < nwg%8) tiles
+    const int st_raw = (virt / (int)gridDim.y) * 4 + wave;
     const bool st_ok = st_raw < p.n64;
     const int st = st_ok ? st_raw : p.n64 - 1;
-    const int rb = blockIdx.y;
+    const int rb = virt % (int)gridDim.y;
 
     const uint32_t* qw = p.qw;
     const __half* sc = p.sc;
