@@ -256,6 +256,66 @@ def test_split_qkv_norm_rope_into_paged_cache_varlen(env, qk_mode, hd):
         assert bool(pool[blk].any()) == (blk in written)
 
 
+def test_ragged_batch_of_many_sequences_including_empty_ones(env):
+    """150 sequences (more than two 64-wide passes of the in-kernel sequence lookups), a few of them with no query token at
+    all: the split/norm/RoPE/paged-write op and the ragged attention grid must place every token with its own sequence."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(2025)
+    nq, nkv, hd, bs, S = 4, 2, 64, 16, 150
+    q_lens = [int(x) for x in rng.integers(1, 7, size=S)]
+    for s in (0, 63, 64, 65, 128, 149):
+        q_lens[s] = 0                                           # empty sequences at chunk boundaries and both ends
+    q_lens[10], q_lens[100] = 40, 23                            # a few longer chunks
+    pos_offs = [int(x) for x in rng.integers(0, 20, size=S)]
+    kv_lens = [p + t for p, t in zip(pos_offs, q_lens)]
+    max_blocks = (max(kv_lens) + bs - 1) // bs
+    num_blocks = sum((n + bs - 1) // bs for n in kv_lens) + 1
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used = 0
+    for s, n in enumerate(kv_lens):
+        nb = (n + bs - 1) // bs
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+    m_total = sum(q_lens)
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    cos, sin = _rope(O, hd, 128)
+    qkv = f16r(rng.standard_normal((m_total, (nq + 2 * nkv) * hd)))
+    qn, kn = f16r(1 + 0.1 * rng.standard_normal(hd)), f16r(1 + 0.1 * rng.standard_normal(hd))
+    # context already in the cache: fill it through the same op, one "prefill" of pos_offs[s] tokens per sequence
+    ctx_lens = pos_offs
+    ctx_total = sum(ctx_lens)
+    ccu = np.concatenate([[0], np.cumsum(ctx_lens)]).astype(np.int32)
+    ctx_qkv = f16r(rng.standard_normal((ctx_total, (nq + 2 * nkv) * hd)))
+    ck, cv = B.alloc_paged_pool(num_blocks, nkv, hd), B.alloc_paged_pool(num_blocks, nkv, hd)
+    cosd, sind, td = torch.from_numpy(cos).cuda(), torch.from_numpy(sin).cuda(), torch.from_numpy(tables).cuda()
+    scratch = torch.empty(max(ctx_total, 1), nq, hd, dtype=torch.float16, device="cuda")
+    B.split_qkv_norm_rope_into_paged_cache_varlen(ctx, dev16(torch, ctx_qkv), dev16(torch, qn), dev16(torch, kn), cosd, sind, scratch,
+                                                  ck, cv, torch.from_numpy(ccu).cuda(), torch.zeros(S, dtype=torch.int32, device="cuda"),
+                                                  td, S, ctx_total, nq, nkv, hd, 1e-6, 1, bs, max_blocks)
+    q_out = torch.empty(m_total, nq, hd, dtype=torch.float16, device="cuda")
+    B.split_qkv_norm_rope_into_paged_cache_varlen(ctx, dev16(torch, qkv), dev16(torch, qn), dev16(torch, kn), cosd, sind, q_out, ck, cv,
+                                                  torch.from_numpy(cu).cuda(), torch.from_numpy(np.array(pos_offs, np.int32)).cuda(),
+                                                  td, S, m_total, nq, nkv, hd, 1e-6, 1, bs, max_blocks)
+    out = torch.full((m_total + 1, nq, hd), 5.0, dtype=torch.float16, device="cuda")
+    B.paged_varlen_attention(ctx, q_out, ck, cv, out, torch.from_numpy(cu).cuda(), torch.from_numpy(np.array(pos_offs, np.int32)).cuda(),
+                             td, S, m_total, max(kv_lens), nq, nkv, hd, 0, bs, max_blocks, max(q_lens))
+    ctx.sync()
+    got_q, got = host(q_out), host(out)
+    assert np.all(got[m_total] == 5.0)
+    for s in range(S):
+        T = q_lens[s]
+        if T == 0:
+            continue
+        q, k, v = O.split_qkv(qkv[cu[s]:cu[s + 1]], nq * hd, nkv * hd)
+        q_ref = O.qk_norm_rope(q.reshape(T, nq, hd), qn, cos, sin, T, nq, hd, pos_offs[s], 1e-6, 1).transpose(1, 0, 2)
+        assert nmse(q_ref, got_q[cu[s]:cu[s + 1]]) < NMSE_FP16_TOL, s
+        kk, vv = B.paged_kv_read(ctx, ck, cv, td[s], kv_lens[s], nkv, hd)
+        ctx.sync()
+        ref = _ref_attention(O, got_q[cu[s]:cu[s + 1]], host(kk), host(vv), pos_offs[s], nq, nkv, hd, 0)
+        assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
+
+
 # ── contiguous-KV lane of the core trait (kv_layer.rs:370-513) ────────────────
 @pytest.mark.parametrize("nq,nkv,hd,mode,window", [(8, 2, 128, 1, 0), (4, 4, 64, 2, 0), (6, 2, 128, 3, 5), (2, 1, 256, 1, 3)])
 def test_contiguous_lane_prefill_then_decode(env, nq, nkv, hd, mode, window):
@@ -518,6 +578,44 @@ def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, monkeyp
     assert np.all(got[m_total] == 9.0)
     for s in range(S):
         ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
+        assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
+
+
+def test_paged_prefill_attention_lds_shared_kv_many_sequences(env, monkeypatch):
+    """The flash form over 70 sequences (two passes of its in-kernel sequence lookup), two of them empty."""
+    pkg, B, ctx, O, torch = env
+    monkeypatch.setenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", "1")
+    rng = np.random.default_rng(404)
+    nq, nkv, hd, S = 4, 2, 128, 70
+    q_lens = [int(x) for x in rng.integers(15, 26, size=S)]
+    q_lens[0], q_lens[64] = 0, 0
+    pos_offs = [int(x) for x in rng.integers(0, 40, size=S)]
+    kv_lens = [p + t for p, t in zip(pos_offs, q_lens)]
+    max_blocks = (max(kv_lens) + 15) // 16
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 1
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used, K, V = 0, [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    m_total = sum(q_lens)
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    q = f16r(rng.standard_normal((m_total, nq, hd)))
+    out = torch.zeros(m_total, nq, hd, dtype=torch.float16, device="cuda")
+    B.paged_varlen_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(cu).cuda(),
+                             torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
+                             m_total, max(kv_lens), nq, nkv, hd, 0, 16, max_blocks, max(q_lens))
+    ctx.sync()
+    got = host(out)
+    for s in range(S):
+        if q_lens[s] == 0:
+            continue
+        ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, 0)
         assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
 
 
