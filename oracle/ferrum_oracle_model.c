@@ -221,12 +221,15 @@ static fo_kv *fo_get_cache(fo_model *m, int cache_id) {
 }
 
 FO_API void fo_model_release_cache(fo_model *m, int cache_id) {
+    if (cache_id < 0 || cache_id >= FO_MAX_CACHES) return;
     fo_kv *c = &m->caches[cache_id];
     free(c->k); free(c->v);
     memset(c, 0, sizeof(*c));
 }
 
-FO_API int fo_model_cache_len(fo_model *m, int cache_id) { return m->caches[cache_id].len; }
+FO_API int fo_model_cache_len(fo_model *m, int cache_id) {
+    return cache_id < 0 || cache_id >= FO_MAX_CACHES ? -1 : m->caches[cache_id].len;
+}
 
 /* Copy layer `layer`'s cached K or V for positions [0,len) out as
  * [len][nkv][hd] token-major (the order ferrum-kv read_kv returns). */
@@ -270,6 +273,7 @@ static float fo_topk_gap(const float *l, int n, int k) {
 FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, int n_tokens,
                             int pos_offset, float *logits_out, float *all_logits) {
     const fo_model_cfg *g = &m->cfg;
+    if (cache_id < 0 || cache_id >= FO_MAX_CACHES) return -4;
     fo_kv *cache = fo_get_cache(m, cache_id);
     if (cache->len != pos_offset) return -2;
     if (pos_offset + n_tokens > g->max_seq_len) return -3;
