@@ -71,7 +71,7 @@ bool arg_flag(int argc, char** argv, const char* name) {
 }  // namespace
 
 int main(int argc, char** argv) {
-    const int layers = arg_int(argc, argv, "--layers", 48);
+    const int layers = arg_int(argc, argv, "--layers", arg_flag(argc, argv, "--dense") ? 32 : 48);   // Llama-3.1-8B: 32 layers, Qwen3-30B-A3B: 48
     const int num_requests = arg_int(argc, argv, "--requests", 96);
     const int conc = arg_int(argc, argv, "--concurrency", 32);
     const int PL = arg_int(argc, argv, "--prompt-len", 256);
