@@ -62,15 +62,26 @@ __device__ __forceinline__ float rows_reduce_sum(float v) {
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+// Whole-wave reductions (every lane gets the result) without LDS round trips: inside a 16-lane row by DPP (quad permutes for
+// lane^1 and lane^2, then row_half_mirror and row_mirror), across the four rows by the permlane swaps above.  __shfl_xor is a
+// ds_bpermute (≈ 100+ cycles each, six per reduction) on the critical path of the latency-bound decode kernels.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_reduce_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp_move<0x141>(v);       // row_half_mirror
+    v += dpp_move<0x140>(v);       // row_mirror
+    return rows_reduce_sum(v);
 }
 __device__ __forceinline__ float wave_reduce_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1>(v));
+    v = fmaxf(v, dpp_move<0x4E>(v));
+    v = fmaxf(v, dpp_move<0x141>(v));
+    v = fmaxf(v, dpp_move<0x140>(v));
+    return rows_reduce_max(v);
 }
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }

@@ -57,8 +57,11 @@ __device__ __forceinline__ RopeRow<HD> rope_row16(const __half* src, const __hal
         float ss = 0.f;
 #pragma unroll
         for (int k = 0; k < 2 * PPL; k++) ss += c[k] * c[k];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) ss += __shfl_xor(ss, off, 64);
+        // sum over the 16 lanes of the row by DPP (no LDS round trips)
+        ss += dpp_move<0xB1>(ss);
+        ss += dpp_move<0x4E>(ss);
+        ss += dpp_move<0x141>(ss);
+        ss += dpp_move<0x140>(ss);
         if (mode == 1) scale = 1.0f / sqrtf(ss / (float)HD + eps);
     }
     float r0[PPL], r1[PPL];
