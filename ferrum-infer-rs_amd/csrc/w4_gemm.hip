@@ -710,6 +710,9 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
     for (int j = 0; j * 16 < n_e; j++) {
         const int id = j * 16 + b < n_e ? s_rows[j * 16 + b] : P;
         const bool row_ok = id < P;
+        int orow[4];          // D row 4a + r ↔ block row 4a + r: its pair id, read now so the epilogue waits for nothing
+#pragma unroll
+        for (int r = 0; r < 4; r++) orow[r] = j * 16 + 4 * a + r < n_e ? s_rows[j * 16 + 4 * a + r] : P;
         const __half* xrow = p.x + (long)(row_ok ? id / p.top_k : 0) * p.K + 8 * a;
         auto issue_a = [&](int buf, int g) {
 #pragma unroll
@@ -748,24 +751,22 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
             consume(0);
         }
 #undef FH_PIN
-        // D row 4a + r ↔ block row 4a + r, whose pair id lives in lane (·, b = 4a + r)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int orow = __shfl(id, 4 * a + r, 64);
-            if (orow >= P) continue;
+            if (orow[r] >= P) continue;
             if (MODE == 2) {
 #pragma unroll
                 for (int jj = 0; jj < 2; jj++) {
                     const float gt = acc[0][jj][r], up = acc[0][2 + jj][r];
                     const float v = (gt / (1.0f + __expf(-gt))) * up;
                     const int col = st * 32 + jj * 16 + b;
-                    if (col < p.ldo) p.out[(long)orow * p.ldo + col] = __float2half(v);
+                    if (col < p.ldo) p.out[(long)orow[r] * p.ldo + col] = __float2half(v);
                 }
             } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) {
                     const int col = st * 64 + nt * 16 + b;
-                    if (col < p.N) p.out[(long)orow * p.ldo + col] = __float2half(acc[0][nt][r]);
+                    if (col < p.N) p.out[(long)orow[r] * p.ldo + col] = __float2half(acc[0][nt][r]);
                 }
             }
         }
