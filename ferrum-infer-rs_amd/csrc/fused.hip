@@ -284,6 +284,31 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
             for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
         }
     }
+    // requested now, used after the two barriers below: the norm weights and the router weights of this wave's first unit
+    // (16 k-steps × 1 KiB per wave) travel while the row statistics are reduced and the row is normalised into LDS
+    half8 wv_pre[CH];
+#pragma unroll
+    for (int c = 0; c < CH; c++) {
+        const int i = threadIdx.x + c * 512;
+        wv_pre[c] = *reinterpret_cast<const half8*>(w + (i < nvec ? i : 0) * 8);
+    }
+    constexpr int U = 16;
+    const int tiles = (num_experts + 15) >> 4;
+    const int tiles_q = num_experts > 0 ? tiles / Q : 0;                      // launcher guarantees divisibility
+    const int ksplit = tiles_q >= 8 || tiles_q == 0 ? 1 : 8 / tiles_q;
+    const int ksteps = H >> 5;
+    half8 bw_pre[U];
+    bool pre = false;
+    if (wave < tiles_q * ksplit) {
+        const int tl = wave / ksplit, ks = wave % ksplit;
+        const int s0 = ksteps * ks / ksplit, s1 = ksteps * (ks + 1) / ksplit;
+        if (s0 + U <= s1) {
+            const __half* wrow = router_w + ((long)(q * tiles_q + tl) * ksteps * 64 + lane) * 8;
+#pragma unroll
+            for (int kk = 0; kk < U; kk++) bw_pre[kk] = *reinterpret_cast<const half8*>(wrow + (long)(s0 + kk) * 512);
+            pre = true;
+        }
+    }
     ss = wave_reduce_sum(ss);
     if (lane == 0) red[wave] = ss;
     __syncthreads();
@@ -293,7 +318,7 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
     for (int c = 0; c < CH; c++) {
         const int i = threadIdx.x + c * 512;
         if (i < nvec) {
-            half8 wv = *reinterpret_cast<const half8*>(w + i * 8);
+            const half8 wv = wv_pre[c];
             half8 o;
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
@@ -314,19 +339,23 @@ __global__ __launch_bounds__(512) void add_rmsnorm_route_part_kernel(
     }
     __syncthreads();
     if (num_experts <= 0) return;
-    const int tiles = (num_experts + 15) >> 4;
-    const int tiles_q = tiles / Q;                      // launcher guarantees divisibility
-    const int ksplit = tiles_q >= 8 ? 1 : 8 / tiles_q;
     const int a = lane >> 4, b = lane & 15;
-    const int ksteps = H >> 5;
     for (int u = wave; u < tiles_q * ksplit; u += 8) {
         const int tl = u / ksplit, ks = u % ksplit;
         const int tile = q * tiles_q + tl;
         const int s0 = ksteps * ks / ksplit, s1 = ksteps * (ks + 1) / ksplit;
         const __half* wrow = router_w + ((long)tile * ksteps * 64 + lane) * 8;
         float4v acc = {0.f, 0.f, 0.f, 0.f};
-        constexpr int U = 16;
         int s = s0;
+        if (u == wave && pre) {                      // the chunk requested at the top of the kernel
+#pragma unroll
+            for (int kk = 0; kk < U; kk++) {
+                half8 av = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (b == 0) av = *reinterpret_cast<const half8*>(xs + (s + kk) * 32 + 8 * a);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bw_pre[kk], acc, 0, 0, 0);
+            }
+            s += U;
+        }
         for (; s + U <= s1; s += U) {
             half8 bw[U];
 #pragma unroll
