@@ -525,13 +525,30 @@ __global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
         int i = threadIdx.x + c * 256;
         if (i < nvec) {
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < top_k; k++) {
+            // the first 8 expert rows, the residual row (and below the norm weights) are requested together: a runtime-bound
+            // loop keeps one load in flight and pays a memory round trip per expert
+            float wk8[8];
+            half8 d8[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int kc = k < top_k ? k : top_k - 1;
+                wk8[k] = weights[row * top_k + kc];
+                d8[k] = *reinterpret_cast<const half8*>(down + (row * top_k + kc) * H + i * 8);
+            }
+            half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < top_k) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += wk8[k] * (float)d8[k][j];
+                }
+            }
+            for (int k = 8; k < top_k; k++) {
                 float wk = weights[row * top_k + k];
                 half8 d = *reinterpret_cast<const half8*>(down + (row * top_k + k) * H + i * 8);
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc[j] += wk * (float)d[j];
             }
-            half8 rv = *reinterpret_cast<const half8*>(residual + row * H + i * 8);
 #pragma unroll
             for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + acc[j]);
             *reinterpret_cast<half8*>(residual_out + row * H + i * 8) = rv;
