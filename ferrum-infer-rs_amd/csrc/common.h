@@ -84,6 +84,33 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
     return rows_reduce_max(v);
 }
 
+// Sum S ≤ 8 fp32 split-K slabs of one 8-element span in slab order.  All 16 loads are issued up front (index
+// clamped, not branched: a load under a runtime condition costs one L2 round trip per slab) and masked in the add.
+__device__ __forceinline__ void reduce_slabs8(const float* __restrict__ base, long slab_stride, int S, float (&o)[8]) {
+    float4v sv[8][2];
+#pragma unroll
+    for (int z = 0; z < 8; z++) {
+        const float4v* sp = reinterpret_cast<const float4v*>(base + (long)(z < S ? z : S - 1) * slab_stride);
+        sv[z][0] = sp[0];
+        sv[z][1] = sp[1];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = 0.f;
+#pragma unroll
+    for (int z = 0; z < 8; z++) {
+        if (z < S) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { o[j] += sv[z][0][j]; o[4 + j] += sv[z][1][j]; }
+        }
+    }
+    for (int z = 8; z < S; z++) {          // S > 8: rare, serial
+        const float4v* sp = reinterpret_cast<const float4v*>(base + (long)z * slab_stride);
+        float4v s0 = sp[0], s1 = sp[1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { o[j] += s0[j]; o[4 + j] += s1[j]; }
+    }
+}
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 __host__ __device__ inline int cdiv_dev(int a, int b) { return (a + b - 1) / b; }

@@ -192,7 +192,23 @@ __global__ void moe_combine_kernel(const __half* __restrict__ down, const float*
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (hidden >> 3)) return;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < top_k; k++) {
+    // the first 8 expert rows are requested together (a runtime-bound loop pays one memory round trip per expert)
+    float w8[8];
+    half8 d8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int kc = k < top_k ? k : top_k - 1;
+        w8[k] = weights[b * top_k + kc];
+        d8[k] = *reinterpret_cast<const half8*>(down + (b * top_k + kc) * hidden + i * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k < top_k) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += w8[k] * (float)d8[k][j];
+        }
+    }
+    for (int k = 8; k < top_k; k++) {
         float w = weights[b * top_k + k];
         half8 d = *reinterpret_cast<const half8*>(down + (b * top_k + k) * hidden + i * 8);
 #pragma unroll

@@ -132,13 +132,8 @@ __global__ __launch_bounds__(256) void sandwich_add_norm_f32_kernel(const __half
         const int i = threadIdx.x + c * 256;
         if (i < nvec) {
             if (SLABS) {   // branch = S fp32 split-K slabs, summed in slab order and rounded like the fp16 GEMM output
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int z = 0; z < S; z++) {
-                    const float4v* sp = reinterpret_cast<const float4v*>(slabs + z * slab_stride + row * ld_slab + i * 8);
-                    const float4v a0 = sp[0], a1 = sp[1];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { acc[j] += a0[j]; acc[4 + j] += a1[j]; }
-                }
+                float acc[8];
+                reduce_slabs8(slabs + row * ld_slab + i * 8, slab_stride, S, acc);     // all slab loads in flight at once
 #pragma unroll
                 for (int j = 0; j < 8; j++) { x[c][j] = (float)(_Float16)acc[j]; ss += x[c][j] * x[c][j]; }
             } else {
@@ -296,15 +291,8 @@ __global__ void gated_act_slabs_kernel(const float* __restrict__ slabs, int S, l
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (im >> 3)) return;
     float g[8], u[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) { g[j] = 0.f; u[j] = 0.f; }
-    for (int z = 0; z < S; z++) {
-        const float4v* gp = reinterpret_cast<const float4v*>(slabs + z * slab_stride + t * ld + i * 8);
-        const float4v* up = reinterpret_cast<const float4v*>(slabs + z * slab_stride + t * ld + im + i * 8);
-        const float4v g0 = gp[0], g1 = gp[1], u0 = up[0], u1 = up[1];
-#pragma unroll
-        for (int j = 0; j < 4; j++) { g[j] += g0[j]; g[4 + j] += g1[j]; u[j] += u0[j]; u[4 + j] += u1[j]; }
-    }
+    reduce_slabs8(slabs + t * ld + i * 8, slab_stride, S, g);          // all slab loads in flight at once (a runtime-bound
+    reduce_slabs8(slabs + t * ld + im + i * 8, slab_stride, S, u);     // loop pays one memory round trip per slab)
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
