@@ -8,6 +8,32 @@
 
 namespace fh {
 
+// (value, index) wave reduction under the total order "larger value, then smaller index" — exact whatever the pairing, so
+// the DPP / permlane form (no LDS round trips, see common.h) gives the same answer as any other tree.
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp_step(float& best, int& idx) {
+    float ob = dpp_move<CTRL>(best);
+    int oi = __builtin_amdgcn_update_dpp(0, idx, CTRL, 0xF, 0xF, true);
+    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+}
+__device__ __forceinline__ void argmax_pick(float& best, int& idx, float v0, int i0, float v1, int i1) {
+    const bool one = v1 > v0 || (v1 == v0 && i1 < i0);
+    best = one ? v1 : v0;
+    idx = one ? i1 : i0;
+}
+__device__ __forceinline__ void wave_argmax(float& best, int& idx) {
+    argmax_dpp_step<0xB1>(best, idx);
+    argmax_dpp_step<0x4E>(best, idx);
+    argmax_dpp_step<0x141>(best, idx);
+    argmax_dpp_step<0x140>(best, idx);
+    auto rv = __builtin_amdgcn_permlane16_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    auto ri = __builtin_amdgcn_permlane16_swap((unsigned)idx, (unsigned)idx, false, false);
+    argmax_pick(best, idx, __uint_as_float(rv[0]), (int)ri[0], __uint_as_float(rv[1]), (int)ri[1]);
+    rv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+    ri = __builtin_amdgcn_permlane32_swap((unsigned)idx, (unsigned)idx, false, false);
+    argmax_pick(best, idx, __uint_as_float(rv[0]), (int)ri[0], __uint_as_float(rv[1]), (int)ri[1]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__ logits, uint32_t* __restrict__ out,
                                                            const uint8_t* __restrict__ mask, int mask_len, int n) {
@@ -22,12 +48,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__
         float v = (float)p[i];
         if (v > best) { best = v; best_idx = i; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float ob = __shfl_xor(best, off, 64);
-        int oi = __shfl_xor(best_idx, off, 64);
-        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
-    }
+    wave_argmax(best, best_idx);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_idx; }
     __syncthreads();
@@ -42,7 +63,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(const T* __restrict__
 // Two-stage form for wide rows (a vocabulary-sized row on ONE workgroup is bound by what one CU can pull, ≈25 GB/s):
 // stage 1 grid (rows, C chunks) → (value, index) partials in the workspace; stage 2 one wave per row.  Same
 // tie-break: first maximum.
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const T* __restrict__ logits, float* __restrict__ pval,
                                                              int* __restrict__ pidx, const uint8_t* __restrict__ mask,
                                                              int mask_len, int n, int chunk) {
@@ -54,17 +75,42 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const T* __restrict
     const T* p = logits + row * n;
     float best = -INFINITY;
     int best_idx = 0x7fffffff;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) {
-        if (mask && (i >= mask_len || mask[i] == 0)) continue;
-        float v = (float)p[i];
-        if (v > best) { best = v; best_idx = i; }
-    }
+    if (VEC) {
+        // chunk == 2048 and n % 8 == 0: one 8-element request per thread (plus the 8 mask bytes), a single round trip per
+        // workgroup instead of eight 2-byte ones.
+        const int i0 = lo + threadIdx.x * 8;
+        if (i0 < hi) {
+            T v8[8];
+            if (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(v8) = *reinterpret_cast<const uint4*>(p + i0);
+            } else {
+                reinterpret_cast<uint4*>(v8)[0] = reinterpret_cast<const uint4*>(p + i0)[0];
+                reinterpret_cast<uint4*>(v8)[1] = reinterpret_cast<const uint4*>(p + i0)[1];
+            }
+            unsigned long long mk = ~0ull;
+            if (mask) {
+                if (i0 + 8 <= mask_len && (reinterpret_cast<uintptr_t>(mask) & 7) == 0) {
+                    mk = *reinterpret_cast<const unsigned long long*>(mask + i0);
+                } else {
+                    mk = 0;
+                    for (int j = 0; j < 8; j++)
+                        if (i0 + j < mask_len && mask[i0 + j]) mk |= 0xffull << (8 * j);
+                }
+            }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float ob = __shfl_xor(best, off, 64);
-        int oi = __shfl_xor(best_idx, off, 64);
-        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
+            for (int j = 0; j < 8; j++) {
+                float v = (float)v8[j];
+                if (((mk >> (8 * j)) & 0xff) && v > best) { best = v; best_idx = i0 + j; }
+            }
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            if (mask && (i >= mask_len || mask[i] == 0)) continue;
+            float v = (float)p[i];
+            if (v > best) { best = v; best_idx = i; }
+        }
     }
+    wave_argmax(best, best_idx);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (lane == 0) { s_val[wave] = best; s_idx[wave] = best_idx; }
     __syncthreads();
@@ -86,12 +132,7 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
         int i = pidx[row * C + c];
         if (v > best || (v == best && i < best_idx)) { best = v; best_idx = i; }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        float ob = __shfl_xor(best, off, 64);
-        int oi = __shfl_xor(best_idx, off, 64);
-        if (ob > best || (ob == best && oi < best_idx)) { best = ob; best_idx = oi; }
-    }
+    wave_argmax(best, best_idx);
     if (threadIdx.x == 0) out[row] = best_idx == 0x7fffffff ? 0u : (uint32_t)best_idx;
 }
 
@@ -99,16 +140,22 @@ template <typename T>
 static int argmax_rows_ws(const T* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                           float* workspace, size_t workspace_bytes, hipStream_t s) {
     if (m <= 0) return 0;
-    int C = std::min(128, std::max(1, n / 2048));
+    // Vector form: 2048-element chunks (one 16/32-byte request per thread) when rows stay 16-byte aligned.
+    const bool vec = n % 8 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && n >= 4096 &&
+                     workspace != nullptr && workspace_bytes >= (size_t)m * cdiv(n, 2048) * 8;
+    int C = vec ? cdiv(n, 2048) : std::min(128, std::max(1, n / 2048));
     if (workspace == nullptr || workspace_bytes < (size_t)m * C * 8 || C < 2) {
         hipLaunchKernelGGL(argmax_rows_kernel<T>, dim3(m), dim3(1024), 0, s, logits, out_ids, valid_mask, mask_len, n);
         FH_CHECK_LAUNCH();
         return 0;
     }
-    const int chunk = cdiv(n, C);
+    const int chunk = vec ? 2048 : cdiv(n, C);
     float* pval = workspace;
     int* pidx = reinterpret_cast<int*>(workspace + (size_t)m * C);
-    hipLaunchKernelGGL(argmax_partial_kernel<T>, dim3(m, C), dim3(256), 0, s, logits, pval, pidx, valid_mask, mask_len, n, chunk);
+    if (vec)
+        hipLaunchKernelGGL((argmax_partial_kernel<T, true>), dim3(m, C), dim3(256), 0, s, logits, pval, pidx, valid_mask, mask_len, n, chunk);
+    else
+        hipLaunchKernelGGL((argmax_partial_kernel<T, false>), dim3(m, C), dim3(256), 0, s, logits, pval, pidx, valid_mask, mask_len, n, chunk);
     FH_CHECK_LAUNCH();
     hipLaunchKernelGGL(argmax_final_kernel, dim3(m), dim3(64), 0, s, pval, pidx, out_ids, C);
     FH_CHECK_LAUNCH();

@@ -1023,6 +1023,30 @@ def test_argmax_rows_first_max_and_mask(env):
     assert np.array_equal(B.argmax_rows_f16(ctx, ld, m, n), ref)
 
 
+@pytest.mark.parametrize("n", [4096, 5003, 40000, 40004])
+def test_argmax_rows_widths_and_mask_tails(env, n):
+    """Row widths on both sides of the vector form's conditions (n % 8, ≥ 4096) with a mask shorter than the row."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(n)
+    m = 7
+    logits = rng.standard_normal((m, n)).astype(np.float32)
+    logits[0, n - 1] = 30.0
+    logits[1, n - 3] = logits[1, 5] = 30.0
+    logits[2, :] = 1.0                                      # all equal → id 0, or the first valid id under the mask
+    ld = torch.from_numpy(logits).cuda()
+    assert np.array_equal(B.argmax_rows_f16(ctx, ld, m, n), O.argmax_rows(logits))
+    l16 = f16r(logits)
+    assert np.array_equal(B.argmax_rows_f16(ctx, dev16(torch, l16), m, n), O.argmax_rows(l16))
+    mask = (rng.random(n) < 0.7).astype(np.uint8)
+    mask[:3] = 0
+    mask_len = n - 5
+    got = B.argmax_rows_f16_masked(ctx, ld, torch.from_numpy(mask).cuda(), mask_len, m, n)
+    masked = logits.copy()
+    masked[:, mask == 0] = -np.inf
+    masked[:, mask_len:] = -np.inf
+    assert np.array_equal(got, O.argmax_rows(masked))
+
+
 def test_sparse_repetition_penalty_then_argmax(env):
     pkg, B, ctx, O, torch = env
     rng = np.random.default_rng(10)
