@@ -951,7 +951,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
                 const float* slabs = nullptr;
                 int S = m->o_slabs, rows_pad = 0, n_pad = 0;
-                if (S > 0) {
+                if (S > 0 && T > 16 && T <= 32 && !L.o.bias) {
+                    // 17–32 rows: activations staged once per workgroup in LDS (a wave fetching its own fragments pulls 2× the
+                    // weight bytes from L2); decode c=32 4.60 → 4.57 ms per step
+                    RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+                    slabs = m->workspace;
+                } else if (S > 0) {
                     RUN(w4_gemm_dense_slabs(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, S, &rows_pad, &n_pad, s));
                     slabs = m->workspace;
                     S = std::min(S, L.o.G);
