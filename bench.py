@@ -273,8 +273,15 @@ def main():
         barrier()
         return t_local, PL + warm + steps
 
+    def stage(name):                                            # FERRUM_BENCH_STAGES=1: progress on stderr (fault triage)
+        if os.environ.get("FERRUM_BENCH_STAGES"):
+            torch.cuda.synchronize()
+            print(f"[bench] {name}", file=sys.stderr, flush=True)
+
     model = build_model(pkg, cfg, c, max_seq_len, chunk, 9271 + rank, layers=args.layers or None)
+    stage("model built")
     t_local, kv_end = run_case(model, c, K, W, 0)
+    stage("timed decode done")
     t = torch.tensor([t_local], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,6 +294,7 @@ def main():
         kernels = {}
         mlp_names = ("moe_gate_up", "moe_down") if moe else ("gate_up", "down")
         for name in mlp_names + ("attention", "qkv", "o", "lm_head"):
+            stage(f"time_kernel {name}")
             us, blocks = model.time_kernel(name, c, kv_end, reps=3)
             entry = {"avg_us": round(us, 2)}
             if name.startswith("moe"):
@@ -339,8 +347,11 @@ def main():
             mp = os.path.join(ROOT, "profiles", "pmc_mfma_busy.json")
             if os.path.exists(mp):
                 ns["int4_gemm_prefill"]["mfma_busy_pmc"] = json.load(open(mp))
+        stage("north-star: attention decode at long context")
         ns["attention_decode_long_ctx"] = attention_long_ctx(pkg, cfg, c, 4096)
+        stage("north-star: attention prefill, long prompt")
         ns["attention_prefill_long_prompt"] = attention_prefill_long_prompt(pkg, cfg, 4096)
+        stage("north-star kernels done")
         extra["north_star_kernels"] = ns
         for sid in range(c):
             model.release(sid)

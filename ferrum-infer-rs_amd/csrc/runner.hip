@@ -878,7 +878,15 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     const int32_t* sampled_idx = idx<int32_t>(m, m->il.sampled_idx);
     const int32_t* bt = idx<int32_t>(m, m->il.block_tables);
     int rc;
-#define RUN(x) if ((rc = (x))) return rc
+    // FERRUM_HIP_TRACE_LAUNCHES=1 (with FERRUM_HIP_NO_GRAPH=1: a stream cannot be synchronised inside a capture): every step of
+    // the forward is named on stderr and waited for, so a faulting kernel is the last line printed
+    static const bool trace = getenv("FERRUM_HIP_TRACE_LAUNCHES") != nullptr && getenv("FERRUM_HIP_NO_GRAPH") != nullptr;
+#define RUN(x)                                                                       \
+    do {                                                                             \
+        if (trace) fprintf(stderr, "[ferrum_hip] T=%d %.70s\n", T, #x);              \
+        if ((rc = (x))) return rc;                                                   \
+        if (trace) FH_CHECK_HIP(hipStreamSynchronize(s));                            \
+    } while (0)
     // arrival counters of the split route kernel: re-armed by the kernel itself, but zeroed per forward as well so that an
     // aborted launch can never poison the next one (one 256-byte memset node per step)
     if (m->route_arrive) FH_CHECK_HIP(hipMemsetAsync(m->route_arrive, 0, 64 * sizeof(unsigned), s));
@@ -1247,10 +1255,17 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
     }
     if (int rc = reserve(m, reqs.data(), n, nullptr)) return rc;
     if (m->history_cap < steps * n) {
+        // the captured step holds the history pointer as a kernel argument: a graph recorded against the old buffer must
+        // not be replayed (it would write the sampled ids into freed memory)
+        if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+        FH_CHECK_HIP(hipStreamSynchronize(m->stream));
         if (m->history) (void)hipFree(m->history);
         m->history = nullptr;
-        FH_CHECK_HIP(hipMalloc((void**)&m->history, (size_t)steps * n * 4));
-        m->history_cap = steps * n;
+        m->history_cap = 0;
+        const int cap = std::max(steps * n, 4096);             // rarely regrown: 4096 ids cover 128 steps of 32 sequences
+        FH_CHECK_HIP(hipMalloc((void**)&m->history, (size_t)cap * 4));
+        m->history_cap = cap;
     }
     uint32_t* h_tok = reinterpret_cast<uint32_t*>(m->idx_host + m->il.tokens);
     uint32_t* h_cu = reinterpret_cast<uint32_t*>(m->idx_host + m->il.cu_seqlens);

@@ -249,6 +249,33 @@ def test_decode_steps_graph_equals_eager_and_oracle(pkg, monkeypatch):
         assert agree or True
 
 
+def test_decode_steps_graph_survives_history_regrowth(pkg, monkeypatch):
+    """A short decode_steps call followed by a longer one on the same batch replays the graph captured by the first (same
+    batch size, same kv bucket) while the sampled-id history buffer is regrown in between (regression: the replayed step
+    kept writing through the old pointer — wrong ids at best, a memory fault at c=64)."""
+    from tests import modelgen
+    tm = modelgen.TinyModel(True, layers=2, seed=23)
+    rng = np.random.default_rng(24)
+    V = tm.cfg["vocab"]
+    n = 40
+    prompts = [rng.integers(0, V, size=5 + i % 8).astype(np.uint32) for i in range(n)]
+    ids = list(range(n))
+    outs = []
+    for mode in ("graph", "eager"):
+        hm = tm.hip_model(pkg, kv_num_blocks=n * 10, max_seqs=n, max_tokens=512)
+        if mode == "eager":
+            monkeypatch.setenv("FERRUM_HIP_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("FERRUM_HIP_NO_GRAPH", raising=False)
+        first, _ = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+        a = hm.decode_steps(ids, first, 3)                       # captures the graph; the history buffer holds 4096 ids
+        b = hm.decode_steps(ids, a[-1], 110)                     # 4400 ids: regrown; kv ≤ 125 stays in the first bucket
+        c = hm.decode_steps(ids, b[-1], 4)
+        outs.append(np.concatenate([a, b, c]))
+    assert outs[0].shape == (117, n)
+    assert np.array_equal(outs[0], outs[1])
+
+
 FULL_DIMS = {
     # one layer at the BASELINE configs' real dimensions (SURVEY.md §8 shape glossary); vocabulary cut to 2048 rows so
     # the scalar f64 oracle finishes in tens of seconds.  c sequences decode together → the decode-sized fast paths
