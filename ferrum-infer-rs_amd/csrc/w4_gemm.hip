@@ -1553,8 +1553,12 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // LDS-shared activations (w4_gemm_ldsa_kernel) + fp32 split-K slabs + one reduce launch.  Measured at m = 32 against
     // the one-launch intra-workgroup split below (tools/exp_dense.py): down 14336→4096 31.3 → 18.4 µs (S = 8),
     // gate_up 4096→28672 25.7 → 23.2 µs (S = 2); the small projections (qkv, o) tie, so they keep the single launch.
-    static const int tile_min_m = getenv("FERRUM_HIP_W4_TILE_MIN_M") ? atoi(getenv("FERRUM_HIP_W4_TILE_MIN_M")) : 64;
-    if (m >= tile_min_m && w.perm == nullptr) {   // prefill: 64-row pipelined tiles (w4_gemm_tilep_kernel)
+    // 64-row pipelined tiles (w4_gemm_tilep_kernel) for prefill — and for 33–63 rows on the larger projections, where the
+    // skinny kernels' four row tiles re-fetch every activation fragment per 16–64 columns (c=48 decode, Llama-3.1-8B 5.18 →
+    // 4.02 ms per step, Gemma-3-27B 15.1 → 11.5; the 2048→5120 / 4096→2048 projections of Qwen3-30B-A3B are faster skinny)
+    static const int tile_min_env = getenv("FERRUM_HIP_W4_TILE_MIN_M") ? atoi(getenv("FERRUM_HIP_W4_TILE_MIN_M")) : 0;
+    const int tile_min_m = tile_min_env > 0 ? tile_min_env : ((long)w.k * w.n >= (12L << 20) ? 33 : 64);
+    if (m >= tile_min_m && w.perm == nullptr) {
         // too few tiles to cover the chip (narrow N or few rows): split K over grid.z into fp32 slabs + one reduce launch,
         // keeping ≥ 8 quant groups per split
         static const int tile_wgs = getenv("FERRUM_HIP_W4_TILE_WGS") ? atoi(getenv("FERRUM_HIP_W4_TILE_WGS")) : 256;

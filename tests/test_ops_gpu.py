@@ -140,7 +140,9 @@ def test_gptq_asymmetric_and_act_order(env, k, n, m):
     (1536, 1000, (5, 20, 64, 130), True), (2048, 640, (24, 64, 96), False), (14336, 512, (32, 64), True),
     # many row tiles through the pipelined tile kernel — ragged last tile, odd group count (K = 640: 5 groups), split-K
     # (narrow N), columns not a multiple of 256, asymmetric + bias
-    (640, 320, (1024, 1100), True), (2048, 512, (1024,), True), (1024, 1000, (1153,), True), (768, 640, (1025,), False)])
+    (640, 320, (1024, 1100), True), (2048, 512, (1024,), True), (1024, 1000, (1153,), True), (768, 640, (1025,), False),
+    # 33–63 rows of the larger projections (K·N ≥ 12 Mi) take the pipelined tile kernel with one ragged 64-row tile
+    (4096, 4096, (33, 48, 63), True), (2048, 6144, (40,), False)])
 def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym):
     pkg, B, ctx, O, torch = env
     qw, sc, qz = O.make_synthetic_gptq(k, n, 128, k * 7 + n, symmetric=sym)
