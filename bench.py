@@ -383,7 +383,11 @@ def main():
             import subprocess
             cmd = [exe, "--requests", "96", "--concurrency", str(c), "--prompt-len", str(PL), "--out-len", "128",
                    "--max-batched-tokens", str(chunk)] + (["--dense"] if args.model == "llama31-8b" else [])
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            # the child is not to be profiled when this process runs under rocprofv3 (its preloaded tool crashed in the
+            # child at exit): drop the profiler's environment
+            env = {k: v for k, v in os.environ.items()
+                   if not (k.startswith(("ROCP", "ROCPROF")) or (k in ("LD_PRELOAD", "HSA_TOOLS_LIB") and "rocprof" in v.lower()))}
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
             if p.returncode != 0:
                 raise RuntimeError(f"ferrum_hip_serve failed: {p.stderr[-500:]}")
             extra["serve_closed_loop"] = json.loads(p.stdout.strip().splitlines()[0])
