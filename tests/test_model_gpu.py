@@ -276,6 +276,34 @@ def test_decode_steps_graph_survives_history_regrowth(pkg, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
+def test_decode_graph_reused_across_sequence_sets(pkg, monkeypatch):
+    """The captured decode step is replayed for a NEW set of sequences of the same batch size (released ids, fresh block
+    tables, different lengths inside the same kv bucket): everything per-sequence must come from the device index buffers."""
+    from tests import modelgen
+    tm = modelgen.TinyModel(True, layers=2, seed=31)
+    rng = np.random.default_rng(32)
+    V = tm.cfg["vocab"]
+    sets = [[rng.integers(0, V, size=n).astype(np.uint32) for n in lens] for lens in ((11, 40, 3), (29, 5, 18), (7, 7, 60))]
+    outs = []
+    for mode in ("graph", "eager"):
+        hm = tm.hip_model(pkg, kv_num_blocks=48, max_seqs=8, max_tokens=128)
+        if mode == "eager":
+            monkeypatch.setenv("FERRUM_HIP_NO_GRAPH", "1")
+        else:
+            monkeypatch.delenv("FERRUM_HIP_NO_GRAPH", raising=False)
+        got = []
+        for si, prompts in enumerate(sets):
+            ids = [100 * si + i for i in range(3)]
+            first, _ = hm.unified_forward([(ids[i], p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+            a = hm.decode_steps(ids, first, 9)
+            b = hm.decode_steps(ids, a[-1], 8)
+            got.append(np.concatenate([first[None, :], a, b]))
+            for i in ids:
+                hm.release(i)
+        outs.append(np.stack(got))
+    assert np.array_equal(outs[0], outs[1])
+
+
 FULL_DIMS = {
     # one layer at the BASELINE configs' real dimensions (SURVEY.md §8 shape glossary); vocabulary cut to 2048 rows so
     # the scalar f64 oracle finishes in tens of seconds.  c sequences decode together → the decode-sized fast paths
