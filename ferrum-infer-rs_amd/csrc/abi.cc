@@ -32,6 +32,7 @@ struct FerrumHipGptq {
     bool symmetric = true;
     __half* gather_scratch = nullptr;   // act-order input gather buffer [m_cap, K]
     int gather_rows = 0;
+    std::vector<void*> retired_scratch;  // outgrown gather buffers: a graph captured earlier may still hold them → freed with the handle
 };
 
 #define H(p) reinterpret_cast<__half*>(p)
@@ -271,6 +272,7 @@ int ferrum_hip_gptq_free(FerrumHipGptq* g) {
     if (g->dev.perm) (void)hipFree(g->dev.perm);
     if (g->dev.bias) (void)hipFree(g->dev.bias);
     if (g->gather_scratch) (void)hipFree(g->gather_scratch);
+    for (void* p : g->retired_scratch) (void)hipFree(p);
     delete g;
     return 0;
 }
@@ -292,9 +294,10 @@ int ferrum_hip_gptq_linear_forward_f16(const FerrumHipGptq* handle, const void* 
     const __half* x = CH(in);
     if (g->dev.perm) {
         // act-order: gather input columns first (cuda/quant.rs:434).  The scratch grows outside
-        // of graph capture only (first call with a larger m).
+        // of graph capture only (first call with a larger m); the outgrown buffer stays allocated until the handle is
+        // freed, because a graph captured at the smaller m holds its address.
         if (g->gather_rows < m) {
-            if (g->gather_scratch) (void)hipFree(g->gather_scratch);
+            if (g->gather_scratch) g->retired_scratch.push_back(g->gather_scratch);
             g->gather_scratch = nullptr;
             FH_CHECK_HIP(hipMalloc((void**)&g->gather_scratch, (size_t)m * g->dev.k * 2));
             g->gather_rows = m;
