@@ -157,15 +157,15 @@ def moe_gemm_bytes(cfg, blocks, tokens, which):
 
 def cpu_baseline(cfg, seed=1):
     """Reference CPU path restated in C (oracle/, f64-accumulating GEMM, 1 thread like cpu.rs:483-491),
-    timed on a bounded sample: ONE of the 48 layers at the full Qwen3-30B-A3B dims, 16-token prefill then 6
-    decode tokens, plus one lm_head; scaled to 48 layers → decode tokens/s at c=1."""
+    timed on a bounded sample (≈ 10–15 s of one host core): ONE of the 48 layers at the full Qwen3-30B-A3B dims, 16-token
+    prefill then 48 decode tokens, plus one lm_head; scaled to 48 layers → decode tokens/s at c=1."""
     from oracle import oracle as O
     t_build = time.time()
     H, E, I = cfg["hidden"], cfg["num_experts"], cfg["expert_inter"]
     nq, nkv, hd, V = cfg["num_heads"], cfg["num_kv_heads"], cfg["head_dim"], cfg["vocab"]
     rng = np.random.default_rng(seed)
     om = O.OracleModel(num_layers=1, hidden=H, num_heads=nq, num_kv_heads=nkv, head_dim=hd, intermediate=0, vocab=V,
-                       max_seq_len=64, has_qk_norm=1, num_experts=E, top_k=cfg["top_k"], expert_inter=I,
+                       max_seq_len=96, has_qk_norm=1, num_experts=E, top_k=cfg["top_k"], expert_inter=I,
                        norm_topk_prob=1, rms_eps=1e-6, rope_theta=1e6)
     emb = (rng.standard_normal((V, H)) * 0.02).astype(np.float32)
     om.set_global("embed", emb)
@@ -189,10 +189,10 @@ def cpu_baseline(cfg, seed=1):
     build_s = time.time() - t_build
     toks = rng.integers(256, V, size=16).astype(np.uint32)
     om.forward(0, toks, 0)
-    n_dec = 6
+    n_dec = 48
     t0 = time.perf_counter()
     for i in range(n_dec):
-        om.forward(0, np.array([toks[i]], np.uint32), 16 + i)
+        om.forward(0, np.array([toks[i % 16]], np.uint32), 16 + i)
     t_total = (time.perf_counter() - t0) / n_dec               # one layer + final norm + lm_head
     x = rng.standard_normal((1, H)).astype(np.float32)
     t1 = time.perf_counter()
