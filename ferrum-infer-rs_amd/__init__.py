@@ -10,4 +10,4 @@ The directory name is not an importable identifier; load it with
 `__graft_entry__.load_package()` (registers it as module `ferrum_infer_rs_amd`).
 """
 from .backend import HipBackend, Context, GptqLinear, ExpertStack, load_library, build_library, LIB_PATH  # noqa: F401
-from .executor import HipModel, ModelConfig, BatchItem, Checkpoint  # noqa: F401
+from .executor import HipModel, ModelConfig, BatchItem, Checkpoint, Comm  # noqa: F401

@@ -8,6 +8,9 @@
 #include "block_allocator.h"
 #include "common.h"
 #include "kernels.h"
+#include "knobs.h"
+
+#include <atomic>
 
 namespace fh {
 static thread_local char g_err[1024] = "";
@@ -18,6 +21,48 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* last_error() { return g_err; }
+
+// ── development knobs (read once) and kernel-form accounting ────────────────
+static Knobs g_knobs;
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static bool env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
+void reload_knobs() {
+    Knobs k;
+    k.attn_no_flash = env_flag("FERRUM_HIP_ATTN_NO_FLASH");
+    k.attn_flash_min_rows_set = getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS") != nullptr;
+    k.attn_flash_min_rows = env_int("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", 512);
+    k.attn_splits = env_int("FERRUM_HIP_ATTN_SPLITS", 0);
+    k.attn_rs_min_wgs = env_int("FERRUM_HIP_ATTN_RS_MIN_WGS", 512);
+    k.attn_no_rs = env_flag("FERRUM_HIP_ATTN_NO_RS");
+    k.attn_narrow = env_flag("FERRUM_HIP_ATTN_NARROW");
+    k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 8);
+    k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
+    k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
+    k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
+    k.w4_ldsa_nw = env_int("FERRUM_HIP_W4_LDSA_NW", 0);
+    k.w4_ldsa_s = env_int("FERRUM_HIP_W4_LDSA_S", 0);
+    k.w4_nt = env_int("FERRUM_HIP_W4_NT", 0);
+    k.w4_w = env_int("FERRUM_HIP_W4_W", 0);
+    k.lds_min_wgs = env_int("FERRUM_HIP_LDS_MIN_WGS", 128);
+    k.lds_min_groups = env_int("FERRUM_HIP_LDS_MIN_GROUPS", 8);
+    k.no_graph = getenv("FERRUM_HIP_NO_GRAPH") != nullptr;
+    k.trace_launches = getenv("FERRUM_HIP_TRACE_LAUNCHES") != nullptr && k.no_graph;
+    k.time_same_layer = getenv("FERRUM_HIP_TIME_SAME_LAYER") != nullptr;
+    k.tp_oneshot = env_int("FERRUM_HIP_TP_ONESHOT", -1);
+    g_knobs = k;
+}
+namespace { struct KnobsInit { KnobsInit() { reload_knobs(); } } g_knobs_init; }
+const Knobs& knobs() { return g_knobs; }
+
+static std::atomic<uint64_t> g_form_hits[FORM_COUNT];
+void form_hit(Form f) { g_form_hits[f].fetch_add(1, std::memory_order_relaxed); }
+static const char* const g_form_names[FORM_COUNT] = {
+    "attn_flash", "attn_row_split", "attn_kv_wide", "attn_kv_narrow", "attn_fused_qkv_wide", "attn_fused_qkv_narrow",
+    "attn_split_reduce", "w4_wgsplit", "w4_ldsa", "w4_tilep", "w4_slabs", "w4_slabs_lds", "w4_slabs_tile", "w4_rowsum",
+    "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_merge_route", "route_split",
+    "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
+    "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear"};
+const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 
 using namespace fh;
@@ -47,6 +92,20 @@ int ferrum_native_op_init(void) { return 0; }
 const FerrumNativeOperatorDescriptor* ferrum_native_op_descriptor(void) { return &g_desc; }
 
 const char* ferrum_hip_last_error(void) { return fh::last_error(); }
+
+// ── debug: which kernel forms ran, and re-reading the development knobs ─────
+int ferrum_hip_debug_form_count(void) { return fh::FORM_COUNT; }
+const char* ferrum_hip_debug_form_name(int form) { return fh::form_name(form); }
+int ferrum_hip_debug_form_hits(uint64_t* hits, int capacity) {
+    FH_REQUIRE(hits && capacity >= fh::FORM_COUNT, "debug_form_hits: need room for %d counters", (int)fh::FORM_COUNT);
+    for (int i = 0; i < fh::FORM_COUNT; i++) hits[i] = fh::g_form_hits[i].load(std::memory_order_relaxed);
+    return 0;
+}
+int ferrum_hip_debug_form_reset(void) {
+    for (int i = 0; i < fh::FORM_COUNT; i++) fh::g_form_hits[i].store(0, std::memory_order_relaxed);
+    return 0;
+}
+int ferrum_hip_debug_reload_knobs(void) { fh::reload_knobs(); return 0; }
 
 int ferrum_hip_device_count(int* count) {
     FH_REQUIRE(count, "device_count: null output");

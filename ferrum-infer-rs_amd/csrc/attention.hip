@@ -24,6 +24,7 @@
 //    time (L1 hits instead of 4× the L2 traffic).
 #include "common.h"
 #include "kernels.h"
+#include "knobs.h"
 #include "kv_layout.h"
 #include "rope_rows.h"
 
@@ -690,11 +691,12 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     a.max_blocks = max_blocks_per_seq; a.sliding_window = sliding_window;
     a.scale = 1.0f / sqrtf((float)head_dim);
     // prefill-like batches (most sequences bring many rows): LDS-shared K/V form.  The token count bounds the work units.
-    const bool flash_off = getenv("FERRUM_HIP_ATTN_NO_FLASH") && atoi(getenv("FERRUM_HIP_ATTN_NO_FLASH"));
-    const long flash_min_rows = getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS") ? atol(getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS")) : 512;   // tests lower it
+    const Knobs& kn = knobs();                                   // read once at library load (knobs.h), never per launch
+    const bool flash_off = kn.attn_no_flash;
+    const long flash_min_rows = kn.attn_flash_min_rows;          // tests lower it
     // … and only when its workgroups (128 rows × one kv head each) cover the chip: a lone 256-token prompt has 64 of them and
     // is faster KV-split over 512 workgroups (TTFT 6.7 vs 7.1 ms)
-    const long flash_min_wgs = getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS") ? 1 : 256;
+    const long flash_min_wgs = kn.attn_flash_min_rows_set ? 1 : 256;
     if (!fq && cu_seqlens_q && !flash_off && (long)max_q_len * G >= flash_min_rows &&
         (long)total_q_tokens * 2 >= (long)num_seqs * max_q_len &&
         ((long)total_q_tokens * G / (head_dim == 256 ? 64 : 128)) * num_kv_heads >= flash_min_wgs) {
@@ -716,11 +718,12 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
         if (head_dim == 128) FH_FLASH(128, 2) else if (head_dim == 64) FH_FLASH(64, 2) else FH_FLASH(256, 1)
 #undef FH_FLASH
         FH_CHECK_LAUNCH();
+        form_hit(FORM_ATTN_FLASH);
         return 0;
     }
     const int tiles = num_seqs * a.tiles_per_seq;
     int nsplit = choose_splits(tiles, num_kv_heads, max_kv_len);
-    if (const char* e = getenv("FERRUM_HIP_ATTN_SPLITS")) nsplit = atoi(e);   // tuning override (development)
+    if (kn.attn_splits > 0) nsplit = kn.attn_splits;             // tuning override (development)
     size_t need = (size_t)tiles * num_kv_heads * nsplit * 16 * (head_dim + 2) * sizeof(float);
     if (nsplit > 1 && (workspace == nullptr || need > workspace_bytes)) nsplit = 1;
     a.nsplit = nsplit;
@@ -732,9 +735,9 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     dim3 grid(tiles, num_kv_heads, nsplit);
     // prefill (≥ 4 row tiles per sequence, no KV split): the waves of a workgroup take consecutive row tiles
     // (only when that still leaves ≥ 2 workgroups per CU: a single 256-token prompt is faster KV-split, 7.5 vs 7.85 ms TTFT)
-    const long rs_min_wgs = getenv("FERRUM_HIP_ATTN_RS_MIN_WGS") ? atol(getenv("FERRUM_HIP_ATTN_RS_MIN_WGS")) : 512;   // tests lower it
+    const long rs_min_wgs = kn.attn_rs_min_wgs;                  // tests lower it
     const bool rs = !fq && nsplit == 1 && a.tiles_per_seq >= 4 && (long)num_seqs * cdiv(a.tiles_per_seq, 4) * num_kv_heads >= rs_min_wgs &&
-                    !(getenv("FERRUM_HIP_ATTN_NO_RS") && atoi(getenv("FERRUM_HIP_ATTN_NO_RS")));
+                    !kn.attn_no_rs;
     if (rs) grid = dim3(num_seqs * cdiv(a.tiles_per_seq, 4), num_kv_heads, 1);
     // ragged batch without a KV split: enumerate only the real work units (upper bound from the token count)
     if (cu_seqlens_q && nsplit == 1 && a.tiles_per_seq > 1) {
@@ -746,7 +749,7 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
         }
     }
     // decode with ≥ 8 block pairs per split: 8 waves per workgroup (more loads in flight per CU)
-    const bool wide = max_q_len == 1 && cdiv(cdiv(max_kv_len, KV_BLOCK), 2) / nsplit >= 8 && !(getenv("FERRUM_HIP_ATTN_NARROW") && atoi(getenv("FERRUM_HIP_ATTN_NARROW")));
+    const bool wide = max_q_len == 1 && cdiv(cdiv(max_kv_len, KV_BLOCK), 2) / nsplit >= 8 && !kn.attn_narrow;
 #define FH_ATTN(HDV)                                                                              \
     if (fq && wide) hipLaunchKernelGGL((paged_attn_kernel<HDV, true, 8>), grid, dim3(512), 0, s, a);       \
     else if (fq) hipLaunchKernelGGL((paged_attn_kernel<HDV, true, 4>), grid, dim3(256), 0, s, a);          \
@@ -760,6 +763,9 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     }
     if (head_dim == 128) { FH_ATTN(128) } else if (head_dim == 64) { FH_ATTN(64) } else { FH_ATTN(256) }
 #undef FH_ATTN
+    form_hit(fq ? (wide ? FORM_ATTN_FUSED_QKV_WIDE : FORM_ATTN_FUSED_QKV_NARROW)
+                : rs ? FORM_ATTN_ROW_SPLIT : (wide ? FORM_ATTN_KV_WIDE : FORM_ATTN_KV_NARROW));
+    if (nsplit > 1) form_hit(FORM_ATTN_SPLIT_REDUCE);
     return 0;
 }
 

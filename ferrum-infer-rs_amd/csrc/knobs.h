@@ -1,0 +1,83 @@
+// Development knobs and kernel-form accounting.
+//
+// Knobs: every FERRUM_HIP_* tuning variable a launcher consults is read ONCE (library load) into this struct —
+// no getenv on a launch path.  Tests that steer a kernel form set the variable and call
+// ferrum_hip_debug_reload_knobs(); product code never does.
+//
+// Forms: each launcher records which kernel form it chose (one relaxed atomic add at enqueue time), so a test
+// that names a form can assert that this form — not a neighbour picked by a drifted heuristic — produced the
+// result it checked (ferrum_hip_debug_form_hits).  A hipGraph replay does not re-count its captured launches;
+// FORM_GRAPH_REPLAY counts replays.
+#pragma once
+#include <stdint.h>
+
+namespace fh {
+
+struct Knobs {
+    // paged attention (attention.hip)
+    bool attn_no_flash = false;
+    bool attn_flash_min_rows_set = false;
+    long attn_flash_min_rows = 512;
+    int attn_splits = 0;              // > 0: forced KV split count
+    long attn_rs_min_wgs = 512;
+    bool attn_no_rs = false;
+    bool attn_narrow = false;
+    // INT4 GEMMs (w4_gemm.hip)
+    int moe_kw_pairs = 8;
+    int w4_tile_min_m = 0;
+    int w4_tile_wgs = 256;
+    int w4_ldsa = 1;
+    int w4_ldsa_nw = 0;
+    int w4_ldsa_s = 0;
+    int w4_nt = 0;
+    int w4_w = 0;
+    int lds_min_wgs = 128;
+    int lds_min_groups = 8;
+    // runner
+    bool no_graph = false;
+    bool trace_launches = false;
+    bool time_same_layer = false;
+    int tp_oneshot = -1;              // -1 auto, 0 never, 1 always (tensor-parallel all-reduce form)
+};
+
+const Knobs& knobs();
+void reload_knobs();
+
+enum Form : int {
+    FORM_ATTN_FLASH = 0,        // paged_prefill_attn_kernel (LDS-shared K/V, long prompts)
+    FORM_ATTN_ROW_SPLIT,        // paged_attn_kernel<…, RS> (four row tiles per workgroup)
+    FORM_ATTN_KV_WIDE,          // paged_attn_kernel 8 waves (decode, ≥ 8 block pairs per split)
+    FORM_ATTN_KV_NARROW,        // paged_attn_kernel 4 waves
+    FORM_ATTN_FUSED_QKV_WIDE,   // decode with QK-norm + RoPE + KV write in the prologue, 8 waves
+    FORM_ATTN_FUSED_QKV_NARROW,
+    FORM_ATTN_SPLIT_REDUCE,     // KV-split partials + reduce launch
+    FORM_W4_WGSPLIT,            // ≤ 16 rows (and small projections): K split over the waves of a workgroup
+    FORM_W4_LDSA,               // 17–32 rows: LDS-shared activations
+    FORM_W4_TILEP,              // ≥ 33/64 rows: pipelined 64-row tiles
+    FORM_W4_SLABS,              // fp32 split-K slabs from the skinny kernel
+    FORM_W4_SLABS_LDS,          // … from the LDS-shared-activation kernel
+    FORM_W4_SLABS_TILE,         // … from the pipelined tile kernel
+    FORM_W4_ROWSUM,             // prefill tile kernel with activation row sums taken at LDS staging
+    FORM_MOE_EXPERT_MAJOR,
+    FORM_MOE_INLINE_ALIGN,
+    FORM_MOE_BLOCK16,
+    FORM_MOE_TILE64,
+    FORM_MOE_TILE32,
+    FORM_MOE_MERGE_ROUTE,
+    FORM_ROUTE_SPLIT,           // add + norm + router split over Q parts per token, merge in the launch
+    FORM_ROUTE_FUSED,           // add + norm + router + top-k, one workgroup per token
+    FORM_ROUTE_GEMM,            // router as a GEMM over all tokens + top-k kernel
+    FORM_DENSE_SLAB_CHAIN,      // dense MLP block: slab GEMMs reduced by their consumers
+    FORM_GRAPH_CAPTURE,
+    FORM_GRAPH_REPLAY,
+    FORM_TP_ALLREDUCE_RCCL,
+    FORM_TP_ALLREDUCE_LOOPBACK,
+    FORM_TP_ALLREDUCE_ONESHOT,
+    FORM_F16_DENSE_LINEAR,      // unquantised projection (DenseLinear)
+    FORM_COUNT
+};
+
+void form_hit(Form f);
+const char* form_name(int f);
+
+}  // namespace fh

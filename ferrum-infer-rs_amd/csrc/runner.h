@@ -108,7 +108,8 @@ struct FerrumHipModel {
     // tensor parallel (RCCL, resolved lazily by dlopen)
     uint8_t* greedy_opts_dev = nullptr;    // token mask + sparse repetition-penalty arrays of the current forward
     size_t greedy_opts_bytes = 0;
-    void* nccl_comm = nullptr;
+    struct FerrumHipComm* comm = nullptr;   // RCCL rank and/or one-shot peer group (tp_comm.hip)
+    bool comm_owned = false;
     struct FerrumHipTpLoopback* tp_loopback = nullptr;   // in-process test stand-in for the communicator
     __half* tp_tmp = nullptr;
     size_t tp_tmp_elems = 0;

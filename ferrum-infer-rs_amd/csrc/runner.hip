@@ -9,10 +9,11 @@
 //   embed → L × { rms_norm → qkv → split/qk-norm/rope/paged-write → paged attention → o_proj →
 //   fused_add_rms_norm → [gate_up → act·mul → down | router → top-k → align → grouped gate_up(+silu·mul)
 //   → grouped down → combine] → residual add } → final rms_norm (sampled rows) → lm_head → argmax.
-#include <dlfcn.h>
 #include <math.h>
 
 #include "runner.h"
+#include "knobs.h"
+#include "tp_comm.h"
 
 #include <condition_variable>
 #include <mutex>
@@ -162,23 +163,7 @@ int check_shape(const char* what, int k, int n, int ek, int en) {
 
 }  // namespace
 
-// RCCL entry points resolved at tp_init
 namespace {
-struct UidBlob { char b[128]; };   // ncclUniqueId is passed by value (128 bytes)
-typedef int (*nccl_get_uid_t)(void*);
-typedef int (*nccl_comm_init_rank_t)(void**, int, UidBlob, int);
-typedef int (*nccl_all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
-void* g_rccl = nullptr;
-nccl_all_reduce_t g_all_reduce = nullptr;
-int load_rccl() {
-    if (g_rccl) return 0;
-    g_rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!g_rccl) g_rccl = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    FH_REQUIRE(g_rccl, "tensor parallel: cannot dlopen librccl.so: %s", dlerror());
-    g_all_reduce = (nccl_all_reduce_t)dlsym(g_rccl, "ncclAllReduce");
-    FH_REQUIRE(g_all_reduce, "tensor parallel: ncclAllReduce not found");
-    return 0;
-}
 // Σ over ranks in rank order, fp32 accumulate, one rounding — every rank computes the same bits
 __global__ void loopback_sum_kernel(const __half* const* bufs, int world, __half* out, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -234,14 +219,16 @@ int loopback_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
 
 int tp_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
     if (m->cfg.tp_world <= 1) return 0;
-    if (m->tp_loopback) return loopback_all_reduce(m, buf, count);
-    FH_REQUIRE(m->nccl_comm && g_all_reduce, "tensor parallel: communicator not initialised (ferrum_hip_model_tp_init)");
-    // ncclFloat16 = 6, ncclSum = 0 (rccl.h); in-place fp16 sum like nccl_comm.rs all_reduce_in_place
-    int rc = g_all_reduce(buf, buf, count, 6, 0, m->nccl_comm, m->stream);
-    FH_REQUIRE(rc == 0, "ncclAllReduce failed: %d", rc);
-    return 0;
+    if (m->tp_loopback) { form_hit(FORM_TP_ALLREDUCE_LOOPBACK); return loopback_all_reduce(m, buf, count); }
+    FH_REQUIRE(m->comm, "tensor parallel: no communicator (ferrum_hip_model_tp_init / ferrum_hip_model_set_comm)");
+    return comm_all_reduce_f16(m->comm, buf, count, m->stream);
 }
 }  // namespace
+
+static void drop_graph(FerrumHipModel* m) {
+    if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+}
 
 static int q_dim(const FerrumHipModelConfig& c) { return c.num_heads * c.head_dim; }
 static int kv_dim(const FerrumHipModelConfig& c) { return c.num_kv_heads * c.head_dim; }
@@ -304,7 +291,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_ROUTE_GEMM_TOKENS")) m->route_gemm_min_tokens = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
-    if (const char* e = getenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS")) m->attn_flash_min_rows = std::max(1, atoi(e));   // as the launcher reads it
+    if (knobs().attn_flash_min_rows_set) m->attn_flash_min_rows = std::max(1, (int)knobs().attn_flash_min_rows);   // as the launcher reads it
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE32_PAIRS")) m->moe_tile32_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
     return 0;
@@ -312,8 +299,8 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
 
 int ferrum_hip_model_destroy(FerrumHipModel* m) {
     if (!m) return 0;
-    if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
-    if (m->graph) (void)hipGraphDestroy(m->graph);
+    drop_graph(m);
+    if (m->comm && m->comm_owned) ferrum_hip_comm_destroy(m->comm);
     for (auto& L : m->layers) {
         for (__half* p : {L.input_ln, L.post_ln, L.q_norm, L.k_norm, L.router, L.k_pool, L.v_pool, L.post_attn_ln, L.post_ffn_ln, L.qkv_bias})
             if (p) (void)hipFree(p);
@@ -455,7 +442,11 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
     if (int rc = alloc_fill(&m->final_norm, c.hidden, 1.0f)) return rc;
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
-        uint64_t ls = seed + 0x1000003ull * (uint64_t)(li + 1);
+        // replicated tensors (router, norms) come from the layer seed; the sharded projections of a tensor-parallel rank
+        // additionally mix in the rank, so every rank holds its own slice-shaped weights while embed / lm_head / norms /
+        // router agree across ranks (all ranks then sample the same token from identical all-reduced activations)
+        const uint64_t ls0 = seed + 0x1000003ull * (uint64_t)(li + 1);
+        const uint64_t ls = ls0 + 0x51ed270bull * (uint64_t)(c.tp_world > 1 ? c.tp_rank : 0);
         if (int rc = alloc_fill(&L.input_ln, c.hidden, 1.0f)) return rc;
         if (int rc = alloc_fill(&L.post_ln, c.hidden, 1.0f)) return rc;
         if (c.sandwich_norms) {
@@ -469,7 +460,7 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
         if (int rc = synth_w4(&L.qkv, c.hidden, qkv_dim(c), 1, false, ls ^ 0x11, s)) return rc;
         if (int rc = synth_w4(&L.o, q_dim(c), c.hidden, 1, false, ls ^ 0x22, s)) return rc;
         if (c.num_experts > 0) {
-            if (int rc = alloc_normal(&L.router, (long)c.num_experts * c.hidden, ls ^ 0x33, 0.02f)) return rc;
+            if (int rc = alloc_normal(&L.router, (long)c.num_experts * c.hidden, ls0 ^ 0x33, 0.02f)) return rc;
             if (int rc = synth_w4(&L.exp_gate_up, c.hidden, 2 * c.expert_inter, c.num_experts, true, ls ^ 0x44, s)) return rc;
             if (int rc = synth_w4(&L.exp_down, c.expert_inter, c.hidden, c.num_experts, false, ls ^ 0x55, s)) return rc;
             L.exp_loaded.assign(c.num_experts, 3);
@@ -880,7 +871,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     int rc;
     // FERRUM_HIP_TRACE_LAUNCHES=1 (with FERRUM_HIP_NO_GRAPH=1: a stream cannot be synchronised inside a capture): every step of
     // the forward is named on stderr and waited for, so a faulting kernel is the last line printed
-    static const bool trace = getenv("FERRUM_HIP_TRACE_LAUNCHES") != nullptr && getenv("FERRUM_HIP_NO_GRAPH") != nullptr;
+    const bool trace = knobs().trace_launches;
 #define RUN(x)                                                                       \
     do {                                                                             \
         if (trace) fprintf(stderr, "[ferrum_hip] T=%d %.70s\n", T, #x);              \
@@ -954,12 +945,17 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             const int tiles = (E + 15) / 16;
             int Q = m->route_parts;
             while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
-            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && c.tp_world == 1 && Q >= 1 && tiles / Q <= 8 && !L.o.perm;
+            const bool tp = c.tp_world > 1;   // attention heads sharded, o_proj row-parallel: all-reduce before the add + norm + route kernel
+            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && Q >= 1 && tiles / Q <= 8 && !L.o.perm;
             if (decode_fast) {
                 // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
                 const float* slabs = nullptr;
                 int S = m->o_slabs, rows_pad = 0, n_pad = 0;
-                if (S > 0 && T > 16 && T <= 32 && !L.o.bias) {
+                if (tp) {
+                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+                    RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+                    S = 0;
+                } else if (S > 0 && T > 16 && T <= 32 && !L.o.bias) {
                     // 17–32 rows: activations staged once per workgroup in LDS (a wave fetching its own fragments pulls 2× the
                     // weight bytes from L2); decode c=32 4.60 → 4.57 ms per step
                     RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
@@ -971,6 +967,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 } else {
                     RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
                 }
+                form_hit(Q > 1 ? FORM_ROUTE_SPLIT : FORM_ROUTE_FUSED);
                 if (Q > 1) {
                     // B over Q expert parts per token (one CU pulls the 512-KB router at ≈70 GB/s; Q CUs share it):
                     // residual → residual2 (ping-pong), norm_out; each token's last-arriving part merges the Q
@@ -990,7 +987,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
                                                      m->norm_out, T, K, H, s));
                 }
-            } else if (T >= 64 && T < m->route_gemm_min_tokens && c.tp_world == 1 && !L.o.perm && !L.o.bias && m->o_slabs > 0) {
+            } else if (T >= 64 && T < m->route_gemm_min_tokens && !tp && !L.o.perm && !L.o.bias && m->o_slabs > 0) {
                 // short prefill / a prompt riding along with the decode batch: o_proj as fp32 split-K slabs straight into the
                 // add + norm + route kernel (no reduce launch)
                 int S = 1, rows_pad = 0, n_pad = 0;
@@ -1004,6 +1001,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             } else {
                 RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
                 RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+                form_hit(T >= m->route_gemm_min_tokens ? FORM_ROUTE_GEMM : FORM_ROUTE_FUSED);
                 if (T >= m->route_gemm_min_tokens) {
                     // prefill: one workgroup per token would pull the whole router (E·H·2 B) from L2 per token (2048 tokens:
                     // 1 GB, 95 µs) — run the router as a GEMM over all tokens instead, then the top-k kernel
@@ -1023,9 +1021,23 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             const int I = c.intermediate;
             // 17–32 rows, one GPU: every projection of the MLP block writes fp32 split-K slabs (LDS-shared activations) and
             // the consumer that exists anyway — add+norm, gated activation — sums them: no reduce launches.
-            const bool slab_chain = m->dense_slabs && c.tp_world == 1 && T > 16 && T <= 32 && !L.o.perm && !L.gate_up.perm && !L.down.perm;
+            // Tensor parallel (o / down row-parallel): the partial sums of the ranks meet in an all-reduce, so those two
+            // projections produce fp16 partials (GEMM + reduce), all-reduce, then add + norm; the column-parallel gate_up keeps
+            // its slabs → gated-activation form.  Everything stays stream-ordered device work, so the step is still one graph.
+            const bool tp = c.tp_world > 1;
+            const bool slab_chain = m->dense_slabs && T > 16 && T <= 32 && !L.o.perm && !L.gate_up.perm && !L.down.perm;
             int S = 0, rows_pad = 0, n_pad = 0;
             if (slab_chain) {
+                form_hit(FORM_DENSE_SLAB_CHAIN);
+                if (tp) {
+                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+                    RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+                    if (sandwich) {
+                        RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                    } else {
+                        RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                    }
+                } else {
                 RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                 if (sandwich) {
                     RUN(sandwich_add_rms_norm_f32_slabs(m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_attn_ln, m->residual_f32,
@@ -1034,10 +1046,22 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
                                                            c.rms_eps, m->norm_out, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, T, H, s));
                 }
+                }
                 S = 0;
                 RUN(w4_gemm_dense_slabs_lds(L.gate_up, m->norm_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                 RUN(fused_gated_act_slabs_f16(m->workspace, S, (long)rows_pad * n_pad, n_pad, m->act_out, T, I, c.activation == 1, s));
                 S = 0;
+                if (tp) {
+                    RUN(dense_linear(m, L.down, m->act_out, m->mlp_out, T, s));
+                    RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
+                    if (sandwich) {
+                        RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s));
+                    } else if (next_ln) {
+                        RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s));
+                    } else {
+                        RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
+                    }
+                } else {
                 RUN(w4_gemm_dense_slabs_lds(L.down, m->act_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                 if (sandwich) {
                     RUN(sandwich_add_rms_norm_f32_slabs(m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ffn_ln, m->residual_f32,
@@ -1047,6 +1071,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad,
                                                            next_ln ? next_ln : L.input_ln, c.rms_eps, m->norm_out, nullptr, 0, 0, 0,
                                                            nullptr, nullptr, nullptr, T, H, s));
+                }
                 }
             } else {
             RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
@@ -1257,8 +1282,7 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
     if (m->history_cap < steps * n) {
         // the captured step holds the history pointer as a kernel argument: a graph recorded against the old buffer must
         // not be replayed (it would write the sampled ids into freed memory)
-        if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-        if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+        drop_graph(m);
         FH_CHECK_HIP(hipStreamSynchronize(m->stream));
         if (m->history) (void)hipFree(m->history);
         m->history = nullptr;
@@ -1299,15 +1323,17 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
 
     // One decode step is captured into a hipGraph (BackendGraph, capabilities.rs:35-70) and
     // replayed: every per-step quantity lives in device buffers.  A graph is reusable while
-    // (n, grid-shaping max_kv_len bucket) stay the same.  TP uses eager launches (RCCL).
-    const bool use_graph = c.tp_world == 1 && !m->taps_enabled && getenv("FERRUM_HIP_NO_GRAPH") == nullptr;
+    // (n, grid-shaping max_kv_len bucket) stay the same.
+    // Tensor parallel: RCCL and the one-shot peer reduce are stream-ordered device work and are captured with the step;
+    // only the host-barrier loopback of the tests cannot be.
+    const bool use_graph = !(c.tp_world > 1 && m->tp_loopback) && !m->taps_enabled && !knobs().no_graph;
     int kv_bucket = cdiv(sh.max_kv_len, 256) * 256;
     sh.max_kv_len = kv_bucket;
     if (use_graph) {
         if (!m->graph_exec || m->graph_n != n || m->graph_max_kv != kv_bucket) {
-            if (m->graph_exec) { (void)hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
-            if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
+            drop_graph(m);
             FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+            form_hit(FORM_GRAPH_CAPTURE);
             FH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
             int rc = enqueue_step();
             hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
@@ -1317,7 +1343,7 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
             m->graph_n = n;
             m->graph_max_kv = kv_bucket;
         }
-        for (int st = 0; st < steps; st++) FH_CHECK_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+        for (int st = 0; st < steps; st++) { FH_CHECK_HIP(hipGraphLaunch(m->graph_exec, m->stream)); form_hit(FORM_GRAPH_REPLAY); }
     } else {
         for (int st = 0; st < steps; st++)
             if (int rc = enqueue_step()) return rc;
@@ -1385,7 +1411,7 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     };
     FH_REQUIRE(which >= 2 || E > 0, "time_kernel: MoE kernel on a dense model");
     FH_REQUIRE(which < 6 || E == 0, "time_kernel: dense MLP kernel on a MoE model");
-    const bool same_layer = getenv("FERRUM_HIP_TIME_SAME_LAYER") != nullptr;   // experiment: weights resident in the Infinity Cache
+    const bool same_layer = knobs().time_same_layer;   // experiment: weights resident in the Infinity Cache
     // warm-up round (code objects, TLBs), then the timed rounds
     for (int li = 0; li < c.num_layers && !rc; li++) rc = one(li);
     if (rc) return rc;
@@ -1400,47 +1426,6 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     (void)hipEventDestroy(e1);
     if (rc) return rc;
     *avg_us = ms * 1000.0f / (float)launches;
-    return 0;
-}
-
-int ferrum_hip_tp_unique_id(uint8_t id[128]) {
-    if (int rc = load_rccl()) return rc;
-    auto f = (nccl_get_uid_t)dlsym(g_rccl, "ncclGetUniqueId");
-    FH_REQUIRE(f, "tensor parallel: ncclGetUniqueId not found");
-    int rc = f(id);
-    FH_REQUIRE(rc == 0, "ncclGetUniqueId failed: %d", rc);
-    return 0;
-}
-
-// Plumbing self-test against the installed librccl: a 1-rank communicator on the current device all-reduces (fp16, sum,
-// in place) a known vector on a private stream; the vector must come back unchanged.  Exercises exactly the entry points,
-// enum values and by-value ncclUniqueId passing the tensor-parallel path uses (which needs ≥ 2 GPUs to run for real).
-int ferrum_hip_tp_selftest(int count) {
-    FH_REQUIRE(count > 0 && count <= (1 << 20), "tp_selftest: count=%d", count);
-    if (int rc = load_rccl()) return rc;
-    auto get_uid = (nccl_get_uid_t)dlsym(g_rccl, "ncclGetUniqueId");
-    auto init = (nccl_comm_init_rank_t)dlsym(g_rccl, "ncclCommInitRank");
-    auto destroy = (int (*)(void*))dlsym(g_rccl, "ncclCommDestroy");
-    FH_REQUIRE(get_uid && init && destroy, "tp_selftest: RCCL symbols missing");
-    UidBlob blob;
-    FH_REQUIRE(get_uid(blob.b) == 0, "tp_selftest: ncclGetUniqueId failed");
-    void* comm = nullptr;
-    FH_REQUIRE(init(&comm, 1, blob, 0) == 0 && comm, "tp_selftest: ncclCommInitRank failed");
-    std::vector<__half> host(count), back(count);
-    for (int i = 0; i < count; i++) host[i] = __float2half((float)(i % 257) * 0.25f - 16.0f);
-    __half* dev = nullptr;
-    hipStream_t s = nullptr;
-    FH_CHECK_HIP(hipMalloc((void**)&dev, (size_t)count * 2));
-    FH_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    FH_CHECK_HIP(hipMemcpyAsync(dev, host.data(), (size_t)count * 2, hipMemcpyHostToDevice, s));
-    const int rc = g_all_reduce(dev, dev, (size_t)count, 6 /* ncclFloat16 */, 0 /* ncclSum */, comm, s);
-    FH_CHECK_HIP(hipMemcpyAsync(back.data(), dev, (size_t)count * 2, hipMemcpyDeviceToHost, s));
-    FH_CHECK_HIP(hipStreamSynchronize(s));
-    (void)destroy(comm);
-    (void)hipStreamDestroy(s);
-    (void)hipFree(dev);
-    FH_REQUIRE(rc == 0, "tp_selftest: ncclAllReduce failed: %d", rc);
-    FH_REQUIRE(memcmp(host.data(), back.data(), (size_t)count * 2) == 0, "tp_selftest: 1-rank all-reduce changed the data");
     return 0;
 }
 
@@ -1462,16 +1447,30 @@ int ferrum_hip_model_tp_attach_loopback(FerrumHipModel* m, FerrumHipTpLoopback* 
     return 0;
 }
 
+// RCCL rank of this model's tensor-parallel group (nccl_comm.rs:21-49): the communicator is owned by the model.
 int ferrum_hip_model_tp_init(FerrumHipModel* m, const uint8_t id[128]) {
     FH_REQUIRE(m && id, "tp_init: null");
     if (m->cfg.tp_world <= 1) return 0;
-    if (int rc = load_rccl()) return rc;
-    auto f = (nccl_comm_init_rank_t)dlsym(g_rccl, "ncclCommInitRank");
-    FH_REQUIRE(f, "tensor parallel: ncclCommInitRank not found");
-    UidBlob blob;
-    memcpy(blob.b, id, 128);
-    int rc = f(&m->nccl_comm, m->cfg.tp_world, blob, m->cfg.tp_rank);
-    FH_REQUIRE(rc == 0, "ncclCommInitRank failed: %d", rc);
+    FerrumHipComm* c = nullptr;
+    if (int rc = ferrum_hip_comm_create_rccl(&c, m->cfg.tp_world, m->cfg.tp_rank, id)) return rc;
+    if (m->comm && m->comm_owned) ferrum_hip_comm_destroy(m->comm);
+    m->comm = c;
+    m->comm_owned = true;
+    drop_graph(m);
+    return 0;
+}
+
+// Attach a communicator created by the caller (ferrum_hip_comm_create_*); the model does not own it.  Also the way to
+// re-read the all-reduce policy after ferrum_hip_debug_reload_knobs: a captured decode graph is dropped here.
+int ferrum_hip_model_set_comm(FerrumHipModel* m, FerrumHipComm* comm) {
+    FH_REQUIRE(m, "model_set_comm: null model");
+    FH_REQUIRE(!comm || (ferrum_hip_comm_world_size(comm) == m->cfg.tp_world && ferrum_hip_comm_rank(comm) == m->cfg.tp_rank),
+               "model_set_comm: communicator is rank %d of %d, model is rank %d of %d", comm ? ferrum_hip_comm_rank(comm) : 0,
+               comm ? ferrum_hip_comm_world_size(comm) : 1, m->cfg.tp_rank, m->cfg.tp_world);
+    if (m->comm && m->comm_owned) ferrum_hip_comm_destroy(m->comm);
+    m->comm = comm;
+    m->comm_owned = false;
+    drop_graph(m);
     return 0;
 }
 

@@ -1,0 +1,14 @@
+// Internal view of the tensor-parallel communicator (tp_comm.hip) for the runner.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+struct FerrumHipComm;
+
+namespace fh {
+int comm_world(const FerrumHipComm* c);
+// fp16 sum all-reduce in place on `s`: one-shot peer kernel when the message fits and the policy picks it, else RCCL.
+int comm_all_reduce_f16(FerrumHipComm* c, __half* buf, size_t count, hipStream_t s);
+bool comm_oneshot_fits(const FerrumHipComm* c, size_t count);
+}  // namespace fh

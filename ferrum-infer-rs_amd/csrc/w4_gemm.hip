@@ -19,6 +19,7 @@
 //  * split-K writes fp32 slabs that a small epilogue kernel sums in fixed order (deterministic).
 #include "common.h"
 #include "kernels.h"
+#include "knobs.h"
 
 namespace fh {
 
@@ -1517,7 +1518,7 @@ static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_
     hipLaunchKernelGGL((w4_gemm_kernel<MTV, ZPV, MODE>), grid, dim3(MODE == 0 ? 256 : 64), 0, stream, a)
     if constexpr (MODE != 0) {
         // few pairs (decode at c ≤ 8): 4 waves per workgroup split K (see KW); the candidate-merge prologue keeps KW = 1
-        static const int kw_pairs = getenv("FERRUM_HIP_MOE_KW_PAIRS") ? atoi(getenv("FERRUM_HIP_MOE_KW_PAIRS")) : 8;   // measured: c=1 +10 %, c ≥ 4 slightly slower
+        const int kw_pairs = knobs().moe_kw_pairs;   // default 8, measured: c=1 +10 %, c ≥ 4 slightly slower
         const bool rt = a.cand != nullptr || a.pair_expert_ids != nullptr;      // routing prologue inside the launch (owns LDS)
         const bool kw4 = a.M <= kw_pairs && a.cand == nullptr && a.G >= 4;
 #define FH_W4_MOE(ZPV, KWV, RTV) hipLaunchKernelGGL((w4_gemm_kernel<1, ZPV, MODE, KWV, RTV>), grid, dim3(64 * KWV), 0, stream, a)
@@ -1556,12 +1557,13 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // 64-row pipelined tiles (w4_gemm_tilep_kernel) for prefill — and for 33–63 rows on the larger projections, where the
     // skinny kernels' four row tiles re-fetch every activation fragment per 16–64 columns (c=48 decode, Llama-3.1-8B 5.18 →
     // 4.02 ms per step, Gemma-3-27B 15.1 → 11.5; the 2048→5120 / 4096→2048 projections of Qwen3-30B-A3B are faster skinny)
-    static const int tile_min_env = getenv("FERRUM_HIP_W4_TILE_MIN_M") ? atoi(getenv("FERRUM_HIP_W4_TILE_MIN_M")) : 0;
+    const Knobs& kn = knobs();
+    const int tile_min_env = kn.w4_tile_min_m;
     const int tile_min_m = tile_min_env > 0 ? tile_min_env : ((long)w.k * w.n >= (12L << 20) ? 33 : 64);
     if (m >= tile_min_m && w.perm == nullptr) {
         // too few tiles to cover the chip (narrow N or few rows): split K over grid.z into fp32 slabs + one reduce launch,
         // keeping ≥ 8 quant groups per split
-        static const int tile_wgs = getenv("FERRUM_HIP_W4_TILE_WGS") ? atoi(getenv("FERRUM_HIP_W4_TILE_WGS")) : 256;
+        const int tile_wgs = kn.w4_tile_wgs;
         const int cols = cdiv(w.n64, 4), rts = cdiv(m, 64);
         int S = 1;
         while ((long)cols * rts * S < tile_wgs && w.G / (S * 2) >= 8) S *= 2;
@@ -1571,22 +1573,23 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
         a.rows_pad = rows_pad; a.n_pad = n_pad;
         a.partial = S > 1 ? workspace : nullptr;
         if (int rc = launch_tilep(a, w.zp != nullptr, dim3(cols, rts, S), stream)) return rc;
+        form_hit(FORM_W4_TILEP);
         if (S == 1) return 0;
         hipLaunchKernelGGL(splitk_reduce_bias_kernel, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, w.bias, S, m,
                            w.n, rows_pad, n_pad, w.n);
         FH_CHECK_LAUNCH();
         return 0;
     }
-    static const int lds_mode = getenv("FERRUM_HIP_W4_LDSA") ? atoi(getenv("FERRUM_HIP_W4_LDSA")) : 1;
+    const int lds_mode = kn.w4_ldsa;
     const bool lds_shape = (w.G >= 64 && w.n64 >= 32) || w.n64 >= 256;
     if (mt >= 2 && w.perm == nullptr && (lds_mode == 2 || (lds_mode == 1 && lds_shape && mt == 2))) {
         int nw = 4;
-        if (const char* e = getenv("FERRUM_HIP_W4_LDSA_NW")) nw = atoi(e) == 8 && mt == 2 ? 8 : 4;
+        if (kn.w4_ldsa_nw) nw = kn.w4_ldsa_nw == 8 && mt == 2 ? 8 : 4;
         const int cols = cdiv(w.n64, nw);
         int S = 1;
         while ((long)cols * row_blocks * S < 128 && w.G / (S * 2) >= 8) S *= 2;
         while (w.n64 <= 128 && (long)cols * row_blocks * S < 256 && w.G / (S * 2) >= 16) S *= 2;
-        if (const char* e = getenv("FERRUM_HIP_W4_LDSA_S")) S = std::max(1, std::min(atoi(e), w.G));
+        if (kn.w4_ldsa_s) S = std::max(1, std::min(kn.w4_ldsa_s, w.G));
         const int rows_pad = row_blocks * 16 * mt, n_pad = w.n64 * 64;
         if (S > 1 && (workspace == nullptr || (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes)) S = 1;
         a.S = S;
@@ -1597,6 +1600,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
         int rc;
         if (mt == 2) rc = nw == 8 ? launch_ldsa<2, 8>(a, zp, grid, stream) : launch_ldsa<2, 4>(a, zp, grid, stream);
         else rc = launch_ldsa<4, 4>(a, zp, grid, stream);      // MT = 4 with 8 waves would exceed 256 VGPRs per lane
+        form_hit(FORM_W4_LDSA);
         if (rc || S == 1) return rc;
         hipLaunchKernelGGL(splitk_reduce_bias_kernel, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, w.bias, S, m,
                            w.n, rows_pad, n_pad, w.n);
@@ -1616,10 +1620,11 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     int W = 4;
     while (wgs * W < 2048 && W * 2 <= std::min(w_cap, w.G) && W * 2 * mt * nt * 4 <= 512) W <<= 1;
     while (W > w.G && W > 1) W >>= 1;
-    if (const char* e = getenv("FERRUM_HIP_W4_NT")) nt = atoi(e);        // tuning overrides (development)
-    if (const char* e = getenv("FERRUM_HIP_W4_W")) W = atoi(e);
+    if (kn.w4_nt) nt = kn.w4_nt;        // tuning overrides (development)
+    if (kn.w4_w) W = kn.w4_w;
     dim3 grid(cdiv(n16, nt), row_blocks, 1);
     const bool zp = w.zp != nullptr;
+    form_hit(FORM_W4_WGSPLIT);
 #define FH_WG(MTV, NTV) return launch_wgsplit<MTV, NTV>(a, zp, grid, W, stream)
     if (mt == 1) { if (nt == 4) FH_WG(1, 4); if (nt == 2) FH_WG(1, 2); FH_WG(1, 1); }
     if (mt == 2) { if (nt == 4) FH_WG(2, 4); if (nt == 2) FH_WG(2, 2); FH_WG(2, 1); }
@@ -1647,6 +1652,7 @@ int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, co
     a.pub_sorted_token_ids = pub_sorted; a.pub_block_ids = pub_block_ids; a.pub_total_post_pad = pub_total;
     a.top_k = top_k;
     dim3 grid(w.n64, max_blocks, 1);
+    form_hit(FORM_MOE_INLINE_ALIGN);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
 }
@@ -1669,6 +1675,7 @@ int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, co
     a.top_k = top_k;
     const dim3 grid(w.n64, num_experts, 1);
     const bool zp = w.zp != nullptr;
+    form_hit(FORM_MOE_EXPERT_MAJOR);
     if (fused_silu) {
         if (zp) hipLaunchKernelGGL((w4_gemm_moe_em_kernel<true, 2>), grid, dim3(64), 0, stream, a);
         else hipLaunchKernelGGL((w4_gemm_moe_em_kernel<false, 2>), grid, dim3(64), 0, stream, a);
@@ -1702,6 +1709,7 @@ int w4_gemm_moe_merge_route(const W4Device& w, const __half* x, __half* out, con
     a.pub_sorted_token_ids = pub_sorted; a.pub_block_ids = pub_block_ids; a.pub_total_post_pad = pub_total;
     a.top_k = top_k;
     dim3 grid(w.n64, max_blocks, 1);
+    form_hit(FORM_MOE_MERGE_ROUTE);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
 }
@@ -1726,6 +1734,7 @@ int w4_gemm_dense_slabs(const W4Device& w, const __half* x, float* slabs, size_t
     *rows_pad_out = a.rows_pad;
     *n_pad_out = a.n_pad;
     // S == 1 still writes a slab (the MODE-0 kernel writes fp16 `out` only when S == 1 → force the slab path)
+    form_hit(FORM_W4_SLABS);
     return launch_w4_slabs(a, mt, w.zp != nullptr, dim3(cdiv(w.n64, 4), row_blocks, S), stream);
 }
 
@@ -1750,6 +1759,7 @@ int w4_gemm_dense_slabs_tile(const W4Device& w, const __half* x, float* slabs, s
     *S_out = S;
     *rows_pad_out = a.rows_pad;
     *n_pad_out = a.n_pad;
+    form_hit(FORM_W4_SLABS_TILE);
     return launch_tilep(a, w.zp != nullptr, dim3(cols, rts, S), stream);
 }
 
@@ -1759,9 +1769,7 @@ int w4_gemm_dense_lds_splits(const W4Device& w, int m) {
     const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
     const int row_blocks = cdiv(m, 16 * mt), cols = cdiv(w.n64, 4);
     int S = 1;
-    int min_wgs = 128, min_groups = 8;
-    if (const char* e = getenv("FERRUM_HIP_LDS_MIN_WGS")) min_wgs = atoi(e);
-    if (const char* e = getenv("FERRUM_HIP_LDS_MIN_GROUPS")) min_groups = atoi(e);
+    const int min_wgs = knobs().lds_min_wgs, min_groups = knobs().lds_min_groups;
     while ((long)cols * row_blocks * S < min_wgs && w.G / (S * 2) >= min_groups) S *= 2;
     // deep K (≥ 16 groups per split left): go on to one workgroup per CU — Llama-70B down 28672→8192 ran on 128 of 256 CUs
     // (narrow N only: for wide N the extra fp32 slabs cost more than the idle CUs — Gemma-3 gate_up 5376→43008 got slower)
@@ -1789,6 +1797,7 @@ int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, si
     *S_inout = S;
     *rows_pad_out = a.rows_pad;
     *n_pad_out = a.n_pad;
+    form_hit(FORM_W4_SLABS_LDS);
     return launch_ldsa<2, 4>(a, w.zp != nullptr, dim3(cdiv(w.n64, 4), 1, S), stream);
 }
 
@@ -1806,6 +1815,7 @@ int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* 
     a.sorted_token_ids = sorted_token_ids; a.block_ids = block_ids; a.total_post_pad = total_post_pad;
     a.top_k = top_k;
     dim3 grid(w.n64, max_blocks, 1);
+    form_hit(FORM_MOE_BLOCK16);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
     return launch_w4<1>(a, 1, w.zp != nullptr, grid, stream);
 }
@@ -1828,6 +1838,7 @@ int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int3
     a.top_k = top_k;
     dim3 grid(cdiv(w.n64, 4), max_blocks, 1);
     const bool zp = w.zp != nullptr;
+    form_hit(block_rows == 64 ? FORM_MOE_TILE64 : FORM_MOE_TILE32);
     if (block_rows == 64) return fused_silu ? launch_tile<2, 4>(a, zp, grid, stream) : launch_tile<1, 4>(a, zp, grid, stream);
     return fused_silu ? launch_tile<2, 2>(a, zp, grid, stream) : launch_tile<1, 2>(a, zp, grid, stream);
 }

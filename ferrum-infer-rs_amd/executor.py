@@ -135,6 +135,76 @@ class Checkpoint:
         return d, arch.value.decode(), bool(tied.value)
 
 
+class Comm:
+    """`BackendCollective` (ferrum-kernels/src/backend/capabilities.rs:84-109) over `ferrum_hip_comm_*`: one rank of a
+    tensor-parallel group.  Transports: RCCL (`Comm.rccl`), a one-shot peer reduce between ranks of one process
+    (`Comm.local_group`) or between processes through hipIpc handles (`oneshot_export` / `oneshot_attach`)."""
+
+    def __init__(self, handle, owner=None):
+        self.lib = load_library()
+        self.h = handle
+        self._owner = owner
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = (C.c_uint8 * 128)()
+        _check(lib.ferrum_hip_comm_unique_id(buf), "comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, world, rank, unique_id):
+        lib = load_library()
+        h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(lib.ferrum_hip_comm_create_rccl(C.byref(h), world, rank, buf), "comm_create_rccl")
+        return cls(h)
+
+    @classmethod
+    def local_group(cls, world, max_message_bytes=1 << 20):
+        lib = load_library()
+        arr = (C.c_void_p * world)()
+        _check(lib.ferrum_hip_comm_create_local_group(arr, world, C.c_size_t(max_message_bytes), None), "comm_create_local_group")
+        return [cls(C.c_void_p(arr[r])) for r in range(world)]
+
+    def oneshot_export(self, max_message_bytes=1 << 20):
+        buf = (C.c_uint8 * 64)()
+        _check(self.lib.ferrum_hip_comm_oneshot_export(self.h, C.c_size_t(max_message_bytes), buf), "comm_oneshot_export")
+        return bytes(buf)
+
+    def oneshot_attach(self, handles):
+        blob = b"".join(handles)
+        arr = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(self.lib.ferrum_hip_comm_oneshot_attach(self.h, arr, len(handles)), "comm_oneshot_attach")
+
+    def oneshot_status(self):
+        e, t = C.c_uint(), C.c_uint()
+        _check(self.lib.ferrum_hip_comm_oneshot_status(self.h, C.byref(e), C.byref(t)), "comm_oneshot_status")
+        return {"epoch": e.value, "timeouts": t.value}
+
+    def world_size(self):
+        return self.lib.ferrum_hip_comm_world_size(self.h)
+
+    def rank(self):
+        return self.lib.ferrum_hip_comm_rank(self.h)
+
+    def all_reduce(self, buf, count, stream):
+        """BackendCollective::all_reduce, ReduceOp::Sum over fp16, in place on `stream` (a torch CUDA tensor or raw pointer)."""
+        ptr = C.c_void_p(buf.data_ptr()) if hasattr(buf, "data_ptr") else buf
+        _check(self.lib.ferrum_hip_all_reduce_f16(self.h, ptr, C.c_size_t(count), stream), "all_reduce")
+
+    def destroy(self):
+        if self.h:
+            self.lib.ferrum_hip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class HipModel:
     @classmethod
     def from_checkpoint(cls, model_dir, kv_num_blocks, max_seqs, max_tokens, max_seq_len=0):
@@ -303,6 +373,16 @@ class HipModel:
         _check(self.lib.ferrum_hip_model_time_kernel(self.h, names[which], n_seqs, max_kv_len, reps, C.byref(us),
                                                      C.byref(blocks)), "time_kernel")
         return us.value, blocks.value
+
+    def set_comm(self, comm):
+        """Attach a tensor-parallel communicator (`Comm`); None detaches.  The model does not own it."""
+        self._comm = comm                                       # keep it alive as long as the model uses it
+        _check(self.lib.ferrum_hip_model_set_comm(self.h, comm.h if comm is not None else None), "model_set_comm")
+
+    def tp_init(self, unique_id):
+        """RCCL rank owned by the model (ferrum_hip_model_tp_init); unique_id: 128 bytes from Comm.unique_id() on rank 0."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _check(self.lib.ferrum_hip_model_tp_init(self.h, buf), "model_tp_init")
 
     def stream(self):
         s = C.c_void_p()

@@ -509,19 +509,50 @@ int ferrum_hip_model_stream(FerrumHipModel* model, void** stream);
  * which: 0 MoE gate_up(+silu·mul), 1 MoE down, 2 paged decode attention, 3 qkv GEMM, 4 o GEMM, 5 lm_head. */
 int ferrum_hip_model_time_kernel(FerrumHipModel* model, int which, int n_seqs, int max_kv_len, int reps,
                                  float* avg_us, int* moe_blocks);
-/* Tensor parallel: 128-byte RCCL unique id created on rank 0 and broadcast by the host. */
-int ferrum_hip_tp_unique_id(uint8_t id[128]);
-/* In-process stand-in for the communicator (tests, one GPU): the ranks of a tensor-parallel group are runner models driven
- * by threads of one process; each all-reduce is two host barriers around a device-side rank-ordered sum.  Validates the
- * sharded forward end to end without a second GPU. */
+/* ── Tensor-parallel communicator: BackendCollective (ferrum-kernels/src/backend/capabilities.rs:84-109; the CUDA lane's
+ * NcclRank, nccl_comm.rs:21-49).  One communicator per rank; `ferrum_hip_all_reduce_f16` is the in-place fp16 sum the
+ * decode runner issues after o_proj and down_proj (cuda/tp_decode.rs:350-372).  Transports: RCCL over xGMI (any size), and a
+ * hand-written one-shot peer reduce for decode-sized messages (rank-ordered fp32 sum, identical bits on every rank) over
+ * buffers of the same process (`create_local_group`) or hipIpc-imported ones (`oneshot_export` / `oneshot_attach`).
+ * Both are stream-ordered device work, so a decode step with its all-reduces is captured in one hipGraph. ── */
+typedef struct FerrumHipComm FerrumHipComm;
+/* 128-byte RCCL unique id created on rank 0 and broadcast by the host. */
+int ferrum_hip_comm_unique_id(uint8_t id[128]);
+int ferrum_hip_tp_unique_id(uint8_t id[128]);                       /* same, older name */
+int ferrum_hip_comm_create_rccl(FerrumHipComm** comm, int world, int rank, const uint8_t id[128]);
+/* `world` ranks inside one process (threads of a test on one GPU; devices[] = NULL puts every buffer on the current device). */
+int ferrum_hip_comm_create_local_group(FerrumHipComm** comms, int world, size_t max_message_bytes, const int* devices);
+int ferrum_hip_comm_oneshot_export(FerrumHipComm* comm, size_t max_message_bytes, uint8_t handle[64]);
+int ferrum_hip_comm_oneshot_attach(FerrumHipComm* comm, const uint8_t* handles /* world x 64 bytes, rank order */, int world);
+int ferrum_hip_comm_oneshot_status(FerrumHipComm* comm, unsigned* epoch, unsigned* timeouts);
+int ferrum_hip_comm_destroy(FerrumHipComm* comm);
+int ferrum_hip_comm_world_size(const FerrumHipComm* comm);          /* BackendCollective::world_size (NULL comm: 1) */
+int ferrum_hip_comm_rank(const FerrumHipComm* comm);                /* BackendCollective::rank */
+int ferrum_hip_all_reduce_f16(FerrumHipComm* comm, void* buf, size_t count, void* stream);   /* ReduceOp::Sum, in place */
+int ferrum_hip_all_gather_f16(FerrumHipComm* comm, const void* local, void* global, size_t local_count, void* stream);
+int ferrum_hip_broadcast_f16(FerrumHipComm* comm, void* buf, size_t count, int src_rank, void* stream);
+/* Runner side: an RCCL rank owned by the model, or a communicator of the caller's. */
+int ferrum_hip_model_tp_init(FerrumHipModel* model, const uint8_t id[128]);
+int ferrum_hip_model_set_comm(FerrumHipModel* model, FerrumHipComm* comm);
+/* In-process stand-in for the communicator with HOST barriers (tests, one GPU, eager launches only): the ranks of a
+ * tensor-parallel group are runner models driven by threads of one process; each all-reduce is two host barriers around a
+ * device-side rank-ordered sum. */
 typedef struct FerrumHipTpLoopback FerrumHipTpLoopback;
 int ferrum_hip_tp_loopback_create(FerrumHipTpLoopback** lb, int world);
 int ferrum_hip_tp_loopback_destroy(FerrumHipTpLoopback* lb);
 int ferrum_hip_model_tp_attach_loopback(FerrumHipModel* model, FerrumHipTpLoopback* lb);
-/* 1-rank RCCL round trip on the current device (fp16 sum all-reduce, in place): checks the dlopen'ed entry points, enum values
- * and by-value ncclUniqueId passing of the tensor-parallel path without needing a second GPU. */
+/* 1-rank RCCL round trip on the current device (fp16 sum all-reduce, in place), eagerly and from a captured + replayed
+ * hipGraph: checks the dlopen'ed entry points, enum values, by-value ncclUniqueId passing and stream capture of the
+ * tensor-parallel path without needing a second GPU. */
 int ferrum_hip_tp_selftest(int count);
-int ferrum_hip_model_tp_init(FerrumHipModel* model, const uint8_t id[128]);
+
+/* ── Debug / test support: which kernel forms the launchers chose, and re-reading the FERRUM_HIP_* development knobs
+ * (they are read once at library load; no launch path calls getenv). ── */
+int ferrum_hip_debug_form_count(void);
+const char* ferrum_hip_debug_form_name(int form);
+int ferrum_hip_debug_form_hits(uint64_t* hits, int capacity);
+int ferrum_hip_debug_form_reset(void);
+int ferrum_hip_debug_reload_knobs(void);
 
 #if defined(__GNUC__)
 #pragma GCC visibility pop

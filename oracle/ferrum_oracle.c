@@ -22,8 +22,19 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define FO_API __attribute__((visibility("default")))
+
+/* Worker threads for the row/head/token loops below.  Every output element is still computed by ONE thread with the
+ * reference's own loop order, so results are bit-identical for any thread count; 1 (the default) is the reference's
+ * single-threaded CPU path (cpu.rs:483-491) and is what bench.py's cpu_baseline times.  Parity tests at the BASELINE
+ * configs' real dimensions raise it so that a 256-token prompt through a full-size layer finishes in seconds. */
+static int fo_threads = 1;
+FO_API void fo_set_threads(int n) { fo_threads = n < 1 ? 1 : n; }
+FO_API int fo_get_threads(void) { return fo_threads; }
 
 /* ─────────────────────────── deterministic inputs ─────────────────────────
  * ferrum-quantization/tests/gptq_parity_test.rs:28-38 (rnd_u32 / rnd_f32). */
@@ -74,6 +85,7 @@ static float fo_dot(const float *a, const float *b, long n) {
 /* cpu.rs:438-493 CpuBackend::gemm, non-macOS branch: out[i,j] =
  * (f32) Σ_p (f64)a[i,p]·(f64)b[j,p];  b is [n,k] row-major. */
 FO_API void fo_gemm(const float *a, const float *b, float *out, int m, int n, int k) {
+#pragma omp parallel for collapse(2) schedule(static) num_threads(fo_threads) if (fo_threads > 1 && (long)m * n * k > (1L << 22))
     for (int i = 0; i < m; i++)
         for (int j = 0; j < n; j++) {
             double sum = 0.0;
@@ -235,8 +247,10 @@ FO_API void fo_cpu_attention(const float *q, const float *k, const float *v, flo
                              int sliding_window) {
     int n_rep = nh / nkv;
     long kv_stride = kv_seq_stride > 0 ? kv_seq_stride : kv_len;
-    float *acc = (float *)malloc(sizeof(float) * d);
+    if (d > 512) return;   /* the per-thread accumulator below; the reference's models use 64/128/256 */
+#pragma omp parallel for schedule(dynamic) num_threads(fo_threads) if (fo_threads > 1 && (long)nh * q_len * kv_len > (1L << 16))
     for (int h = 0; h < nh; h++) {
+        float acc[512];   /* d ≤ 512 (head_dim 64/128/256) */
         int kv_h = h / n_rep;
         long q_off = (long)h * q_len * d;
         long k_off = (long)kv_h * kv_stride * d;
@@ -272,7 +286,6 @@ FO_API void fo_cpu_attention(const float *q, const float *k, const float *v, flo
             }
         }
     }
-    free(acc);
 }
 
 /* ferrum-kv/src/attention.rs:30-114 paged_attention over a paged pool.
@@ -480,10 +493,14 @@ FO_API int fo_moe_align_block_size(const int32_t *expert_ids_per_pair, int batch
 FO_API void fo_moe_forward_cpu(const float *x, int batch, int hidden, int inter, int top_k,
                                const uint32_t *expert_ids, const float *expert_weights,
                                const float *gate_up_w, const float *down_w, float *out) {
+    memset(out, 0, sizeof(float) * (long)batch * hidden);
+    /* tokens are independent (each b owns out[b]); the inner 1-row gemms stay serial inside a token's thread */
+#pragma omp parallel num_threads(fo_threads) if (fo_threads > 1 && batch > 1)
+    {
     float *gu = (float *)malloc(sizeof(float) * 2 * inter);
     float *act = (float *)malloc(sizeof(float) * inter);
     float *dn = (float *)malloc(sizeof(float) * hidden);
-    memset(out, 0, sizeof(float) * (long)batch * hidden);
+#pragma omp for schedule(dynamic)
     for (int b = 0; b < batch; b++) {
         const float *xb = x + (long)b * hidden;
         for (int k = 0; k < top_k; k++) {
@@ -500,6 +517,7 @@ FO_API void fo_moe_forward_cpu(const float *x, int batch, int hidden, int inter,
     free(gu);
     free(act);
     free(dn);
+    }
 }
 
 /* ──────────────────────────────── sampling ─────────────────────────────── */

@@ -109,6 +109,9 @@ typedef struct {
     /* test aid: smallest k-th / (k+1)-th router-logit gap over the layers and tokens of the last call — lets a
      * parity test tell a routing near-tie (a legitimately different expert pick) from an arithmetic error */
     float last_route_gap;
+    /* … and the same gap relative to that token's router-logit spread (max − min): the scale fp16 storage noise of the router
+     * input has to be compared with */
+    float last_route_gap_rel;
 } fo_model;
 
 static float *fo_dup(const float *src, long n) {
@@ -252,6 +255,7 @@ FO_API void fo_model_enable_taps(fo_model *m, int max_tokens) {
 }
 FO_API const float *fo_model_taps(fo_model *m) { return m->tap_hidden; }
 FO_API float fo_model_last_route_gap(const fo_model *m) { return m->last_route_gap; }
+FO_API float fo_model_last_route_gap_rel(const fo_model *m) { return m->last_route_gap_rel; }
 
 /* gap between the k-th and (k+1)-th largest of n logits (n > k) */
 static float fo_topk_gap(const float *l, int n, int k) {
@@ -278,6 +282,7 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
     if (cache->len != pos_offset) return -2;
     if (pos_offset + n_tokens > g->max_seq_len) return -3;
     m->last_route_gap = INFINITY;
+    m->last_route_gap_rel = INFINITY;
     int T = n_tokens, H = g->hidden, nh = g->num_heads, nkv = g->num_kv_heads, hd = g->head_dim;
     int q_dim = nh * hd, kv_dim = nkv * hd, qkv_dim = q_dim + 2 * kv_dim;
     int I = g->intermediate;
@@ -362,6 +367,11 @@ FO_API int fo_model_forward(fo_model *m, int cache_id, const uint32_t *tokens, i
             for (int t = 0; t < T; t++) {
                 float gap = fo_topk_gap(router_logits + (long)t * g->num_experts, g->num_experts, g->top_k);
                 if (gap < m->last_route_gap) m->last_route_gap = gap;
+                const float *rl = router_logits + (long)t * g->num_experts;
+                float lo = rl[0], hi = rl[0];
+                for (int e = 1; e < g->num_experts; e++) { if (rl[e] < lo) lo = rl[e]; if (rl[e] > hi) hi = rl[e]; }
+                float rel = hi > lo ? gap / (hi - lo) : INFINITY;
+                if (rel < m->last_route_gap_rel) m->last_route_gap_rel = rel;
             }
             fo_moe_forward_cpu(norm_out, T, H, g->expert_inter, g->top_k, eids, ew,
                                L->exp_gate_up_w, L->exp_down_w, mlp_out);

@@ -123,8 +123,20 @@ def _declare(l):
     l.fo_block_hash_chain.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     l.fo_model_last_route_gap.restype = C.c_float
     l.fo_model_last_route_gap.argtypes = [C.c_void_p]
+    l.fo_model_last_route_gap_rel.restype = C.c_float
+    l.fo_model_last_route_gap_rel.argtypes = [C.c_void_p]
     l.fo_model_forward.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int,
                                    C.POINTER(C.c_float), C.POINTER(C.c_float)]
+
+
+def set_threads(n):
+    """Worker threads of the oracle's row/head/token loops (results are bit-identical for any count; default 1 = the
+    reference's single-threaded CPU path)."""
+    lib().fo_set_threads(int(n))
+
+
+def get_threads():
+    return int(lib().fo_get_threads())
 
 
 def f32(a):
@@ -541,6 +553,10 @@ class OracleModel:
     def last_route_gap(self):
         """Smallest k-th/(k+1)-th router-logit gap over the last forward's layers and tokens (inf for dense models)."""
         return float(lib().fo_model_last_route_gap(self._h))
+
+    def last_route_gap_rel(self):
+        """The same gap divided by that token's router-logit spread (max − min)."""
+        return float(lib().fo_model_last_route_gap_rel(self._h))
 
     def enable_taps(self, max_tokens):
         self._tap_tokens = max_tokens

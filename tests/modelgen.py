@@ -271,44 +271,102 @@ def margin(logits):
     return float(s[-1] - s[-2])
 
 
-def run_parity_case(pkg, moe, layers=2, prompt_len=19, decode_steps=4, seed=0, **model_kw):
+# ── greedy-id accounting ─────────────────────────────────────────────────────
+# north_star: "bit-exact greedy token ids, logits within a stated fp tolerance".  The device stores activations in fp16,
+# the oracle in f32, so a sampled row whose two best oracle logits lie closer than the logit error CAN pick the other
+# id.  Note that a differing id always satisfies margin ≤ 2·max|Δlogit| (the winner moved down and the runner-up up by at
+# most the error each), so "excuse an id when the margin is within k× the error" excuses EVERY mismatch and asserts
+# nothing.  What is asserted instead: ids are compared exactly and every mismatch is COUNTED; tiny models allow none, the
+# real-dimension cases a single-digit number stated in the test, each with its margin and error reported; the device id
+# must always be the first maximum of the device's own logits; logits stay within the stated relative tolerance.
+ROUTE_TIE_REL = 4.0 * 2.0 ** -11     # fp16 storage of the router input: 2^-11 relative rounding per element, ×4 headroom
+
+
+class Parity:
+    """Accumulates one model-level parity case: exact-id comparison with every mismatch recorded, worst cosine / relative
+    logit error, and the rows on which a router near-tie (k-th vs (k+1)-th oracle router logit closer than ROUTE_TIE_REL of
+    that token's logit spread) actually changed the result."""
+
+    def __init__(self, case, cos_min=0.999, rel_max=2e-2):
+        self.case, self.cos_min, self.rel_max = case, cos_min, rel_max
+        self.rows = 0
+        self.mismatches = []          # (tag, oracle_id, device_id, oracle_margin, max_abs_logit_err)
+        self.route_ties = []          # (tag, relative router gap, cosine)
+        self.worst_cos, self.worst_rel = 1.0, 0.0
+
+    def check(self, tag, o_logits, g_logits, g_tok, route_gap_rel=float("inf")):
+        self.rows += 1
+        oi = int(O.argmax_rows(o_logits[None])[0])
+        gi_own = int(O.argmax_rows(g_logits[None])[0])
+        assert int(g_tok) == gi_own, f"{self.case} {tag}: device id {int(g_tok)} is not the first maximum of its own logits ({gi_own})"
+        c = cosine(o_logits, g_logits)
+        err = float(np.max(np.abs(o_logits - g_logits)))
+        rel = err / (float(np.max(np.abs(o_logits))) + 1e-30)
+        if route_gap_rel < ROUTE_TIE_REL and (c < self.cos_min or rel > self.rel_max):
+            # a different expert was picked at a router near-tie: the row is counted, bounded by the caller, and only has
+            # to stay close in direction
+            self.route_ties.append((tag, float(route_gap_rel), c))
+            assert c > 0.99, f"{self.case} {tag}: route near-tie row drifted, cosine {c}"
+            return oi
+        self.worst_cos, self.worst_rel = min(self.worst_cos, c), max(self.worst_rel, rel)
+        if int(g_tok) != oi:
+            self.mismatches.append((tag, oi, int(g_tok), margin(o_logits), err))
+        return oi
+
+    def report(self):
+        return {"case": self.case, "rows": self.rows, "id_mismatches": len(self.mismatches), "route_ties": len(self.route_ties),
+                "worst_cosine": round(self.worst_cos, 6), "worst_rel_logit_err": round(self.worst_rel, 6),
+                "mismatch_detail": [(t, o, g, round(m, 6), round(e, 6)) for t, o, g, m, e in self.mismatches],
+                "route_tie_detail": [(t, round(g, 6), round(c, 5)) for t, g, c in self.route_ties]}
+
+    def finish(self, max_mismatches=0, max_route_ties=0):
+        """Record the counts (gpurun_out/parity_counts.jsonl) and assert the bars."""
+        import json
+        import os
+        rep = self.report()
+        log = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_counts.jsonl")
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        with open(log, "a") as f:
+            f.write(json.dumps(rep) + "\n")
+        assert self.worst_cos > self.cos_min, rep
+        assert self.worst_rel < self.rel_max, rep
+        assert len(self.mismatches) <= max_mismatches, rep
+        assert len(self.route_ties) <= max_route_ties, rep
+        return rep
+
+
+def run_parity_case(pkg, moe, layers=2, prompt_len=19, decode_steps=4, seed=0, case=None, rel_tol=2e-2, **model_kw):
     """Single-sequence prefill + teacher-forced greedy decode, HIP runner vs oracle.
-    Acceptance follows the reference's model-level criterion (qwen3_cuda_parity_test.rs:194-240):
-    same argmax AND cosine > 0.999 at every step; ids are only required to match where the oracle's
-    top-1/top-2 margin exceeds the fp16-storage noise (documented in DESIGN.md)."""
+    Acceptance follows the reference's model-level criterion (qwen3_cuda_parity_test.rs:194-240): same argmax AND
+    cosine > 0.999 at every step.  Ids are compared exactly; mismatches are counted in res["parity"] (see Parity)."""
     tm = TinyModel(moe, layers=layers, seed=seed, **model_kw)
     om, hm = tm.oracle_model(), tm.hip_model(pkg, max_tokens=max(256, prompt_len))
     rng = np.random.default_rng(seed + 1)
     vocab = tm.cfg["vocab"]
     prompt = rng.integers(0, vocab, size=prompt_len).astype(np.uint32)
-    res = {"ids_equal": True, "min_cosine": 1.0, "max_rel_logit_err": 0.0, "steps": [], "near_ties": 0}
+    par = Parity(case or f"tiny-{'moe' if moe else 'dense'}-L{layers}-p{prompt_len}-s{seed}", cos_min=0.999, rel_max=rel_tol)
+    res = {"steps": [], "parity": par}
 
-    def check(o_logits, g_logits):
+    def check(tag, o_logits, g_logits, g_tok):
+        oi = par.check(tag, o_logits, g_logits, g_tok, om.last_route_gap_rel() if moe else float("inf"))
         c = cosine(o_logits, g_logits)
         rel = float(np.max(np.abs(o_logits - g_logits)) / (np.max(np.abs(o_logits)) + 1e-30))
-        oi, gi = int(O.argmax_rows(o_logits[None])[0]), int(O.argmax_rows(g_logits[None])[0])
-        tol = 4.0 * float(np.max(np.abs(o_logits - g_logits)))
-        near = margin(o_logits) <= tol
-        res["min_cosine"] = min(res["min_cosine"], c)
-        res["max_rel_logit_err"] = max(res["max_rel_logit_err"], rel)
-        res["steps"].append((oi, gi, c, rel))
-        if oi != gi:
-            if near:
-                res["near_ties"] += 1
-            else:
-                res["ids_equal"] = False
+        res["steps"].append((oi, int(g_tok), c, rel))
         return oi
 
     o_last = om.forward(0, prompt, 0)
     g_tok, g_logits = hm.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
-    tok = check(o_last, g_logits[0])
-    assert int(g_tok[0]) == int(O.argmax_rows(g_logits)[0]), "device argmax disagrees with first-max of its own logits"
+    tok = check("prefill", o_last, g_logits[0], g_tok[0])
     pos = prompt_len
-    for _ in range(decode_steps):
+    for st in range(decode_steps):
         o_last = om.forward(0, np.array([tok], np.uint32), pos)
         g_tok, g_logits = hm.unified_forward([(1, np.array([tok], np.uint32), pos, True)], greedy=True, want_logits=True)
-        tok = check(o_last, g_logits[0])
+        tok = check(f"step{st}", o_last, g_logits[0], g_tok[0])
         pos += 1
+    res["min_cosine"] = min(c for _, _, c, _ in res["steps"])
+    res["max_rel_logit_err"] = max(r for _, _, _, r in res["steps"])
+    res["id_mismatches"] = len(par.mismatches)
+    res["ids_equal"] = not par.mismatches and not par.route_ties
     # KV parity (layer 0 and last): values within fp16 storage tolerance
     res["kv_nmse"] = 0.0
     for li in (0, layers - 1):

@@ -2,9 +2,10 @@
 device greedy sampling, hipGraph decode loop) vs the CPU oracle model on identical synthetic weights.
 
 Acceptance is the reference's own model-level criterion (ferrum-models/tests/qwen3_cuda_parity_test.rs:194-240):
-same argmax AND cosine > 0.999 on prefill and on every decode step; greedy ids must be bit-exact
-wherever the oracle's top-1/top-2 logit margin exceeds 4× the observed fp16-storage logit error
-(tests/modelgen.py), KV placement must follow the reference allocator exactly."""
+same argmax AND cosine > 0.999 on prefill and on every decode step.  Greedy ids are compared EXACTLY and every
+mismatch is counted (tests/modelgen.py `Parity`): the tiny models allow none; the real-dimension cases state a
+single-digit bound and report each excused row's margin and logit error; all counts are appended to
+gpurun_out/parity_counts.jsonl.  KV placement must follow the reference allocator exactly."""
 import numpy as np
 import pytest
 
@@ -21,33 +22,34 @@ def pkg():
     return p
 
 
-def _assert_parity(res, rel_tol=2e-2):
-    assert res["ids_equal"], res["steps"]
-    assert res["min_cosine"] > 0.999, res["steps"]
-    assert res["max_rel_logit_err"] < rel_tol, res["steps"]    # logits tolerance: 2 % of max |logit|
+def _assert_parity(res):
+    """Exact greedy ids on every sampled row (no excused near-ties, no route ties), cosine > 0.999, logits within the
+    case's relative tolerance (2 % of max |logit| unless the case passed rel_tol), KV within the fp16 round-trip bucket."""
+    res["parity"].finish(max_mismatches=0, max_route_ties=0)
     assert res["kv_nmse"] < 3e-3                                # fp16-storage round-trip bucket (op_diff 3e-3)
 
 
 @pytest.mark.parametrize("moe", [False, True])
 def test_prefill_and_decode_match_oracle(pkg, moe):
     from tests import modelgen
-    res = modelgen.run_parity_case(pkg, moe=moe, layers=3, prompt_len=37, decode_steps=6, seed=3)
+    res = modelgen.run_parity_case(pkg, moe=moe, layers=3, prompt_len=37, decode_steps=6, seed=3, rel_tol=5e-2)
     # the dense seed-3 instance is ill-conditioned: one-ulp differences in the attention output (KV-split vs row-split
     # waves, both < 1e-5 NMSE from the oracle at op level) move its prefill logit error between 0.6 % and 2.8 %, where
     # seeds 1, 2, 4…8 sit at 0.04 % either way — it keeps the reference's criterion (argmax + cosine) and the 5 % bound
-    _assert_parity(res, rel_tol=5e-2)
+    _assert_parity(res)
     blocks, kv_len = res["block_table"]
     assert kv_len == 37 + 6
     assert blocks == [0, 1, 2]                                   # BlockAllocator hands out 0,1,2,… (paged_pool.rs:466-472)
 
 
 @pytest.mark.parametrize("moe", [False, True])
-def test_long_prompt_prefill_row_tiles(pkg, moe, monkeypatch):
+def test_long_prompt_prefill_row_tiles(pkg, moe, knobs, forms):
     """A 300-token prompt: five 64-row tiles through the pipelined dense GEMM (ragged last tile), 64-pair MoE blocks through
     the grouped tile kernel (75 pairs per expert), 38 attention row tiles through the row-split prefill form."""
     from tests import modelgen
-    monkeypatch.setenv("FERRUM_HIP_ATTN_RS_MIN_WGS", "1")
+    knobs.set(ATTN_RS_MIN_WGS=1)
     res = modelgen.run_parity_case(pkg, moe=moe, layers=2, prompt_len=300, decode_steps=2, seed=17, max_seq_len=512)
+    forms.require("w4_tilep", "attn_row_split", *(("moe_tile64",) if moe else ()))
     _assert_parity(res)
 
 
@@ -142,8 +144,7 @@ def test_mixed_batch_chunked_prefill_matches_per_sequence_oracle(pkg):
     refs = [om.forward(0, np.array([ta], np.uint32), 23), om.forward(1, pb[16:], 16), om.forward(2, pc, 0)]
     for j, r in enumerate(refs):
         assert modelgen.cosine(r, lg[j]) > 0.999
-        if modelgen.margin(r) > 4 * np.max(np.abs(r - lg[j])):
-            assert int(toks[j]) == int(np.argmax(r))
+        assert int(toks[j]) == int(np.argmax(r)), (j, modelgen.margin(r), float(np.max(np.abs(r - lg[j]))))   # exact ids
     # block tables follow allocation order across sequences: A got 0,1; B got 2 then grew to 3,4; C got 5
     assert hm.block_table(10)[0] == [0, 1]
     assert hm.block_table(11)[0] == [2, 3, 4]
@@ -153,12 +154,12 @@ def test_mixed_batch_chunked_prefill_matches_per_sequence_oracle(pkg):
             assert modelgen.nmse(om.read_kv(oc, 1, is_v), hm.read_kv(sid, 1, is_v)) < 3e-3
 
 
-def test_mixed_batch_decode_rows_then_prompts_two_attention_launches(pkg, monkeypatch):
+def test_mixed_batch_decode_rows_then_prompts_two_attention_launches(pkg, knobs, forms):
     """A continuous-batching iteration in the order the C++ driver builds it — decode rows first, fresh prompts after them:
     attention runs as two launches (KV-split for the decode rows, LDS-shared K/V form for the prompts; thresholds lowered so
     that 30-token prompts qualify).  Every sampled row against the per-sequence oracle."""
     from tests import modelgen
-    monkeypatch.setenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", "2")       # runner: two launches from 16 × 2 rows per prompt
+    knobs.set(ATTN_FLASH_MIN_ROWS=2)                                # runner: two launches from 16 × 2 rows per prompt
     tm = modelgen.TinyModel(False, layers=2, seed=23)
     om, hm = tm.oracle_model(), tm.hip_model(pkg, kv_num_blocks=64, max_seqs=8, max_tokens=256)
     rng = np.random.default_rng(24)
@@ -167,14 +168,15 @@ def test_mixed_batch_decode_rows_then_prompts_two_attention_launches(pkg, monkey
     first, _ = hm.unified_forward([(1, pa, 0, True), (2, pb, 0, True)], greedy=True)
     oa, ob = om.forward(0, pa, 0), om.forward(1, pb, 0)
     ta, tb = int(np.argmax(oa)), int(np.argmax(ob))
+    forms.reset()
     toks, lg = hm.unified_forward([(1, [ta], 19, True), (2, [tb], 33, True), (3, pc, 0, True), (4, pd, 0, True)], greedy=True,
                                   want_logits=True)
+    forms.require("attn_flash", "attn_kv_narrow")                   # prompts: LDS-shared K/V form; decode rows: KV-split form
     refs = [om.forward(0, np.array([ta], np.uint32), 19), om.forward(1, np.array([tb], np.uint32), 33), om.forward(2, pc, 0),
             om.forward(3, pd, 0)]
     for j, r in enumerate(refs):
         assert modelgen.cosine(r, lg[j]) > 0.999, j
-        if modelgen.margin(r) > 4 * np.max(np.abs(r - lg[j])):
-            assert int(toks[j]) == int(np.argmax(r))
+        assert int(toks[j]) == int(np.argmax(r)), (j, modelgen.margin(r), float(np.max(np.abs(r - lg[j]))))   # exact ids
 
 
 @pytest.mark.parametrize("moe", [False, True])
@@ -206,7 +208,7 @@ def test_decode_batch_larger_than_64_sequences(pkg, moe):
     assert checked >= 2
 
 
-def test_decode_steps_graph_equals_eager_and_oracle(pkg, monkeypatch):
+def test_decode_steps_graph_equals_eager_and_oracle(pkg, knobs, forms):
     """The hipGraph-replayed decode loop must produce the same ids as step-by-step unified_forward."""
     from tests import modelgen
     tm = modelgen.TinyModel(True, layers=2, seed=21)
@@ -217,10 +219,8 @@ def test_decode_steps_graph_equals_eager_and_oracle(pkg, monkeypatch):
     outs = []
     for mode in ("graph", "eager", "unified"):
         hm = tm.hip_model(pkg, kv_num_blocks=64, max_seqs=8, max_tokens=128)
-        if mode == "eager":
-            monkeypatch.setenv("FERRUM_HIP_NO_GRAPH", "1")
-        else:
-            monkeypatch.delenv("FERRUM_HIP_NO_GRAPH", raising=False)
+        knobs.set(NO_GRAPH=1 if mode == "eager" else None)
+        forms.reset()
         first, _ = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
         if mode == "unified":
             cur = first.copy()
@@ -232,6 +232,10 @@ def test_decode_steps_graph_equals_eager_and_oracle(pkg, monkeypatch):
         else:
             outs.append(hm.decode_steps([0, 1, 2], first, steps))
             assert [hm.block_table(i)[1] for i in range(3)] == [len(p) + steps for p in prompts]
+            if mode == "graph":
+                forms.require("graph_capture", "graph_replay")
+            else:
+                forms.require(absent=("graph_capture", "graph_replay"))
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     # and against the oracle, teacher-forced on the GPU's tokens (margin-aware)
     om = tm.oracle_model()
@@ -249,7 +253,7 @@ def test_decode_steps_graph_equals_eager_and_oracle(pkg, monkeypatch):
         assert agree or True
 
 
-def test_decode_steps_graph_survives_history_regrowth(pkg, monkeypatch):
+def test_decode_steps_graph_survives_history_regrowth(pkg, knobs, forms):
     """A short decode_steps call followed by a longer one on the same batch replays the graph captured by the first (same
     batch size, same kv bucket) while the sampled-id history buffer is regrown in between (regression: the replayed step
     kept writing through the old pointer — wrong ids at best, a memory fault at c=64)."""
@@ -263,10 +267,8 @@ def test_decode_steps_graph_survives_history_regrowth(pkg, monkeypatch):
     outs = []
     for mode in ("graph", "eager"):
         hm = tm.hip_model(pkg, kv_num_blocks=n * 10, max_seqs=n, max_tokens=512)
-        if mode == "eager":
-            monkeypatch.setenv("FERRUM_HIP_NO_GRAPH", "1")
-        else:
-            monkeypatch.delenv("FERRUM_HIP_NO_GRAPH", raising=False)
+        knobs.set(NO_GRAPH=1 if mode == "eager" else None)
+        forms.reset()
         first, _ = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
         a = hm.decode_steps(ids, first, 3)                       # captures the graph; the history buffer holds 4096 ids
         b = hm.decode_steps(ids, a[-1], 110)                     # 4400 ids: regrown; kv ≤ 125 stays in the first bucket
@@ -276,7 +278,7 @@ def test_decode_steps_graph_survives_history_regrowth(pkg, monkeypatch):
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_decode_graph_reused_across_sequence_sets(pkg, monkeypatch):
+def test_decode_graph_reused_across_sequence_sets(pkg, knobs, forms):
     """The captured decode step is replayed for a NEW set of sequences of the same batch size (released ids, fresh block
     tables, different lengths inside the same kv bucket): everything per-sequence must come from the device index buffers."""
     from tests import modelgen
@@ -287,10 +289,8 @@ def test_decode_graph_reused_across_sequence_sets(pkg, monkeypatch):
     outs = []
     for mode in ("graph", "eager"):
         hm = tm.hip_model(pkg, kv_num_blocks=48, max_seqs=8, max_tokens=128)
-        if mode == "eager":
-            monkeypatch.setenv("FERRUM_HIP_NO_GRAPH", "1")
-        else:
-            monkeypatch.delenv("FERRUM_HIP_NO_GRAPH", raising=False)
+        knobs.set(NO_GRAPH=1 if mode == "eager" else None)
+        forms.reset()
         got = []
         for si, prompts in enumerate(sets):
             ids = [100 * si + i for i in range(3)]
@@ -303,6 +303,8 @@ def test_decode_graph_reused_across_sequence_sets(pkg, monkeypatch):
         outs.append(np.stack(got))
     assert np.array_equal(outs[0], outs[1])
 
+
+ORACLE_THREADS = 16      # worker threads of the oracle's row loops in the real-dimension cases (bit-identical to 1 thread)
 
 FULL_DIMS = {
     # one layer at the BASELINE configs' real dimensions (SURVEY.md §8 shape glossary); vocabulary cut to 2048 rows so
@@ -329,56 +331,121 @@ FULL_DIMS = {
 @pytest.mark.parametrize("name", sorted(FULL_DIMS))
 def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     from tests import modelgen
+    from oracle import oracle as O
     kw = dict(FULL_DIMS[name])
     c, moe = kw.pop("c"), kw.pop("moe")
     layers, plen, steps = kw.pop("layers", 1), kw.pop("plen", 3), kw.pop("steps", 2)
     tm = modelgen.TinyModel(moe, layers=layers, vocab=2048, seed=41, max_seq_len=64, **kw)
+    O.set_threads(ORACLE_THREADS)
     om = tm.oracle_model()
     hm = tm.hip_model(pkg, kv_num_blocks=c + 4, max_seqs=c, max_tokens=max(4, plen) * c)
     rng = np.random.default_rng(42)
     prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
     toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
     cur = np.zeros(c, np.uint32)
-    worst_cos, worst_rel, near = 1.0, 0.0, 0
-
-    route_ties = 0
-
-    def check(i, ref, got, tok):
-        nonlocal worst_cos, worst_rel, near, route_ties
-        ri = int(np.argmax(ref))
-        # a router near-tie (k-th and (k+1)-th logits closer than the fp16 noise of the router input, ≈1e-3 of the
-        # logit scale) may legitimately pick the other expert: such a row only has to stay close in direction
-        if om.last_route_gap() < 0.05:
-            route_ties += 1
-            assert modelgen.cosine(ref, got) > 0.99
-            return ri
-        worst_cos = min(worst_cos, modelgen.cosine(ref, got))
-        err = float(np.max(np.abs(ref - got)))
-        worst_rel = max(worst_rel, err / (float(np.max(np.abs(ref))) + 1e-30))
-        if modelgen.margin(ref) > 4 * err:
-            assert int(tok) == ri, (name, i)
-        else:
-            near += 1
-        return ri
-
-    for i, p in enumerate(prompts):
-        cur[i] = check(i, om.forward(i, p, 0), lg[i], toks[i])
-    for s in range(steps):                                       # teacher-forced on the oracle's tokens
-        toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
-        for i in range(c):
-            cur[i] = check(i, om.forward(i, np.array([cur[i]], np.uint32), plen + s), lg[i], toks[i])
     # Reference criterion (qwen3_cuda_parity_test.rs:194-240): argmax + cosine > 0.999.  The logits bound is wider than the
     # tiny models' 2 %: a numpy emulation of the fp16 lane's storage roundings (f16 after every op, same experts picked)
     # differs from the f32 CPU path by percent-level logit errors on single tokens at these dims (measured with an earlier,
     # larger-gain weight set: hidden NMSE 7.7e-4 on the worst token where the GPU had 6.7e-4).
     # (the hidden-256 entries average the fp16 storage rounding over 8–20× fewer terms than the BASELINE shapes: 0.995 / 10 %)
     small = tm.cfg["hidden"] <= 256
-    assert worst_cos > (0.995 if small else 0.999) and worst_rel < (0.1 if small else 5e-2), (worst_cos, worst_rel)
-    assert near <= c and route_ties <= (c if small else c // 4)  # near-ties are rare at real dims; rows must be decided
+    par = modelgen.Parity(f"full-dims-{name}", cos_min=0.995 if small else 0.999, rel_max=0.1 if small else 5e-2)
+    gap = (lambda: om.last_route_gap_rel()) if moe else (lambda: float("inf"))
+    for i, p in enumerate(prompts):
+        ref = om.forward(i, p, 0)
+        cur[i] = par.check(f"prefill/{i}", ref, lg[i], toks[i], gap())
+    for s in range(steps):                                       # teacher-forced on the oracle's tokens
+        toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+        for i in range(c):
+            ref = om.forward(i, np.array([cur[i]], np.uint32), plen + s)
+            cur[i] = par.check(f"step{s}/{i}", ref, lg[i], toks[i], gap())
+    O.set_threads(1)
+    # c·(steps+1) sampled rows: exact ids, at most 2 excused rows in all (their margin and error are in the record), and
+    # at most 2 rows on which a router near-tie picked another expert
+    par.finish(max_mismatches=0 if small else 2, max_route_ties=2 if moe else 0)
     for i in (0, c - 1):
         for is_v in (0, 1):
             assert modelgen.nmse(om.read_kv(i, layers - 1, is_v), hm.read_kv(i, layers - 1, is_v)) < 3e-3
     assert [hm.block_table(i)[0] for i in range(c)] == [[i] for i in range(c)]   # one block each, ids in arrival order
+
+
+# ── the benchmark's own workload at the BASELINE configs' real dimensions ────
+# One layer (vocabulary cut to 2048 rows), c = 32 sequences with 256-token prompts prefilled in ONE 8192-token forward (the
+# forward bench.py times), then 8 decode steps at kv 256 → 264 with all 32 rows in the batch.  The oracle follows three of the
+# sequences (first, middle, last row: ≈ 3 × 256-token prefills at full dims, seconds with the oracle's worker threads);
+# those rows are teacher-forced on the oracle's ids, the other 29 on the device's own.
+BENCH_DIMS = {
+    "qwen3-30b-a3b": dict(moe=True, hidden=2048, nq=32, nkv=4, hd=128, experts=128, top_k=8, expert_inter=768),
+    "llama31-8b": dict(moe=False, hidden=4096, nq=32, nkv=8, hd=128, inter=14336, qk_norm=False, rope_theta=500000.0,
+                       rope_scaling_kind=2, rope_p=(8.0, 1.0, 4.0, 8192.0)),
+    "llama3-70b": dict(moe=False, hidden=8192, nq=64, nkv=8, hd=128, inter=28672, qk_norm=False, rope_theta=500000.0),
+}
+_TM_CACHE = {}
+
+
+def _bench_dims_model(name):
+    from tests import modelgen
+    if name not in _TM_CACHE:
+        _TM_CACHE.clear()                                        # one full-size layer of host weights at a time
+        kw = dict(BENCH_DIMS[name])
+        _TM_CACHE[name] = modelgen.TinyModel(kw.pop("moe"), layers=1, vocab=2048, seed=43, max_seq_len=320, **kw)
+    return _TM_CACHE[name]
+
+
+@pytest.mark.parametrize("name", sorted(BENCH_DIMS))
+def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, forms):
+    from tests import modelgen
+    from oracle import oracle as O
+    tm = _bench_dims_model(name)
+    moe = tm.cfg["num_experts"] > 0
+    c, plen, steps, followed = 32, 256, 8, (0, 13, 31)
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    hm = tm.hip_model(pkg, kv_num_blocks=c * 18 + 4, max_seqs=c, max_tokens=c * plen)
+    rng = np.random.default_rng(44)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    forms.reset()
+    toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    # the forms the 8192-token prefill is meant to take: pipelined 64-row GEMM tiles, LDS-shared K/V attention, and for
+    # the MoE model the router GEMM + 64-pair grouped tiles
+    forms.require("w4_tilep", "attn_flash", *(("route_gemm", "moe_tile64") if moe else ()))
+    par = modelgen.Parity(f"bench-workload-{name}", cos_min=0.999, rel_max=5e-2)
+    gap = (lambda: om.last_route_gap_rel()) if moe else (lambda: float("inf"))
+    cur = np.array(toks, np.uint32)                               # unfollowed rows continue on the device's own ids
+    for oc, i in enumerate(followed):
+        cur[i] = par.check(f"prefill/{i}", om.forward(oc, prompts[i], 0), lg[i], toks[i], gap())
+    fed = [cur.copy()]
+    forms.reset()
+    dev_ids = []
+    for s in range(steps):
+        toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+        dev_ids.append(np.array(toks, np.uint32))
+        cur = np.array(toks, np.uint32)
+        for oc, i in enumerate(followed):
+            cur[i] = par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i], gap())
+        fed.append(cur.copy())
+    # decode at c = 32, kv ≈ 260: fused rope + attention with 8 waves, and the 17–32-row chains
+    forms.require("attn_fused_qkv_wide", *(("route_split", "moe_expert_major") if moe else ("dense_slab_chain", "w4_slabs_lds")))
+    O.set_threads(1)
+    rep = par.finish(max_mismatches=1, max_route_ties=1 if moe else 0)   # 27 followed rows: exact ids, at most one excused row
+    for oc, i in enumerate(followed[:2]):
+        for is_v in (0, 1):
+            assert modelgen.nmse(om.read_kv(oc, 0, is_v), hm.read_kv(i, 0, is_v)) < 3e-3
+    # 264 tokens = 17 blocks: 16 handed out at prefill in arrival order, the 17th when the first decode step crossed the
+    # block boundary — after every sequence's prompt blocks, again in row order (paged_pool.rs:466-472)
+    assert hm.block_table(0)[0] == list(range(16)) + [16 * c] and hm.block_table(c - 1)[0] == list(range(16 * (c - 1), 16 * c)) + [17 * c - 1]
+    # the hipGraph decode loop on the same weights and prompts reproduces the eager steps' ids bit for bit (rows whose fed
+    # ids equal the device's own throughout, i.e. all rows unless a followed row was excused above)
+    for i in range(c):
+        hm.release(i)
+    toks2, _ = hm.unified_forward([(100 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+    forms.reset()
+    g = hm.decode_steps([100 + i for i in range(c)], toks2, steps)
+    forms.require("graph_capture", "graph_replay")
+    same = [i for i in range(c) if all(int(fed[s][i]) == int((toks2 if s == 0 else g[s - 1])[i]) for s in range(steps))]
+    assert len(same) >= c - rep["id_mismatches"] - rep["route_ties"] - (3 if rep["id_mismatches"] + rep["route_ties"] else 0), (len(same), rep)
+    for s in range(steps):
+        assert np.array_equal(g[s][same], dev_ids[s][same]), s
 
 
 def test_block_level_prefix_cache_reuses_kv_and_matches_full_prefill(pkg):
@@ -462,78 +529,99 @@ def test_decode_steps_graph_on_windowed_models(pkg, kind):
                 assert int(np.argmax(lg)) == seq[s + 1], (kind, i, s)
 
 
-def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg):
-    """TP=2 of the runner, end to end on one GPU: two rank models (per-rank config, Megatron-style GPTQ shards from tp.py:
-    column-parallel qkv / gate_up, row-parallel o / down, kv heads split) run on two threads and meet in an in-process
-    all-reduce after o_proj and down_proj (tp_decode.rs:363-366).  Both ranks must produce identical logits, equal to the
-    unsharded model's within fp16 tolerance (TP=n vs TP=1, ids equal)."""
-    import ctypes as C
+def _load_tp(pkg):
     import os
-    import threading
     import __graft_entry__ as ge
-    from tests import modelgen
     spec = ge.importlib.util.spec_from_file_location("fh_tp", os.path.join(os.path.dirname(pkg.__file__), "tp.py"))
     tp = ge.importlib.util.module_from_spec(spec)
     spec.loader.exec_module(tp)
-    nq, nkv, hd, H, I, world = 8, 4, 128, 256, 512, 2
-    tm = modelgen.TinyModel(False, layers=3, hidden=H, nq=nq, nkv=nkv, hd=hd, inter=I, seed=111)
-    full = tm.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    return tp
+
+
+def _tp_rank_models(pkg, tm, world, **model_kw):
+    """The `world` rank models of a dense TinyModel: per-rank config (heads, kv heads and intermediate divided by world) and
+    Megatron-style GPTQ shards from tp.py — column-parallel qkv / gate_up, row-parallel o / down, everything else replicated
+    (tensor_parallel.rs:148-340)."""
+    tp = _load_tp(pkg)
+    c = tm.cfg
+    nq, nkv, hd, I = c["num_heads"], c["num_kv_heads"], c["head_dim"], c["intermediate"]
     qd, kvd = nq * hd, nkv * hd
-    lib = pkg.load_library()
-    lb = C.c_void_p()
-    assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
     ranks = []
     for r in range(world):
-        cfg = dict(tm.cfg, num_heads=nq // world, num_kv_heads=nkv // world, intermediate=I // world, tp_rank=r, tp_world=world)
-        m = pkg.HipModel(group_size=128, kv_num_blocks=16, max_seqs=4, max_tokens=64, **cfg)
+        cfg = dict(c, num_heads=nq // world, num_kv_heads=nkv // world, intermediate=I // world, tp_rank=r, tp_world=world)
+        m = pkg.HipModel(group_size=128, **model_kw, **cfg)
         for name, data in tm.glob.items():
             m.set_global(name, data)
         for li, L in enumerate(tm.layers):
             for name, data in L["dense"].items():
                 m.set_layer_dense(li, name, data)
             k, n, qw, sc, qz = L["gptq"]["qkv"]
-            s = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [qd, kvd, kvd], r, world)
-            m.set_gptq(li, "qkv", *s, k, s[0].shape[1])
+            sh = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [qd, kvd, kvd], r, world)
+            m.set_gptq(li, "qkv", *sh, k, sh[0].shape[1])
             k, n, qw, sc, qz = L["gptq"]["o"]
-            s = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
-            m.set_gptq(li, "o", *s, k // world, n)
+            sh = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
+            m.set_gptq(li, "o", *sh, k // world, n)
             k, n, qw, sc, qz = L["gptq"]["gate_up"]
-            s = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [I, I], r, world)
-            m.set_gptq(li, "gate_up", *s, k, s[0].shape[1])
+            sh = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [I, I], r, world)
+            m.set_gptq(li, "gate_up", *sh, k, sh[0].shape[1])
             k, n, qw, sc, qz = L["gptq"]["down"]
-            s = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
-            m.set_gptq(li, "down", *s, k // world, n)
+            sh = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
+            m.set_gptq(li, "down", *sh, k // world, n)
         m.finalize()
-        assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
         ranks.append(m)
-    rng = np.random.default_rng(112)
-    prompt = rng.integers(0, tm.cfg["vocab"], size=19).astype(np.uint32)
-    results = [None] * world
-    errors = []
+    return ranks
+
+
+def _run_ranks(ranks, fn, timeout=300):
+    """fn(rank_index, model) on one thread per rank (the reference drives one OS thread per rank, tp_decode.rs:94-148)."""
+    import threading
+    results, errors = [None] * len(ranks), []
 
     def run(r):
         try:
-            out = []
-            toks, lg = ranks[r].unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
-            out.append((int(toks[0]), lg[0].copy()))
-            for s in range(3):
-                toks, lg = ranks[r].unified_forward([(1, [out[-1][0]], len(prompt) + s, True)], greedy=True, want_logits=True)
-                out.append((int(toks[0]), lg[0].copy()))
-            results[r] = out
-        except Exception as e:      # a rank that dies would leave the other in the barrier: surface it
-            errors.append(e)
+            results[r] = fn(r, ranks[r])
+        except Exception as e:      # a rank that dies would leave the others waiting: surface it
+            errors.append((r, e))
 
-    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    th = [threading.Thread(target=run, args=(r,)) for r in range(len(ranks))]
     [t_.start() for t_ in th]
-    [t_.join(timeout=120) for t_ in th]
+    [t_.join(timeout=timeout) for t_ in th]
     assert not errors, errors
     assert all(r is not None for r in results), "a rank did not finish"
-    ref = []
-    toks, lg = full.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
-    ref.append((int(toks[0]), lg[0].copy()))
-    for s in range(3):
-        toks, lg = full.unified_forward([(1, [ref[-1][0]], len(prompt) + s, True)], greedy=True, want_logits=True)
-        ref.append((int(toks[0]), lg[0].copy()))
+    return results
+
+
+def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg, forms):
+    """TP=2 of the runner, end to end on one GPU: two rank models run on two threads and meet in an in-process all-reduce
+    after o_proj and down_proj (tp_decode.rs:363-366).  Both ranks must produce identical logits, equal to the unsharded
+    model's within fp16 tolerance (TP=n vs TP=1, ids equal)."""
+    import ctypes as C
+    from tests import modelgen
+    nq, nkv, hd, H, I, world = 8, 4, 128, 256, 512, 2
+    tm = modelgen.TinyModel(False, layers=3, hidden=H, nq=nq, nkv=nkv, hd=hd, inter=I, seed=111)
+    full = tm.hip_model(pkg, kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    lib = pkg.load_library()
+    lb = C.c_void_p()
+    assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
+    ranks = _tp_rank_models(pkg, tm, world, kv_num_blocks=16, max_seqs=4, max_tokens=64)
+    for m in ranks:
+        assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
+    rng = np.random.default_rng(112)
+    prompt = rng.integers(0, tm.cfg["vocab"], size=19).astype(np.uint32)
+
+    def drive(_r, m):
+        out = []
+        toks, lg = m.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
+        out.append((int(toks[0]), lg[0].copy()))
+        for s in range(3):
+            toks, lg = m.unified_forward([(1, [out[-1][0]], len(prompt) + s, True)], greedy=True, want_logits=True)
+            out.append((int(toks[0]), lg[0].copy()))
+        return out
+
+    forms.reset()
+    results = _run_ranks(ranks, drive, timeout=120)
+    forms.require("tp_allreduce_loopback")
+    ref = drive(0, full)
     for s in range(4):
         assert np.array_equal(results[0][s][1], results[1][s][1])               # ranks agree bit for bit
         assert results[0][s][0] == ref[s][0]                                     # ids equal to TP=1
@@ -541,6 +629,133 @@ def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg):
         assert np.max(np.abs(ref[s][1] - results[0][s][1])) < 5e-3 * np.max(np.abs(ref[s][1]))
     del ranks
     lib.ferrum_hip_tp_loopback_destroy(lb)
+
+
+def _tp_vs_single(tm, full, results, c, steps, label):
+    """Rank agreement (bit for bit) and TP=n vs TP=1 (ids equal, logits within fp16 tolerance).  Returns the
+    number of sampled rows whose id differs from the unsharded model's (a different K-summation order can flip a near-tie)."""
+    from tests import modelgen
+    ref = results["ref"]
+    flips = 0
+    for s in range(steps + 1):
+        for r in range(1, len(results["ranks"])):
+            assert np.array_equal(results["ranks"][0][s][1], results["ranks"][r][s][1]), (label, "rank", r, "step", s)
+            assert np.array_equal(results["ranks"][0][s][0], results["ranks"][r][s][0])
+        g_ids, g_lg = results["ranks"][0][s]
+        r_ids, r_lg = ref[s]
+        for i in range(c):
+            assert modelgen.cosine(r_lg[i], g_lg[i]) > 0.9999, (label, s, i)
+            assert np.max(np.abs(r_lg[i] - g_lg[i])) < 1e-2 * np.max(np.abs(r_lg[i])), (label, s, i)
+            flips += int(g_ids[i]) != int(r_ids[i])
+    return flips
+
+
+def test_tp8_llama70b_rank_shard_shapes_through_loopback(pkg, forms):
+    """BASELINE configs[4] (Llama-3 70B GPTQ-INT4, TP=8) at its real per-rank shapes — qkv 8192→1280, o 1024→8192, gate_up
+    8192→7168, down 3584→8192, 8 query heads and ONE kv head per rank (tensor_parallel.rs:148-340) — one layer, eight rank
+    models on eight threads meeting in the in-process all-reduce after o_proj and down_proj.  A 480-token prefill (pipelined
+    tile GEMMs at the shard shapes) and three decode steps of 20 rows (the 17–32-row chain with its tensor-parallel branch);
+    teacher-forced on the unsharded model's ids.  The unsharded model itself is checked against the oracle at these
+    dimensions by test_bench_workload_at_real_dims_prefill_8192_then_decode_c32[llama3-70b]."""
+    import ctypes as C
+    tm = _bench_dims_model("llama3-70b")
+    world, c, plen, steps = 8, 20, 24, 3
+    full = tm.hip_model(pkg, kv_num_blocks=c * 3 + 4, max_seqs=c, max_tokens=c * plen)
+    lib = pkg.load_library()
+    lb = C.c_void_p()
+    assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
+    ranks = _tp_rank_models(pkg, tm, world, kv_num_blocks=c * 3 + 4, max_seqs=c, max_tokens=c * plen)
+    assert (ranks[0].cfg.num_heads, ranks[0].cfg.num_kv_heads, ranks[0].cfg.intermediate) == (8, 1, 3584)
+    for m in ranks:
+        assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
+    rng = np.random.default_rng(45)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    ref = []
+    toks, lg = full.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    ref.append((np.array(toks), lg.copy()))
+    for s in range(steps):
+        toks, lg = full.unified_forward([(i, [int(ref[-1][0][i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+        ref.append((np.array(toks), lg.copy()))
+
+    def drive(_r, m):
+        out = []
+        toks, lg = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        out.append((np.array(toks), lg.copy()))
+        for s in range(steps):                                   # teacher-forced on the unsharded model's ids
+            toks, lg = m.unified_forward([(i, [int(ref[s][0][i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+            out.append((np.array(toks), lg.copy()))
+        return out
+
+    forms.reset()
+    res = _run_ranks(ranks, drive)
+    forms.require("tp_allreduce_loopback", "w4_tilep", "dense_slab_chain", "w4_slabs_lds")
+    flips = _tp_vs_single(tm, full, {"ranks": res, "ref": ref}, c, steps, "llama70b-tp8")
+    assert flips <= 1, flips                                     # 80 sampled rows: ids equal to TP=1 (at most one near-tie flip)
+    del ranks
+    lib.ferrum_hip_tp_loopback_destroy(lb)
+
+
+def test_tp2_gemma27b_shards_graph_decode_with_oneshot_allreduce(pkg, forms, knobs):
+    """BASELINE configs[3] (Gemma-3 27B GPTQ-INT4, TP=2) at its real per-rank shapes — 16 query / 8 kv heads and
+    intermediate 10752 per rank, hidden 5376 (42 quant groups), sandwich norms on an fp32 residual, one local and one global
+    layer — with the decode loop captured in a hipGraph PER RANK: the all-reduce inside the graph is the hand-written
+    one-shot peer reduce between the two ranks' comm buffers (rank-ordered fp32 sum: the same bits on both ranks and the
+    same bits as the host-barrier loopback).  Free-running greedy decode of 18 rows; ids against the unsharded model."""
+    import ctypes as C
+    from tests import modelgen
+    kw = dict(FULL_DIMS["gemma3-27b"])
+    for k_ in ("c", "moe", "layers", "plen", "steps"):
+        kw.pop(k_)
+    tm = modelgen.TinyModel(False, layers=2, vocab=2048, seed=47, max_seq_len=64, **kw)
+    world, c, plen, steps = 2, 18, 4, 6
+    mk = dict(kv_num_blocks=c + 4, max_seqs=c, max_tokens=c * plen)
+    full = tm.hip_model(pkg, **mk)
+    rng = np.random.default_rng(48)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    ids = list(range(c))
+
+    def drive(_r, m):
+        toks, lg = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        return np.array(toks), lg.copy(), m.decode_steps(ids, toks, steps)
+
+    ref = drive(0, full)
+    # (a) one-shot peer all-reduce, decode loop in a graph on each rank
+    ranks = _tp_rank_models(pkg, tm, world, **mk)
+    assert (ranks[0].cfg.num_heads, ranks[0].cfg.num_kv_heads, ranks[0].cfg.intermediate) == (16, 8, 10752)
+    comms = pkg.Comm.local_group(world, 4 << 20)
+    for m, cm in zip(ranks, comms):
+        m.set_comm(cm)
+    forms.reset()
+    one = _run_ranks(ranks, drive)
+    forms.require("tp_allreduce_oneshot", "graph_capture", "graph_replay", "dense_slab_chain", absent=("tp_allreduce_rccl", "tp_allreduce_loopback"))
+    for cm in comms:
+        st = cm.oneshot_status()
+        assert st["timeouts"] == 0 and st["epoch"] > 0, st
+    del ranks
+    # (b) the same shards through the host-barrier loopback, eager launches
+    lib = pkg.load_library()
+    lb = C.c_void_p()
+    assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
+    ranks = _tp_rank_models(pkg, tm, world, **mk)
+    for m in ranks:
+        assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
+    forms.reset()
+    host = _run_ranks(ranks, drive)
+    forms.require("tp_allreduce_loopback", absent=("graph_replay", "tp_allreduce_oneshot"))
+    del ranks
+    lib.ferrum_hip_tp_loopback_destroy(lb)
+    for r in range(world):
+        for a_, b_ in zip(one[r], host[r]):
+            assert np.array_equal(a_, b_), r                     # graph + one-shot ≡ eager + host loopback, bit for bit
+        for a_, b_ in zip(one[0], one[r]):
+            assert np.array_equal(a_, b_), r                     # ranks agree bit for bit
+    # against TP=1: prefill logits within fp16 tolerance, ids equal (a free-running row that flips at a near-tie diverges
+    # from there on, so rows are compared as whole histories: at most one of the 18 may differ)
+    for i in range(c):
+        assert modelgen.cosine(ref[1][i], one[0][1][i]) > 0.9999
+        assert np.max(np.abs(ref[1][i] - one[0][1][i])) < 1e-2 * np.max(np.abs(ref[1][i]))
+    same = sum(int(ref[0][i]) == int(one[0][0][i]) and np.array_equal(ref[2][:, i], one[0][2][:, i]) for i in range(c))
+    assert same >= c - 1, same
 
 
 def test_greedy_policy_with_token_mask_and_repetition_penalty(pkg):
@@ -582,7 +797,8 @@ def test_greedy_policy_with_token_mask_and_repetition_penalty(pkg):
 
 def test_rccl_plumbing_selftest(pkg):
     """The tensor-parallel path needs ≥ 2 GPUs; what can be checked on one is that the RCCL entry points resolve and a
-    1-rank fp16 sum all-reduce on a stream is the identity."""
+    1-rank fp16 sum all-reduce on a stream is the identity — eagerly and from inside a captured, replayed hipGraph (the
+    decode loop captures its all-reduces)."""
     lib = pkg.load_library()
     assert lib.ferrum_hip_tp_selftest(4096 * 32) == 0, lib.ferrum_hip_last_error().decode()
 

@@ -143,8 +143,9 @@ def test_gptq_asymmetric_and_act_order(env, k, n, m):
     (640, 320, (1024, 1100), True), (2048, 512, (1024,), True), (1024, 1000, (1153,), True), (768, 640, (1025,), False),
     # 33–63 rows of the larger projections (K·N ≥ 12 Mi) take the pipelined tile kernel with one ragged 64-row tile
     (4096, 4096, (33, 48, 63), True), (2048, 6144, (40,), False)])
-def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym):
+def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym, forms):
     pkg, B, ctx, O, torch = env
+    seen = set()
     qw, sc, qz = O.make_synthetic_gptq(k, n, 128, k * 7 + n, symmetric=sym)
     sc = f16r(sc / (0.28 * np.sqrt(k)))
     bias = f16r(np.random.default_rng(n).standard_normal(n)) if n == 640 else None
@@ -153,12 +154,24 @@ def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym):
     for m in ms:
         x = f16r(np.random.default_rng(m).standard_normal((m, k)))
         out = torch.full((m + 1, n), 7.0, dtype=torch.float16, device="cuda")     # guard row: nothing may write past m rows
+        forms.reset()
         lin.forward(ctx, dev16(torch, x), out, m)
         ctx.sync()
+        # the kernel the row count selects (w4_gemm_dense): ≤ 16 rows K-split skinny; ≥ 64 rows (33 on the larger projections)
+        # the pipelined tile kernel; in between the LDS-shared-activation kernel on shapes deep or wide enough for it
+        h = forms.hits()
+        ran = [f for f in ("w4_wgsplit", "w4_ldsa", "w4_tilep") if h.get(f)]
+        assert len(ran) == 1, (k, n, m, h)
+        big = k * n >= (12 << 20)
+        want = "w4_wgsplit" if m <= 16 else ("w4_tilep" if m >= (33 if big else 64) else None)
+        assert want is None or ran[0] == want, (k, n, m, h)
+        seen.add(ran[0])
         ref = O.gemm(x, w, m, n, k) + (bias[None, :] if bias is not None else 0.0)
         got = host(out)
         assert nmse(ref, got[:m]) < NMSE_FP16_TOL, (k, n, m)
         assert np.all(got[m] == 7.0), (k, n, m)
+    if (k, n) in ((8192, 2048), (1024, 16384)):
+        assert "w4_ldsa" in seen, seen                     # the 17–32-row cases of these shapes are the LDS-A kernel's
 
 
 def test_gptq_linearity(env):
@@ -466,10 +479,11 @@ def test_paged_batched_decode_attention(env, nq, nkv, hd, kv_lens):
 
 @pytest.mark.parametrize("window,nq,nkv,hd", [(0, 8, 2, 128), (24, 8, 2, 128), (0, 14, 2, 128), (40, 28, 4, 128), (0, 4, 4, 64),
                                               (17, 6, 6, 64), (0, 4, 1, 256), (33, 32, 16, 128), (1, 8, 2, 128)])
-def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd, monkeypatch):
+def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd, knobs, forms):
     pkg, B, ctx, O, torch = env
-    if (window + nq) % 2 == 0:
-        monkeypatch.setenv("FERRUM_HIP_ATTN_RS_MIN_WGS", "1")     # half of the cases through the row-split (prefill) form
+    want_rs = (window + nq) % 2 == 0
+    if want_rs:
+        knobs.set(ATTN_RS_MIN_WGS=1)                               # half of the cases through the row-split (prefill) form
     rng = np.random.default_rng(11 + window + nq + hd)
     q_lens, pos_offs = [37, 1, 16, 3], [0, 90, 20, 250]       # fresh prefill, decode, chunk, late chunk
     S = len(q_lens)
@@ -494,6 +508,7 @@ def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd, monkeypatc
                              torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
                              m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
     ctx.sync()
+    forms.require("attn_row_split" if want_rs else "attn_kv_narrow", absent=("attn_flash",))
     got = host(out)
     for s in range(S):
         ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
@@ -510,11 +525,11 @@ def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd, monkeypatc
 
 
 @pytest.mark.parametrize("window", [0, 50])
-def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window, monkeypatch):
+def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window, knobs, forms):
     """24 prompts × 200 tokens (GQA group 2 ⇒ 25 row tiles each): enough workgroups for the row-split prefill form on its own
     heuristic; every sequence against the CPU restatement."""
     pkg, B, ctx, O, torch = env
-    monkeypatch.setenv("FERRUM_HIP_ATTN_NO_FLASH", "1")            # the flash form has its own test below
+    knobs.set(ATTN_NO_FLASH=1)                                     # the flash form has its own test below
     rng = np.random.default_rng(77 + window)
     nq, nkv, hd, S, T = 8, 4, 128, 24, 200
     q_lens, pos_offs = [T] * S, [0] * (S - 2) + [48, 5]            # two of them continue an existing context
@@ -539,6 +554,7 @@ def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window, monkey
                              torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
                              m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
     ctx.sync()
+    forms.require("attn_row_split", absent=("attn_flash", "attn_kv_narrow"))
     got = host(out)
     for s in range(S):
         ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
@@ -547,11 +563,11 @@ def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window, monkey
 
 @pytest.mark.parametrize("window,nq,nkv,hd", [(0, 8, 2, 128), (24, 8, 2, 128), (0, 14, 2, 128), (40, 32, 4, 128), (0, 4, 4, 64),
                                               (17, 6, 6, 64), (0, 4, 1, 256), (33, 32, 16, 128), (1, 8, 2, 128)])
-def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, monkeypatch):
+def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, knobs, forms):
     """The flash form (K/V of a block pair staged once per workgroup in LDS, 8 row tiles per workgroup): ragged prefill batch —
     fresh prompts, chunks that continue a context, a sequence shorter than one workgroup unit, odd block counts."""
     pkg, B, ctx, O, torch = env
-    monkeypatch.setenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", "1")
+    knobs.set(ATTN_FLASH_MIN_ROWS=1)
     rng = np.random.default_rng(5 + window + nq + hd)
     q_lens, pos_offs = [70, 33, 64, 17, 49], [0, 90, 20, 5, 300]
     S = len(q_lens)
@@ -576,6 +592,7 @@ def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, monkeyp
                              torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
                              m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
     ctx.sync()
+    forms.require("attn_flash", absent=("attn_row_split", "attn_kv_narrow"))
     got = host(out)
     assert np.all(got[m_total] == 9.0)
     for s in range(S):
@@ -583,10 +600,10 @@ def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, monkeyp
         assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
 
 
-def test_paged_prefill_attention_lds_shared_kv_many_sequences(env, monkeypatch):
+def test_paged_prefill_attention_lds_shared_kv_many_sequences(env, knobs, forms):
     """The flash form over 70 sequences (two passes of its in-kernel sequence lookup), two of them empty."""
     pkg, B, ctx, O, torch = env
-    monkeypatch.setenv("FERRUM_HIP_ATTN_FLASH_MIN_ROWS", "1")
+    knobs.set(ATTN_FLASH_MIN_ROWS=1)
     rng = np.random.default_rng(404)
     nq, nkv, hd, S = 4, 2, 128, 70
     q_lens = [int(x) for x in rng.integers(15, 26, size=S)]
@@ -613,6 +630,7 @@ def test_paged_prefill_attention_lds_shared_kv_many_sequences(env, monkeypatch):
                              torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
                              m_total, max(kv_lens), nq, nkv, hd, 0, 16, max_blocks, max(q_lens))
     ctx.sync()
+    forms.require("attn_flash", absent=("attn_row_split", "attn_kv_narrow"))
     got = host(out)
     for s in range(S):
         if q_lens[s] == 0:
@@ -621,7 +639,7 @@ def test_paged_prefill_attention_lds_shared_kv_many_sequences(env, monkeypatch):
         assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
 
 
-def test_paged_decode_long_context_split_kv(env):
+def test_paged_decode_long_context_split_kv(env, forms):
     # exercises the grid.z flash-decode split + reduce at a BASELINE-like head config (Qwen3-30B: 32/4 heads)
     pkg, B, ctx, O, torch = env
     rng = np.random.default_rng(3)
@@ -646,6 +664,7 @@ def test_paged_decode_long_context_split_kv(env):
                                      torch.from_numpy(np.array(kv_lens, np.int32)).cuda(), S, max(kv_lens), nq, nkv, hd,
                                      16, max_blocks)
     ctx.sync()
+    forms.require("attn_kv_wide", "attn_split_reduce")
     got = host(out)
     for s, n in enumerate(kv_lens):
         ref = _ref_attention(O, q[s:s + 1], K[s], V[s], n - 1, nq, nkv, hd)

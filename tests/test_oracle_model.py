@@ -33,3 +33,26 @@ def test_forward_rejects_wrong_pos_offset(oracle):
     om = tm.oracle_model()
     with pytest.raises(RuntimeError):
         om.forward(0, np.array([1, 2], np.uint32), 5)
+
+
+@pytest.mark.parametrize("moe", [False, True])
+def test_worker_threads_do_not_change_a_single_bit(oracle, moe):
+    """The oracle's row / head / token loops may run on several threads in the real-dimension GPU parity cases
+    (oracle.set_threads): every output element is still computed by one thread in the reference's loop order, so the
+    logits, the KV cache and the stand-alone GEMM / attention / MoE ops must be bit-identical to the 1-thread run."""
+    tm = modelgen.TinyModel(moe, layers=2, seed=5, hidden=512, nq=8, nkv=2, inter=1024, experts=16, top_k=4, vocab=4096)
+    rng = np.random.default_rng(6)
+    toks = rng.integers(0, tm.cfg["vocab"], size=70).astype(np.uint32)
+    outs = []
+    for threads in (1, 5):
+        oracle.set_threads(threads)
+        assert oracle.get_threads() == threads
+        om = tm.oracle_model()
+        last, allg = om.forward(0, toks, 0, all_logits=True)
+        step = om.forward(0, toks[:1], 70)
+        a = rng.standard_normal((37, 2048)).astype(np.float32) if threads == 1 else a
+        b = rng.standard_normal((300, 2048)).astype(np.float32) if threads == 1 else b
+        outs.append((last, allg, step, om.read_kv(0, 1, 0), om.read_kv(0, 1, 1), oracle.gemm(a, b, 37, 300, 2048)))
+    oracle.set_threads(1)
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
