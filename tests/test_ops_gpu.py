@@ -481,9 +481,10 @@ def test_paged_batched_decode_attention(env, nq, nkv, hd, kv_lens):
                                               (17, 6, 6, 64), (0, 4, 1, 256), (33, 32, 16, 128), (1, 8, 2, 128)])
 def test_paged_varlen_attention_mixed_batch(env, window, nq, nkv, hd, knobs, forms):
     pkg, B, ctx, O, torch = env
-    want_rs = (window + nq) % 2 == 0
-    if want_rs:
-        knobs.set(ATTN_RS_MIN_WGS=1)                               # half of the cases through the row-split (prefill) form
+    # half of the cases ask for the row-split (prefill) form; it applies from 4 row tiles per sequence (37 tokens × GQA group / 16)
+    want_rs = (window + nq) % 2 == 0 and -(-37 * (nq // nkv) // 16) >= 4
+    if (window + nq) % 2 == 0:
+        knobs.set(ATTN_RS_MIN_WGS=1)
     rng = np.random.default_rng(11 + window + nq + hd)
     q_lens, pos_offs = [37, 1, 16, 3], [0, 90, 20, 250]       # fresh prefill, decode, chunk, late chunk
     S = len(q_lens)
