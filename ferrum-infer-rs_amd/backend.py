@@ -130,6 +130,13 @@ class ExpertStack(GptqLinear):
                "moe_gemm_phase")
 
 
+    def gemm_phase_batched(self, ctx, inp, dispatches, output, k, fused_silu_mul=False):
+        """MarlinExpertStack::gemm_phase_batched: dispatches = [(expert, in_row_offset, out_row_offset, m)] (host)."""
+        import numpy as np
+        d = np.ascontiguousarray(np.asarray(dispatches, np.int32).reshape(-1, 4))
+        _check(ctx.lib.ferrum_hip_moe_gemm_phase_batched_f16(self.handle, _ptr(inp), d.ctypes.data_as(i32p), len(d), _ptr(output), k,
+                                                             int(fused_silu_mul), ctx.stream), "gemm_phase_batched")
+
     def gemm_phase_inline_align(self, ctx, inp, expert_ids_per_pair, output, prob_m, num_experts, top_k, max_blocks,
                                 fused_silu_mul=False):
         _check(ctx.lib.ferrum_hip_moe_gemm_phase_inline_align_f16(self.handle, _ptr(inp), _ptr(expert_ids_per_pair),
@@ -414,6 +421,63 @@ class HipBackend:
         _check(ctx.lib.ferrum_hip_moe_align_block_size(_ptr(expert_ids), _ptr(sorted_token_ids), _ptr(block_ids),
                                                        _ptr(total_post_pad), batch_x_topk, num_experts, block_size,
                                                        sorted_max, ctx.stream), "moe_align_block_size")
+
+    @staticmethod
+    def moe_align_block_size(ctx, expert_ids, sorted_token_ids, block_ids, total_post_pad, batch_x_topk, num_experts,
+                             block_size, sorted_max):
+        """capabilities.rs:429 — sorted_token_ids hold unpadded packed rows."""
+        _check(ctx.lib.ferrum_hip_moe_align_block_size_packed_rows(_ptr(expert_ids), _ptr(sorted_token_ids), _ptr(block_ids),
+                                                                   _ptr(total_post_pad), batch_x_topk, num_experts,
+                                                                   block_size, sorted_max, ctx.stream), "moe_align_block_size")
+
+    @staticmethod
+    def moe_build_pairs_by_token(ctx, expert_ids, pairs_by_token, packed_token_idx, expert_offsets, batch_x_topk,
+                                 num_experts, top_k):
+        _check(ctx.lib.ferrum_hip_moe_build_pairs_by_token(_ptr(expert_ids), _ptr(pairs_by_token), _ptr(packed_token_idx),
+                                                           _ptr(expert_offsets), batch_x_topk, num_experts, top_k,
+                                                           ctx.stream), "moe_build_pairs_by_token")
+
+    @staticmethod
+    def moe_combine_pairs(ctx, packed_down, pairs_by_token, pair_weights, out, batch, hidden, top_k, total_pairs):
+        """BackendMoeFused::moe_combine with the trait's arguments (capabilities.rs:684)."""
+        _check(ctx.lib.ferrum_hip_moe_combine_pairs_f16(_ptr(packed_down), _ptr(pairs_by_token), _ptr(pair_weights), _ptr(out),
+                                                        batch, hidden, top_k, total_pairs, ctx.stream), "moe_combine")
+
+    @staticmethod
+    def weighted_sum_batched_offset(ctx, slots, weights, weights_offset, out, out_offset, batch, top_k, hidden):
+        _check(ctx.lib.ferrum_hip_weighted_sum_batched_f16(_ptr(slots), _ptr(weights), C.c_size_t(weights_offset), _ptr(out),
+                                                           C.c_size_t(out_offset), batch, top_k, hidden, ctx.stream),
+               "weighted_sum_batched")
+
+    @staticmethod
+    def weighted_sum_batched(ctx, slots, weights, out, batch, top_k, hidden):
+        HipBackend.weighted_sum_batched_offset(ctx, slots, weights, 0, out, 0, batch, top_k, hidden)
+
+    @staticmethod
+    def paged_decode_attention(ctx, q, k_pool, v_pool, out, block_tables, context_lens, num_seqs, num_heads, num_kv_heads,
+                               head_dim, block_size, max_num_blocks_per_seq, q_len):
+        _check(ctx.lib.ferrum_hip_paged_decode_attention_f16(
+            _ptr(q), _ptr(k_pool), _ptr(v_pool), _ptr(out), _ptr(block_tables), _ptr(context_lens), num_seqs, num_heads,
+            num_kv_heads, head_dim, block_size, max_num_blocks_per_seq, q_len, ctx.ws, ctx.stream), "paged_decode_attention")
+
+    # ── BackendGraph (capabilities.rs:35-70) ─────────────────────────────────
+    @staticmethod
+    def begin_graph_capture(ctx):
+        _check(ctx.lib.ferrum_hip_graph_begin_capture(ctx.stream), "begin_graph_capture")
+
+    @staticmethod
+    def end_graph_capture(ctx):
+        g = C.c_void_p()
+        _check(ctx.lib.ferrum_hip_graph_end_capture(ctx.stream, C.byref(g)), "end_graph_capture")
+        return g
+
+    @staticmethod
+    def replay_graph(ctx, graph):
+        _check(ctx.lib.ferrum_hip_graph_replay(graph, ctx.stream), "replay_graph")
+
+    @staticmethod
+    def reset_graph(ctx, graph):
+        _check(ctx.lib.ferrum_hip_graph_destroy(graph), "reset_graph")
 
     @staticmethod
     def moe_combine(ctx, down, weights, out, tokens, top_k, hidden, accumulate=False):

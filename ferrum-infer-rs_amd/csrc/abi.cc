@@ -78,6 +78,15 @@ struct FerrumHipGptq {
     __half* gather_scratch = nullptr;   // act-order input gather buffer [m_cap, K]
     int gather_rows = 0;
     std::vector<void*> retired_scratch;  // outgrown gather buffers: a graph captured earlier may still hold them → freed with the handle
+    // gemm_phase_batched: rotating (pinned host, device, event) slots for the per-call dispatch arrays
+    struct DispatchSlot { int32_t* host = nullptr; int32_t* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; };
+    DispatchSlot slots[4];
+    int next_slot = 0;
+};
+
+struct FerrumHipGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
 };
 
 #define H(p) reinterpret_cast<__half*>(p)
@@ -332,6 +341,11 @@ int ferrum_hip_gptq_free(FerrumHipGptq* g) {
     if (g->dev.bias) (void)hipFree(g->dev.bias);
     if (g->gather_scratch) (void)hipFree(g->gather_scratch);
     for (void* p : g->retired_scratch) (void)hipFree(p);
+    for (auto& sl : g->slots) {
+        if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+        if (sl.host) (void)hipHostFree(sl.host);
+        if (sl.dev) (void)hipFree(sl.dev);
+    }
     delete g;
     return 0;
 }
@@ -516,6 +530,75 @@ int ferrum_hip_paged_batched_decode_attention_f16(const void* q, const void* k_p
                                               ST(stream));
 }
 
+// BackendPagedKv::paged_decode_attention (traits.rs:1719-1738).  q_len == 1: q / out [num_seqs, num_heads, head_dim]
+// token-major, one query token per sequence.  q_len > 1: ONE sequence in causal prefill, q / out [num_heads, q_len, head_dim]
+// head-major; context_lens[0] is the FINAL kv length (token i sees positions [0, context_len − q_len + 1 + i)).
+__global__ void single_seq_index_kernel(const uint32_t* __restrict__ context_lens, uint32_t* __restrict__ cu, uint32_t* __restrict__ pos, int q_len) {
+    if (threadIdx.x == 0) { cu[0] = 0; cu[1] = (uint32_t)q_len; pos[0] = context_lens[0] - (uint32_t)q_len; }
+}
+int ferrum_hip_paged_decode_attention_f16(const void* q, const void* k_pool, const void* v_pool, void* out,
+                                          const int32_t* block_tables, const uint32_t* context_lens, int num_seqs, int num_heads,
+                                          int num_kv_heads, int head_dim, int block_size, int max_num_blocks_per_seq, int q_len,
+                                          FerrumHipWorkspace* ws, void* stream) {
+    FH_REQUIRE(num_seqs == 0 || (q && k_pool && v_pool && out && block_tables && context_lens), "paged_decode_attention: null buffer");
+    FH_REQUIRE(q_len >= 1, "paged_decode_attention: q_len=%d", q_len);
+    if (num_seqs <= 0) return 0;
+    const int kv_bound = max_num_blocks_per_seq * block_size;            // the kv lengths live on the device: the table width bounds them
+    if (q_len == 1)
+        return paged_batched_decode_attention_f16(CH(q), CH(k_pool), CH(v_pool), H(out), block_tables, context_lens, num_seqs, kv_bound,
+                                                  num_heads, num_kv_heads, head_dim, block_size, max_num_blocks_per_seq,
+                                                  ws ? ws->ptr : nullptr, ws ? ws->bytes : 0, ST(stream));
+    if (num_seqs != 1) { fh::set_error("paged_decode_attention: q_len=%d > 1 is the single-sequence prefill form (num_seqs=%d)", q_len, num_seqs); return FERRUM_HIP_UNSUPPORTED; }
+    const size_t elems = (size_t)q_len * num_heads * head_dim;
+    const size_t need = 2 * elems * 2 + 256;
+    FH_REQUIRE(ws && ws->ptr && ws->bytes >= need + (1 << 20), "paged_decode_attention: workspace of %zu bytes needed for the head-major transposes", need + (1 << 20));
+    __half* q_tm = reinterpret_cast<__half*>(ws->ptr);
+    __half* o_tm = q_tm + elems;
+    uint32_t* idx = reinterpret_cast<uint32_t*>(o_tm + elems);
+    float* attn_ws = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ws->ptr) + (need + 255) / 256 * 256);
+    const size_t attn_ws_bytes = ws->bytes - (need + 255) / 256 * 256;
+    hipLaunchKernelGGL(single_seq_index_kernel, dim3(1), dim3(64), 0, ST(stream), context_lens, idx, idx + 2, q_len);
+    FH_CHECK_LAUNCH();
+    if (int rc = transpose_head_to_token_f16(CH(q), q_tm, q_len, num_heads, head_dim, ST(stream))) return rc;
+    if (int rc = paged_varlen_attention_f16(q_tm, CH(k_pool), CH(v_pool), o_tm, idx, idx + 2, block_tables, 1, q_len, q_len, kv_bound,
+                                            num_heads, num_kv_heads, head_dim, 0, block_size, max_num_blocks_per_seq, attn_ws,
+                                            attn_ws_bytes, ST(stream))) return rc;
+    return transpose_token_to_head_f16(o_tm, H(out), q_len, num_heads, head_dim, ST(stream));
+}
+
+// BackendGraph (capabilities.rs:35-70): begin / end stream capture, replay, drop.  The key → graph map of the trait
+// (`end_graph_capture(key)`, `replay_graph(key)`) is a HashMap in the binding; this side owns the graph objects.
+int ferrum_hip_graph_begin_capture(void* stream) {
+    FH_CHECK_HIP(hipStreamBeginCapture(ST(stream), hipStreamCaptureModeThreadLocal));
+    return 0;
+}
+int ferrum_hip_graph_end_capture(void* stream, FerrumHipGraph** graph) {
+    FH_REQUIRE(graph, "graph_end_capture: null output");
+    auto* g = new FerrumHipGraph();
+    hipError_t e = hipStreamEndCapture(ST(stream), &g->graph);
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+        fh::set_error("graph_end_capture: %s", hipGetErrorString(e));
+        return 1;
+    }
+    *graph = g;
+    return 0;
+}
+int ferrum_hip_graph_replay(FerrumHipGraph* graph, void* stream) {
+    FH_REQUIRE(graph && graph->exec, "graph_replay: null graph");
+    FH_CHECK_HIP(hipGraphLaunch(graph->exec, ST(stream)));
+    return 0;
+}
+int ferrum_hip_graph_destroy(FerrumHipGraph* graph) {
+    if (!graph) return 0;
+    if (graph->exec) (void)hipGraphExecDestroy(graph->exec);
+    if (graph->graph) (void)hipGraphDestroy(graph->graph);
+    delete graph;
+    return 0;
+}
+
 int ferrum_hip_paged_decode_attention_fused_qkv_f16(const void* qkv, const void* q_norm_w, const void* k_norm_w,
                                                     const float* cos_tab, const float* sin_tab, float eps, int qk_mode,
                                                     void* k_pool, void* v_pool, void* out, const int32_t* block_tables,
@@ -559,6 +642,102 @@ int ferrum_hip_moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_t
 int ferrum_hip_moe_combine_f16(const void* down, const float* weights, void* out, int tokens, int top_k, int hidden,
                                int accumulate, void* stream) {
     return moe_combine_f16(CH(down), weights, H(out), tokens, top_k, hidden, accumulate, ST(stream));
+}
+
+int ferrum_hip_moe_align_block_size_packed_rows(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
+                                                int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
+                                                int sorted_max, void* stream) {
+    FH_REQUIRE(batch_x_topk == 0 || (expert_ids && sorted_token_ids && block_ids && total_post_pad), "moe_align_block_size: null buffer");
+    return moe_align_block_size_packed_rows(expert_ids, sorted_token_ids, block_ids, total_post_pad, batch_x_topk, num_experts,
+                                            block_size, sorted_max, ST(stream));
+}
+int ferrum_hip_moe_build_pairs_by_token(const int32_t* expert_ids, int32_t* pairs_by_token, int32_t* packed_token_idx,
+                                        int32_t* expert_offsets, int batch_x_topk, int num_experts, int top_k, void* stream) {
+    FH_REQUIRE(expert_offsets && (batch_x_topk == 0 || (expert_ids && pairs_by_token && packed_token_idx)), "moe_build_pairs_by_token: null buffer");
+    return moe_build_pairs_by_token(expert_ids, pairs_by_token, packed_token_idx, expert_offsets, batch_x_topk, num_experts, top_k,
+                                    ST(stream));
+}
+int ferrum_hip_moe_combine_pairs_f16(const void* packed_down, const int32_t* pairs_by_token, const float* pair_weights, void* out,
+                                     int batch, int hidden, int top_k, int total_pairs, void* stream) {
+    FH_REQUIRE(batch == 0 || (packed_down && pairs_by_token && pair_weights && out), "moe_combine: null buffer");
+    return moe_combine_pairs_f16(CH(packed_down), pairs_by_token, pair_weights, H(out), batch, hidden, top_k, total_pairs, ST(stream));
+}
+// weighted_sum_batched / weighted_sum_batched_offset (capabilities.rs:560-600): out[b, h] = Σ_k weights[b, k]·slots[b, k, h];
+// offsets in ELEMENTS into `weights` (start of [batch, top_k]) and `out` (start of [batch, hidden]).
+int ferrum_hip_weighted_sum_batched_f16(const void* slots, const float* weights, size_t weights_offset, void* out, size_t out_offset,
+                                        int batch, int top_k, int hidden, void* stream) {
+    FH_REQUIRE(batch == 0 || (slots && weights && out), "weighted_sum_batched: null buffer");
+    FH_REQUIRE(out_offset % 8 == 0, "weighted_sum_batched: out_offset=%zu must be a multiple of 8 elements", out_offset);
+    return moe_combine_f16(CH(slots), weights + weights_offset, H(out) + out_offset, batch, top_k, hidden, 0, ST(stream));
+}
+
+// MarlinExpertStack::gemm_phase_batched (marlin_expert_stack.rs:63-74): dispatches[i] = (expert, in_row_offset,
+// out_row_offset, m); rows [in_off, in_off + m) of `input` × tile[expert] → rows [out_off, out_off + m) of `output`.
+// One grouped launch per distinct (out_off − in_off): the dispatch list becomes the block-major routing arrays of the
+// grouped GEMM (16-row blocks, or 64-row LDS tiles when the experts see ≥ 32 rows on average).
+int ferrum_hip_moe_gemm_phase_batched_f16(FerrumHipGptq* stack, const void* input, const int32_t* dispatches, int num_dispatches,
+                                          void* output, int k, int fused_silu_mul, void* stream) {
+    FH_REQUIRE(stack && (num_dispatches == 0 || (input && dispatches && output)), "gemm_phase_batched: null argument");
+    FH_REQUIRE(k == stack->dev.k, "gemm_phase_batched: k=%d but the stack was packed with K=%d", k, stack->dev.k);
+    FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "gemm_phase_batched: fused epilogue needs a stack loaded with fuse_gate_up");
+    FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "gemm_phase_batched: stack was loaded with fuse_gate_up; plain output is column-permuted");
+    if (num_dispatches <= 0) return 0;
+    long rows = 0, max_row = 0;
+    for (int i = 0; i < num_dispatches; i++) {
+        const int32_t* d = dispatches + 4 * i;
+        FH_REQUIRE(d[0] >= 0 && d[0] < stack->dev.num_experts && d[1] >= 0 && d[2] >= 0 && d[3] >= 0,
+                   "gemm_phase_batched: dispatch %d = (%d, %d, %d, %d) out of range", i, d[0], d[1], d[2], d[3]);
+        rows += d[3];
+        max_row = std::max<long>(max_row, (long)d[1] + d[3]);
+    }
+    if (rows == 0) return 0;
+    const int br = rows >= 32L * num_dispatches ? 64 : 16;
+    // group by output displacement (normally one group: in_off == out_off, the packed-row convention)
+    std::vector<long> deltas;
+    for (int i = 0; i < num_dispatches; i++) {
+        const long dl = (long)dispatches[4 * i + 2] - dispatches[4 * i + 1];
+        if (dispatches[4 * i + 3] > 0 && std::find(deltas.begin(), deltas.end(), dl) == deltas.end()) deltas.push_back(dl);
+    }
+    const int ldo = fused_silu_mul ? stack->dev.n / 2 : stack->dev.n;
+    for (long dl : deltas) {
+        std::vector<int32_t> sorted, blocks;
+        for (int i = 0; i < num_dispatches; i++) {
+            const int32_t* d = dispatches + 4 * i;
+            if (d[3] == 0 || (long)d[2] - d[1] != dl) continue;
+            for (int r0 = 0; r0 < d[3]; r0 += br) {
+                blocks.push_back(d[0]);
+                for (int r = 0; r < br; r++) sorted.push_back(r0 + r < d[3] ? d[1] + r0 + r : (int32_t)max_row);   // sentinel = prob_m
+            }
+        }
+        const size_t nb = blocks.size(), need = sorted.size() + nb + 4;
+        FerrumHipGptq::DispatchSlot& sl = stack->slots[stack->next_slot];
+        stack->next_slot = (stack->next_slot + 1) % 4;
+        if (sl.done) FH_CHECK_HIP(hipEventSynchronize(sl.done));      // the launch that last used this slot has consumed it
+        else FH_CHECK_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        if (sl.cap < need) {
+            if (sl.host) (void)hipHostFree(sl.host);
+            if (sl.dev) (void)hipFree(sl.dev);
+            sl.host = nullptr; sl.dev = nullptr; sl.cap = 0;
+            FH_CHECK_HIP(hipHostMalloc((void**)&sl.host, need * 2 * 4, hipHostMallocDefault));
+            FH_CHECK_HIP(hipMalloc((void**)&sl.dev, need * 2 * 4));
+            sl.cap = need * 2;
+        }
+        memcpy(sl.host, sorted.data(), sorted.size() * 4);
+        memcpy(sl.host + sorted.size(), blocks.data(), nb * 4);
+        sl.host[sorted.size() + nb] = (int32_t)sorted.size();           // total_tokens_post_pad
+        FH_CHECK_HIP(hipMemcpyAsync(sl.dev, sl.host, need * 4, hipMemcpyHostToDevice, ST(stream)));
+        const int32_t* d_sorted = sl.dev;
+        const int32_t* d_blocks = sl.dev + sorted.size();
+        const int32_t* d_total = sl.dev + sorted.size() + nb;
+        __half* out_shift = H(output) + dl * ldo;                        // row (in_off + r) of the shifted view = out_off + r
+        int rc = br == 64 ? w4_gemm_moe_tile(stack->dev, CH(input), out_shift, d_sorted, d_blocks, d_total, (int)max_row, (int)nb, 64, 1,
+                                             fused_silu_mul, ST(stream))
+                          : w4_gemm_moe(stack->dev, CH(input), out_shift, d_sorted, d_blocks, d_total, (int)max_row, (int)nb, 1,
+                                        fused_silu_mul, ST(stream));
+        if (rc) return rc;
+        FH_CHECK_HIP(hipEventRecord(sl.done, ST(stream)));
+    }
+    return 0;
 }
 
 int ferrum_hip_fused_add_rms_norm_route_f16(void* residual, const void* x, const void* w, float eps, void* norm_out,
@@ -670,16 +849,24 @@ int ferrum_hip_block_allocator_allocate_n(FerrumHipBlockAllocator* a, uint32_t n
 }
 int ferrum_hip_block_allocator_free(FerrumHipBlockAllocator* a, const uint32_t* blocks, uint32_t n) {
     FH_REQUIRE(a && (n == 0 || blocks), "block_allocator_free: null argument");
+    // the reference indexes its ref-count vector (a bad id panics, paged_pool.rs:333-345): a bad id from the FFI side must
+    // fail here, before anything is freed, instead of writing outside the vectors
+    for (uint32_t i = 0; i < n; i++)
+        FH_REQUIRE(blocks[i] < a->impl.capacity(), "block_allocator_free: block %u >= capacity %u", blocks[i], a->impl.capacity());
     a->impl.free(blocks, n);
     return 0;
 }
 int ferrum_hip_block_allocator_acquire(FerrumHipBlockAllocator* a, uint32_t block) {
     FH_REQUIRE(a, "block_allocator_acquire: null");
+    FH_REQUIRE(block < a->impl.capacity(), "block_allocator_acquire: block %u >= capacity %u", block, a->impl.capacity());
+    // paged_pool.rs acquire: checked_add on the ref count (panics on overflow) — here: an error, the count is left alone
+    FH_REQUIRE(a->impl.ref_count(block) < 0xFFFFu, "block_allocator_acquire: ref count of block %u would overflow", block);
     a->impl.acquire(block);
     return 0;
 }
 int ferrum_hip_block_allocator_register_hash(FerrumHipBlockAllocator* a, uint32_t block, uint64_t hash) {
     FH_REQUIRE(a, "block_allocator_register_hash: null");
+    FH_REQUIRE(block < a->impl.capacity(), "block_allocator_register_hash: block %u >= capacity %u", block, a->impl.capacity());
     a->impl.register_block_hash(block, hash);
     return 0;
 }
@@ -689,7 +876,7 @@ int ferrum_hip_block_allocator_try_acquire_by_hash(FerrumHipBlockAllocator* a, u
     return 0;
 }
 uint32_t ferrum_hip_block_allocator_free_count(const FerrumHipBlockAllocator* a) { return a->impl.free_count(); }
-uint32_t ferrum_hip_block_allocator_ref_count(const FerrumHipBlockAllocator* a, uint32_t b) { return a->impl.ref_count(b); }
+uint32_t ferrum_hip_block_allocator_ref_count(const FerrumHipBlockAllocator* a, uint32_t b) { return b < a->impl.capacity() ? a->impl.ref_count(b) : 0; }
 uint32_t ferrum_hip_block_allocator_peak_in_use(const FerrumHipBlockAllocator* a) { return a->impl.peak_in_use(); }
 uint32_t ferrum_hip_block_allocator_hash_table_size(const FerrumHipBlockAllocator* a) { return a->impl.hash_table_size(); }
 

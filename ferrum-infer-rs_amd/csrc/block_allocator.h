@@ -131,6 +131,7 @@ public:
             ref_counts_[block] = 1;
             track_peak();
         } else {
+            if (ref_counts_[block] == 0xFFFF) return -1;   // would overflow the u16 count: treated as a miss
             ref_counts_[block]++;
         }
         return (int64_t)block;

@@ -28,6 +28,8 @@ struct W4Device {
     int32_t* perm = nullptr;     // device act-order permutation or null
     __half* bias = nullptr;      // optional [n]
     bool fused_gate_up = false;  // columns permuted for the fused silu·mul epilogue
+    __half* f16t = nullptr;      // UNQUANTISED projection (DenseLinear, linear.rs:109-129): fp16 weights [n, k] in f16t tiles;
+                                 // qw / sc are then null and w4_gemm_dense routes to the fp16 GEMM
 };
 
 int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* qzeros,
@@ -145,6 +147,13 @@ int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* 
 int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
                          int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
                          int sorted_max, hipStream_t s);
+int moe_align_block_size_packed_rows(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
+                                     int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
+                                     int sorted_max, hipStream_t s);
+int moe_build_pairs_by_token(const int32_t* expert_ids, int32_t* pairs_by_token, int32_t* packed_token_idx,
+                             int32_t* expert_offsets, int batch_x_topk, int num_experts, int top_k, hipStream_t s);
+int moe_combine_pairs_f16(const __half* packed_down, const int32_t* pairs_by_token, const float* pair_weights, __half* out,
+                          int batch, int hidden, int top_k, int total_pairs, hipStream_t s);
 int moe_combine_f16(const __half* down, const float* weights, __half* out, int tokens, int top_k, int hidden,
                     int accumulate_into_residual, hipStream_t s);
 

@@ -281,7 +281,14 @@ static int open_shard(FerrumHipCheckpoint* ck, const std::string& path) {
         const std::string& d = dt->str;
         ti.dtype = d == "F32" ? StDtype::F32 : d == "F16" ? StDtype::F16 : d == "BF16" ? StDtype::BF16 : d == "I32" ? StDtype::I32
                  : d == "I64" ? StDtype::I64 : StDtype::Other;
-        for (const Value& s : shp->arr) ti.shape.push_back((int64_t)s.num);
+        // JSON numbers are doubles: only finite, non-negative integers below 2^53 are offsets / extents
+        auto exact = [](const Value& v) { return v.kind == Value::Num && v.num >= 0.0 && v.num < 9007199254740992.0 && v.num == (double)(uint64_t)v.num; };
+        for (const Value& s : shp->arr) {
+            FH_REQUIRE(exact(s), "checkpoint: %s: '%s' has a non-integer / negative shape entry", path.c_str(), kv.first.c_str());
+            ti.shape.push_back((int64_t)s.num);
+        }
+        FH_REQUIRE(exact(off->arr[0]) && exact(off->arr[1]), "checkpoint: %s: '%s' data_offsets are not non-negative integers", path.c_str(),
+                   kv.first.c_str());
         ti.begin = (size_t)off->arr[0].num;
         ti.end = (size_t)off->arr[1].num;
         FH_REQUIRE(ti.begin <= ti.end && sh->data_off + ti.end <= sh->size, "checkpoint: %s: '%s' outside the file", path.c_str(),

@@ -96,18 +96,28 @@ int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* 
     return 0;
 }
 
-// One workgroup per expert: histogram of every pair (LDS atomics, order-free) → padded prefix →
-// ordered compaction of this expert's pair ids (ballot prefix keeps ascending pair id).
+// One workgroup per expert: histogram of every pair (LDS atomics, order-free) → prefixes →
+// ordered compaction of this expert's pair ids (ballot prefix keeps ascending pair id).  Three outputs share the walk:
+//   MODE 0  moe_align_block_size_pair_ids (capabilities.rs:449): sorted_token_ids holds pair ids p = token·top_k + slot
+//   MODE 1  moe_align_block_size (capabilities.rs:429, kernels/moe_align_block_size.cu:1-30): sorted_token_ids holds the
+//           UNPADDED packed row of each slot (expert e's region = unpadded_offset[e] + 0, 1, …) — no compaction needed
+//   MODE 2  moe_build_pairs_by_token (capabilities.rs:410, kernels/moe_build_pairs.cu): pairs_by_token[p] = packed row of
+//           pair p, packed_token_idx[row] = p / top_k, expert_offsets[E + 1] — the stable counting sort of
+//           MoeBucketPlan::rebuild_into (moe/dispatch.rs:1408-1461); ids outside [0, E) get pairs_by_token = −1
 constexpr int MAX_EXPERTS = 512;
 constexpr int ALIGN_THREADS = 1024;
+template <int MODE>
 __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t* __restrict__ expert_ids,
                                                                   int32_t* __restrict__ sorted_token_ids,
                                                                   int32_t* __restrict__ block_ids,
                                                                   int32_t* __restrict__ total_post_pad, int n_pairs,
-                                                                  int num_experts, int block_size, int sorted_max) {
+                                                                  int num_experts, int block_size, int sorted_max,
+                                                                  int32_t* __restrict__ pairs_by_token,
+                                                                  int32_t* __restrict__ packed_token_idx,
+                                                                  int32_t* __restrict__ expert_offsets, int top_k) {
     __shared__ int counts[MAX_EXPERTS];
     __shared__ int wave_cnt[ALIGN_THREADS / 64];
-    __shared__ int s_offset, s_total;
+    __shared__ int s_offset, s_total, s_unpadded;
     constexpr int NT = ALIGN_THREADS, NWV = ALIGN_THREADS / 64;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < num_experts; i += NT) counts[i] = 0;
@@ -115,26 +125,37 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t*
     for (int p = tid; p < n_pairs; p += NT) {
         int x = expert_ids[p];
         if (x >= 0 && x < num_experts) atomicAdd(&counts[x], 1);
+        else if (MODE == 2 && e == 0) pairs_by_token[p] = -1;
     }
     __syncthreads();
     if (tid == 0) {
-        int acc = 0, mine = 0;
+        int acc = 0, mine = 0, uacc = 0, umine = 0;
         for (int i = 0; i < num_experts; i++) {
-            if (i == e) mine = acc;
+            if (i == e) { mine = acc; umine = uacc; }
+            if (MODE == 2 && e == 0) expert_offsets[i] = uacc;
             acc += ((counts[i] + block_size - 1) / block_size) * block_size;
+            uacc += counts[i];
         }
         s_offset = mine;
         s_total = acc;
-        if (e == 0) total_post_pad[0] = acc;
+        s_unpadded = umine;
+        if (MODE != 2 && e == 0) total_post_pad[0] = acc;
+        if (MODE == 2 && e == 0) expert_offsets[num_experts] = uacc;
     }
     __syncthreads();
-    const int offset = s_offset, total = s_total;
+    const int offset = MODE == 2 ? s_unpadded : s_offset, total = s_total;
     const int cnt = counts[e];
-    const int padded = ((cnt + block_size - 1) / block_size) * block_size;
-    // sentinel for the padding tail of this expert and (striped) the unused end of the array
-    for (int i = cnt + tid; i < padded; i += NT) sorted_token_ids[offset + i] = n_pairs;
-    for (int i = total + e * NT + tid; i < sorted_max; i += NT * gridDim.x) sorted_token_ids[i] = n_pairs;
-    for (int b = tid; b < padded / block_size; b += NT) block_ids[offset / block_size + b] = e;
+    if (MODE != 2) {
+        const int padded = ((cnt + block_size - 1) / block_size) * block_size;
+        // sentinel for the padding tail of this expert and (striped) the unused end of the array
+        for (int i = cnt + tid; i < padded; i += NT) sorted_token_ids[offset + i] = n_pairs;
+        for (int i = total + e * NT + tid; i < sorted_max; i += NT * gridDim.x) sorted_token_ids[i] = n_pairs;
+        for (int b = tid; b < padded / block_size; b += NT) block_ids[offset / block_size + b] = e;
+    }
+    if (MODE == 1) {
+        for (int i = tid; i < cnt; i += NT) sorted_token_ids[offset + i] = s_unpadded + i;
+        return;
+    }
     // ordered compaction, 4 consecutive pairs per thread and 4096 per trip (ascending pair id is kept: thread order,
     // then element order); a prefill batch has tens of thousands of pairs, so barrier trips matter
     int base = 0;
@@ -165,7 +186,15 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t*
         int pos = offset + base + before + incl - c;
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (mine[j]) sorted_token_ids[pos++] = p + j;
+            if (mine[j]) {
+                if (MODE == 2) {
+                    pairs_by_token[p + j] = pos;
+                    packed_token_idx[pos] = (p + j) / top_k;
+                    pos++;
+                } else {
+                    sorted_token_ids[pos++] = p + j;
+                }
+            }
         base += chunk_total;
         __syncthreads();
     }
@@ -177,8 +206,63 @@ int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, i
     FH_REQUIRE(num_experts > 0 && num_experts <= MAX_EXPERTS, "moe align: num_experts=%d must be in [1,%d]", num_experts, MAX_EXPERTS);
     FH_REQUIRE(block_size > 0, "moe align: block_size=%d", block_size);
     FH_REQUIRE(sorted_max >= batch_x_topk, "moe align: sorted_max=%d < pairs=%d", sorted_max, batch_x_topk);
-    hipLaunchKernelGGL(moe_align_kernel, dim3(num_experts), dim3(ALIGN_THREADS), 0, s, expert_ids, sorted_token_ids, block_ids,
-                       total_post_pad, batch_x_topk, num_experts, block_size, sorted_max);
+    hipLaunchKernelGGL(moe_align_kernel<0>, dim3(num_experts), dim3(ALIGN_THREADS), 0, s, expert_ids, sorted_token_ids, block_ids,
+                       total_post_pad, batch_x_topk, num_experts, block_size, sorted_max, nullptr, nullptr, nullptr, 1);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+int moe_align_block_size_packed_rows(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,
+                                     int32_t* total_post_pad, int batch_x_topk, int num_experts, int block_size,
+                                     int sorted_max, hipStream_t s) {
+    FH_REQUIRE(num_experts > 0 && num_experts <= MAX_EXPERTS, "moe align: num_experts=%d must be in [1,%d]", num_experts, MAX_EXPERTS);
+    FH_REQUIRE(block_size > 0, "moe align: block_size=%d", block_size);
+    FH_REQUIRE(sorted_max >= batch_x_topk, "moe align: sorted_max=%d < pairs=%d", sorted_max, batch_x_topk);
+    hipLaunchKernelGGL(moe_align_kernel<1>, dim3(num_experts), dim3(ALIGN_THREADS), 0, s, expert_ids, sorted_token_ids, block_ids,
+                       total_post_pad, batch_x_topk, num_experts, block_size, sorted_max, nullptr, nullptr, nullptr, 1);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+int moe_build_pairs_by_token(const int32_t* expert_ids, int32_t* pairs_by_token, int32_t* packed_token_idx,
+                             int32_t* expert_offsets, int batch_x_topk, int num_experts, int top_k, hipStream_t s) {
+    FH_REQUIRE(num_experts > 0 && num_experts <= MAX_EXPERTS, "moe build pairs: num_experts=%d must be in [1,%d]", num_experts, MAX_EXPERTS);
+    FH_REQUIRE(top_k > 0 && batch_x_topk >= 0, "moe build pairs: top_k=%d pairs=%d", top_k, batch_x_topk);
+    hipLaunchKernelGGL(moe_align_kernel<2>, dim3(num_experts), dim3(ALIGN_THREADS), 0, s, expert_ids, nullptr, nullptr, nullptr,
+                       batch_x_topk, num_experts, 1, 0, pairs_by_token, packed_token_idx, expert_offsets, top_k);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// moe_combine with the trait's own signature (capabilities.rs:684-724; kernels/moe_combine.cu:29): rows of the
+// expert-bucketed `packed_down` are found through pairs_by_token (−1 = skipped slot); k ascending, fp32 accumulate.
+__global__ void moe_combine_pairs_kernel(const __half* __restrict__ packed_down, const int32_t* __restrict__ pairs_by_token,
+                                         const float* __restrict__ weights, __half* __restrict__ out, int top_k, int hidden,
+                                         int total_pairs) {
+    const long b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (hidden >> 3)) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < top_k; k++) {
+        const int row = pairs_by_token[b * top_k + k];
+        if (row < 0 || row >= total_pairs) continue;
+        const float w = weights[b * top_k + k];
+        const half8 d = *reinterpret_cast<const half8*>(packed_down + (long)row * hidden + i * 8);
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] += w * (float)d[j];
+    }
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (_Float16)acc[j];
+    *reinterpret_cast<half8*>(out + b * hidden + i * 8) = o;
+}
+
+int moe_combine_pairs_f16(const __half* packed_down, const int32_t* pairs_by_token, const float* pair_weights, __half* out,
+                          int batch, int hidden, int top_k, int total_pairs, hipStream_t s) {
+    if (batch <= 0) return 0;
+    FH_REQUIRE(hidden % 8 == 0 && top_k > 0, "moe combine: hidden=%d must be a multiple of 8, top_k=%d", hidden, top_k);
+    hipLaunchKernelGGL(moe_combine_pairs_kernel, dim3(cdiv(hidden / 8, 256), batch), dim3(256), 0, s, packed_down, pairs_by_token,
+                       pair_weights, out, top_k, hidden, total_pairs);
     FH_CHECK_LAUNCH();
     return 0;
 }

@@ -48,6 +48,7 @@ void free_w4(W4Device& w) {
     if (w.zp) (void)hipFree(w.zp);
     if (w.perm) (void)hipFree(w.perm);
     if (w.bias) (void)hipFree(w.bias);
+    if (w.f16t) (void)hipFree(w.f16t);
     w = W4Device();
 }
 
@@ -401,6 +402,36 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int exper
     return 0;
 }
 
+// Unquantised projection (DenseLinear, ferrum-kernels/src/linear.rs:109-129): W [n, k] row-major f32 on the host → fp16
+// f16t tiles on the device; the forward then runs it through the fp16 GEMM (B::gemm).  which: 0 qkv, 1 o, 2 gate_up, 3 down.
+int ferrum_hip_model_set_dense_f32(FerrumHipModel* m, int layer, int which, const float* weight, int k, int n) {
+    FH_REQUIRE(m && weight && !m->finalized && layer >= 0 && layer < m->cfg.num_layers, "model_set_dense: bad argument");
+    const FerrumHipModelConfig& c = m->cfg;
+    LayerWeights& L = m->layers[layer];
+    const int H = c.hidden;
+    int rc = 0;
+    W4Device* dst = nullptr;
+    switch (which) {
+    case 0: rc = check_shape("qkv", k, n, H, qkv_dim(c)); dst = &L.qkv; break;
+    case 1: rc = check_shape("o", k, n, q_dim(c), H); dst = &L.o; break;
+    case 2: rc = check_shape("gate_up", k, n, H, 2 * c.intermediate); dst = &L.gate_up; break;
+    case 3: rc = check_shape("down", k, n, c.intermediate, H); dst = &L.down; break;
+    default: fh::set_error("model_set_dense: which=%d", which); return FERRUM_HIP_INVALID;
+    }
+    if (rc) return rc;
+    FH_REQUIRE(k % 32 == 0, "model_set_dense: K=%d must be a multiple of 32", k);
+    free_w4(*dst);
+    dst->k = k; dst->n = n; dst->n64 = (n + 63) / 64; dst->G = k / 128; dst->num_experts = 1;
+    __half* row = nullptr;
+    if (int r = upload_f32_as_f16(weight, (size_t)n * k, &row)) return r;
+    hipError_t e = hipMalloc((void**)&dst->f16t, f16t_elems(n, k) * 2);
+    if (e != hipSuccess) { (void)hipFree(row); fh::set_error("model_set_dense: hipMalloc: %s", hipGetErrorString(e)); return 1; }
+    rc = f16t_repack(row, dst->f16t, n, k, m->stream);
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipFree(row);
+    return rc;
+}
+
 static void launch1d(void (*k)(__half*, long, uint64_t, float, float), __half* p, long n, uint64_t seed, float a, float b, hipStream_t s) {
     hipLaunchKernelGGL(k, dim3(cdiv(n, 256)), dim3(256), 0, s, p, n, seed, a, b);
 }
@@ -480,7 +511,8 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     FH_REQUIRE(m->embed && m->final_norm, "model_finalize: embed / final_norm missing");
     for (int li = 0; li < c.num_layers; li++) {
         const LayerWeights& L = m->layers[li];
-        FH_REQUIRE(L.input_ln && L.post_ln && L.qkv.qw && L.o.qw, "model_finalize: layer %d attention weights missing", li);
+        auto have = [](const W4Device& w) { return w.qw != nullptr || w.f16t != nullptr; };
+        FH_REQUIRE(L.input_ln && L.post_ln && have(L.qkv) && have(L.o), "model_finalize: layer %d attention weights missing", li);
         FH_REQUIRE(!c.has_qk_norm || (L.q_norm && L.k_norm), "model_finalize: layer %d q/k norm missing", li);
         FH_REQUIRE(!c.sandwich_norms || (L.post_attn_ln && L.post_ffn_ln), "model_finalize: layer %d sandwich norms missing", li);
         if (m->layers[li].qkv_bias) {    // the GEMM epilogue / split-K reduce adds it (W4Device::bias owns it from here)
@@ -492,7 +524,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
             for (int e = 0; e < c.num_experts; e++)
                 FH_REQUIRE(L.exp_loaded[e] == 3, "model_finalize: layer %d expert %d incomplete", li, e);
         } else {
-            FH_REQUIRE(L.gate_up.qw && L.down.qw, "model_finalize: layer %d MLP weights missing", li);
+            FH_REQUIRE(have(L.gate_up) && have(L.down), "model_finalize: layer %d MLP weights missing", li);
         }
     }
     const size_t T = c.max_tokens, S = c.max_seqs, H = c.hidden;
@@ -947,11 +979,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
             const bool tp = c.tp_world > 1;   // attention heads sharded, o_proj row-parallel: all-reduce before the add + norm + route kernel
             const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && Q >= 1 && tiles / Q <= 8 && !L.o.perm;
+            const bool o_quant = L.o.qw != nullptr;           // the slab forms are INT4 kernels; an unquantised o_proj takes the direct GEMM
             if (decode_fast) {
                 // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
                 const float* slabs = nullptr;
                 int S = m->o_slabs, rows_pad = 0, n_pad = 0;
-                if (tp) {
+                if (tp || !o_quant) {
                     RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
                     RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                     S = 0;
@@ -987,7 +1020,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
                                                      m->norm_out, T, K, H, s));
                 }
-            } else if (T >= 64 && T < m->route_gemm_min_tokens && !tp && !L.o.perm && !L.o.bias && m->o_slabs > 0) {
+            } else if (T >= 64 && T < m->route_gemm_min_tokens && !tp && o_quant && !L.o.perm && !L.o.bias && m->o_slabs > 0) {
                 // short prefill / a prompt riding along with the decode batch: o_proj as fp32 split-K slabs straight into the
                 // add + norm + route kernel (no reduce launch)
                 int S = 1, rows_pad = 0, n_pad = 0;
@@ -1025,7 +1058,8 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             // projections produce fp16 partials (GEMM + reduce), all-reduce, then add + norm; the column-parallel gate_up keeps
             // its slabs → gated-activation form.  Everything stays stream-ordered device work, so the step is still one graph.
             const bool tp = c.tp_world > 1;
-            const bool slab_chain = m->dense_slabs && T > 16 && T <= 32 && !L.o.perm && !L.gate_up.perm && !L.down.perm;
+            const bool slab_chain = m->dense_slabs && T > 16 && T <= 32 && !L.o.perm && !L.gate_up.perm && !L.down.perm &&
+                                    L.o.qw && L.gate_up.qw && L.down.qw;   // INT4 slab kernels; unquantised projections take the op chain
             int S = 0, rows_pad = 0, n_pad = 0;
             if (slab_chain) {
                 form_hit(FORM_DENSE_SLAB_CHAIN);

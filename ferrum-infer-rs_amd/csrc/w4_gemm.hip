@@ -1546,6 +1546,11 @@ static int launch_w4_slabs(const W4Args& a, int mt, bool has_zp, dim3 grid, hipS
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream) {
     if (m <= 0) return 0;
+    if (w.f16t) {                                     // DenseLinear: B::gemm on fp16 weights (linear.rs:109-129)
+        form_hit(FORM_F16_DENSE_LINEAR);
+        if (int rc = f16t_gemm(x, w.f16t, out, m, w.n, w.k, workspace, workspace_bytes, stream)) return rc;
+        return w.bias ? add_bias_f16(out, w.bias, m, w.n, stream) : 0;
+    }
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp; a.bias = w.bias;
     a.x = x; a.out = out; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n; a.S = 1;

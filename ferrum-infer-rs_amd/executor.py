@@ -255,6 +255,12 @@ class HipModel:
                                                   sc.ctypes.data_as(C.POINTER(C.c_float)), qz.ctypes.data_as(p),
                                                   None if gi is None else gi.ctypes.data_as(p), k, n), f"set_gptq({name})")
 
+    def set_dense(self, layer, name, weight, k, n):
+        """Unquantised projection (DenseLinear): weight [n, k] f32; name in qkv / o / gate_up / down."""
+        w = _f32(np.asarray(weight).reshape(n, k))
+        _check(self.lib.ferrum_hip_model_set_dense_f32(self.h, layer, GPTQ[name], w.ctypes.data_as(C.POINTER(C.c_float)), k, n),
+               f"set_dense({name})")
+
     def init_synthetic(self, seed):
         _check(self.lib.ferrum_hip_model_init_synthetic(self.h, C.c_uint64(seed)), "init_synthetic")
 

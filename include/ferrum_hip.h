@@ -206,6 +206,12 @@ int ferrum_hip_paged_batched_decode_attention_f16(const void* q, const void* k_p
                                                   int num_seqs, int max_kv_len, int num_heads, int num_kv_heads,
                                                   int head_dim, int block_size, int max_num_blocks_per_seq,
                                                   FerrumHipWorkspace* ws, void* stream);
+/* BackendPagedKv::paged_decode_attention (traits.rs:1719): q_len == 1 → one token per sequence, q/out [num_seqs, nq, hd];
+ * q_len > 1 → ONE sequence in causal prefill, q/out head-major [nq, q_len, hd], context_lens[0] = final kv length. */
+int ferrum_hip_paged_decode_attention_f16(const void* q, const void* k_pool, const void* v_pool, void* out,
+                                          const int32_t* block_tables, const uint32_t* context_lens, int num_seqs,
+                                          int num_heads, int num_kv_heads, int head_dim, int block_size,
+                                          int max_num_blocks_per_seq, int q_len, FerrumHipWorkspace* ws, void* stream);
 /* Decode step of one layer in ONE launch: split_qkv_norm_rope_into_paged_cache_varlen with one token per sequence
  * at position valid_kv_lens[s] − 1, then paged_batched_decode_attention.  Bit-identical to the two-op chain
  * (same float operations per row); q is never materialised.  GQA group ≤ 14.  sliding_window > 0 restricts every
@@ -238,6 +244,27 @@ int ferrum_hip_moe_align_block_size(const int32_t* expert_ids_per_pair, int32_t*
 /* out[b] = Σ_k weights[b,k]·down[b·top_k+k]; accumulate != 0 adds into out (fused residual add). */
 int ferrum_hip_moe_combine_f16(const void* down, const float* weights, void* out, int tokens, int top_k,
                                int hidden, int accumulate, void* stream);
+/* BackendMoeFused::moe_align_block_size (capabilities.rs:429; kernels/moe_align_block_size.cu): the variant whose
+ * sorted_token_ids hold UNPADDED PACKED ROWS (expert e's region = expert_offsets[e] + 0, 1, …; padding = batch_x_topk). */
+int ferrum_hip_moe_align_block_size_packed_rows(const int32_t* expert_ids_per_pair, int32_t* sorted_token_ids, int32_t* block_ids,
+                                                int32_t* total_tokens_post_pad, int batch_x_topk, int num_experts, int block_size,
+                                                int sorted_max_size, void* stream);
+/* BackendMoeFused::moe_build_pairs_by_token (capabilities.rs:410; kernels/moe_build_pairs.cu): stable counting sort of the
+ * (token, slot) pairs by expert = MoeBucketPlan::rebuild_into (moe/dispatch.rs:1408-1461), bit for bit: pairs_by_token[p] =
+ * packed row of pair p (−1 for ids outside [0, E)), packed_token_idx[row] = p / top_k, expert_offsets[E + 1]. */
+int ferrum_hip_moe_build_pairs_by_token(const int32_t* expert_ids, int32_t* pairs_by_token, int32_t* packed_token_idx,
+                                        int32_t* expert_offsets, int batch_x_topk, int num_experts, int top_k, void* stream);
+/* BackendMoeFused::moe_combine with the trait's own arguments (capabilities.rs:684): rows of the expert-bucketed packed_down
+ * are found through pairs_by_token (−1 = skipped). */
+int ferrum_hip_moe_combine_pairs_f16(const void* packed_down, const int32_t* pairs_by_token, const float* pair_weights, void* out,
+                                     int batch, int hidden, int top_k, int total_pairs, void* stream);
+/* BackendMoeFused::weighted_sum_batched / weighted_sum_batched_offset (capabilities.rs:560,580): offsets in elements. */
+int ferrum_hip_weighted_sum_batched_f16(const void* slots, const float* weights, size_t weights_offset, void* out,
+                                        size_t out_offset, int batch, int top_k, int hidden, void* stream);
+/* MarlinExpertStack::gemm_phase_batched (marlin_expert_stack.rs:63): dispatches = num_dispatches × (expert, in_row_offset,
+ * out_row_offset, m) int32 on the HOST (like the reference's slice); one grouped launch. */
+int ferrum_hip_moe_gemm_phase_batched_f16(FerrumHipGptq* stack, const void* input, const int32_t* dispatches, int num_dispatches,
+                                          void* output, int k, int fused_silu_mul, void* stream);
 
 /* Fused forms of op chains the reference issues back to back (qwen3_moe_forward_unified_layer.rs:380-451);
  * same per-element arithmetic as the unfused entry points, one launch each:
@@ -409,6 +436,9 @@ int ferrum_hip_model_set_global_f32(FerrumHipModel* model, int which, const floa
 int ferrum_hip_model_set_layer_dense_f32(FerrumHipModel* model, int layer, int which, const float* data);
 int ferrum_hip_model_set_gptq(FerrumHipModel* model, int layer, int which, int expert, const int32_t* qweight,
                               const float* scales, const int32_t* qzeros, const int32_t* g_idx, int k, int n);
+/* Unquantised projection (DenseLinear next to GptqLinear, ferrum-kernels/src/linear.rs:109-129): weight [n, k] row-major
+ * f32 on the host, kept as fp16 on the device; which = 0 qkv, 1 o, 2 gate_up, 3 down (dense-MLP models). */
+int ferrum_hip_model_set_dense_f32(FerrumHipModel* model, int layer, int which, const float* weight, int k, int n);
 /* Deterministic synthetic weights generated on the device (bench: no checkpoints offline). */
 int ferrum_hip_model_init_synthetic(FerrumHipModel* model, uint64_t seed);
 int ferrum_hip_model_finalize(FerrumHipModel* model);
@@ -545,6 +575,14 @@ int ferrum_hip_model_tp_attach_loopback(FerrumHipModel* model, FerrumHipTpLoopba
  * hipGraph: checks the dlopen'ed entry points, enum values, by-value ncclUniqueId passing and stream capture of the
  * tensor-parallel path without needing a second GPU. */
 int ferrum_hip_tp_selftest(int count);
+
+/* ── BackendGraph (capabilities.rs:35-70): stream capture / replay of whatever the caller enqueues between begin and end.
+ * No entry point allocates inside a capture window as long as workspaces and handles were created before it. ── */
+typedef struct FerrumHipGraph FerrumHipGraph;
+int ferrum_hip_graph_begin_capture(void* stream);
+int ferrum_hip_graph_end_capture(void* stream, FerrumHipGraph** graph);
+int ferrum_hip_graph_replay(FerrumHipGraph* graph, void* stream);
+int ferrum_hip_graph_destroy(FerrumHipGraph* graph);
 
 /* ── Debug / test support: which kernel forms the launchers chose, and re-reading the FERRUM_HIP_* development knobs
  * (they are read once at library load; no launch path calls getenv). ── */

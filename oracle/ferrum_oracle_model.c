@@ -210,6 +210,17 @@ FO_API int fo_model_set_gptq(fo_model *m, int layer, int which, int expert,
     return fo_dequant_gptq(qweight, scales, qzeros, g_idx, 4, group, k, n, *slot + off);
 }
 
+/* Unquantised projection (DenseLinear, ferrum-kernels/src/linear.rs:109-129; weights upcast to f32 on the CPU backend):
+ * which 0 qkv, 1 o, 2 gate_up, 3 down; weight [n, k] row-major — the layout fo_gemm's b operand takes. */
+FO_API int fo_model_set_dense(fo_model *m, int layer, int which, const float *weight, int k, int n) {
+    fo_layer *L = &m->layers[layer];
+    float **slot = which == 0 ? &L->qkv_w : which == 1 ? &L->o_w : which == 2 ? &L->gate_up_w : which == 3 ? &L->down_w : NULL;
+    if (!slot) return -1;
+    free(*slot);
+    *slot = fo_dup(weight, (long)n * k);
+    return 0;
+}
+
 static fo_kv *fo_get_cache(fo_model *m, int cache_id) {
     fo_kv *c = &m->caches[cache_id];
     if (!c->used) {

@@ -108,6 +108,7 @@ def _declare(l):
     l.fo_model_free.argtypes = [C.c_void_p]
     l.fo_model_set_global.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     l.fo_model_set_layer_dense.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    l.fo_model_set_dense.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), C.c_int, C.c_int]
     l.fo_model_set_gptq.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32),
                                     C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.c_int, C.c_int, C.c_int]
@@ -526,6 +527,14 @@ class OracleModel:
         rc = lib().fo_model_set_gptq(self._h, layer, self.GPTQ[name], expert, _i(qw), _f(sc), _i(qz), gp,
                                      group, k, n)
         assert rc == 0
+
+    def set_dense(self, layer, name, weight, k, n):
+        """Unquantised projection: weight [n, k] f32 (DenseLinear)."""
+        which = {"qkv": 0, "o": 1, "gate_up": 2, "down": 3}[name]
+        w = np.ascontiguousarray(weight, np.float32).reshape(n, k)
+        rc = lib().fo_model_set_dense(self._h, layer, which, _f(w), k, n)
+        if rc != 0:
+            raise RuntimeError(f"fo_model_set_dense({name}) failed: {rc}")
 
     def forward(self, cache_id, tokens, pos_offset, all_logits=False):
         toks = np.ascontiguousarray(tokens, np.uint32)

@@ -29,7 +29,7 @@ class TinyModel:
                  expert_inter=128, qk_norm=True, seed=0, max_seq_len=256, activation=0, sliding_window=0,
                  rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False, sandwich=False,
                  sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False,
-                 qkv_bias=False):
+                 qkv_bias=False, dense_proj=False):
         self.cfg = dict(num_layers=layers, hidden=hidden, num_heads=nq, num_kv_heads=nkv, head_dim=hd,
                         intermediate=0 if moe else inter, vocab=vocab, max_seq_len=max_seq_len, has_qk_norm=int(qk_norm),
                         activation=activation, num_experts=experts if moe else 0, top_k=top_k if moe else 0,
@@ -60,6 +60,14 @@ class TinyModel:
             s0 = 1000 * (li + 1) + seed * 77
             sym = not asym_act_order
             L["g_idx"] = {}
+            L["densew"] = {}
+            if dense_proj:
+                # unquantised checkpoint (DenseLinear, e.g. BASELINE configs[0] Qwen3-0.6B bf16): fp16-representable [n, k] weights
+                assert not moe
+                for name, k_, n_, gain in (("qkv", H, qd + 2 * kvd, 1.0), ("o", qd, H, 0.3), ("gate_up", H, 2 * inter, 1.0), ("down", inter, H, 0.3)):
+                    L["densew"][name] = (k_, n_, f16r(rng.standard_normal((n_, k_)) * (gain / np.sqrt(k_))))
+                self.layers.append(L)
+                continue
             L["gptq"]["qkv"] = (H, qd + 2 * kvd) + synth_gptq(H, qd + 2 * kvd, s0 + 1, symmetric=sym)
             L["gptq"]["o"] = (qd, H) + synth_gptq(qd, H, s0 + 2, symmetric=sym, gain=0.3)
             if moe:
@@ -82,6 +90,8 @@ class TinyModel:
         for li, L in enumerate(self.layers):
             for name, data in L["dense"].items():
                 model.set_layer_dense(li, name, data)
+            for name, (k, n, w) in L.get("densew", {}).items():
+                model.set_dense(li, name, w, k, n)
             for name, (k, n, qw, sc, qz) in L["gptq"].items():
                 gi = L.get("g_idx", {}).get(name)
                 if is_oracle:

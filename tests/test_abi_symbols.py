@@ -56,6 +56,29 @@ def test_product_does_not_link_the_oracle(pkg):
                 assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("no CPU fallback", ""), f
 
 
+def test_block_allocator_rejects_out_of_range_ids_and_ref_count_overflow(pkg):
+    """The reference indexes its vectors and uses checked_add (a bad id or a wrapped count panics, paged_pool.rs:333-365);
+    over the C ABI the same mistakes must come back as errors and leave the allocator untouched."""
+    from ferrum_infer_rs_amd.backend import BlockAllocator
+    a = BlockAllocator(4)
+    b0 = a.allocate()
+    for bad in (4, 5, 2 ** 31):
+        with pytest.raises(RuntimeError):
+            a.free([b0, bad])                                    # nothing of the call is applied
+        with pytest.raises(RuntimeError):
+            a.acquire(bad)
+        with pytest.raises(RuntimeError):
+            a.register_block_hash(bad, 7)
+        assert a.ref_count(bad) == 0
+    assert a.ref_count(b0) == 1 and a.free_count() == 3
+    for _ in range(0xFFFF - 1):
+        a.acquire(b0)
+    assert a.ref_count(b0) == 0xFFFF
+    with pytest.raises(RuntimeError):
+        a.acquire(b0)                                            # u16 count would wrap
+    assert a.ref_count(b0) == 0xFFFF
+
+
 def test_block_allocator_matches_reference_sequences(pkg, oracle):
     # paged_pool.rs:465-481 + randomised differential test against the oracle restatement
     from ferrum_infer_rs_amd.backend import BlockAllocator

@@ -99,6 +99,48 @@ def test_qkv_bias_model(pkg, prompt_len):
     _assert_parity(res)
 
 
+@pytest.mark.parametrize("prompt_len", [11, 23, 70])
+def test_unquantised_dense_linear_model(pkg, prompt_len, forms):
+    """DenseLinear next to GptqLinear (ferrum-kernels/src/linear.rs:109-129): every projection of the layer unquantised fp16
+    (a bf16 / fp16 checkpoint such as BASELINE configs[0]) through the ≤16-row, 17–32-row and ≥64-row regimes of the fp16 GEMM;
+    prefill + decode against the oracle."""
+    from tests import modelgen
+    res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=prompt_len, decode_steps=3, seed=151 + prompt_len,
+                                   dense_proj=True, tied=True)
+    forms.require("f16_dense_linear", absent=("w4_wgsplit", "w4_ldsa", "w4_tilep", "dense_slab_chain"))
+    _assert_parity(res)
+
+
+def test_qwen3_06b_dims_unquantised_layer(pkg, forms):
+    """BASELINE configs[0] (Qwen3-0.6B: H 1024, 16/8 heads × 128, I 3072, QK-norm, θ 1e6, tied lm_head, unquantised weights) —
+    one layer at its real dimensions (vocabulary cut to 2048), 24 sequences: 40-token prompts in one forward, then three
+    decode steps; five sequences followed by the oracle."""
+    from tests import modelgen
+    from oracle import oracle as O
+    tm = modelgen.TinyModel(False, layers=1, hidden=1024, nq=16, nkv=8, hd=128, inter=3072, vocab=2048, seed=161, max_seq_len=64,
+                            dense_proj=True, tied=True)
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    c, plen, steps, followed = 24, 40, 3, (0, 5, 11, 17, 23)
+    hm = tm.hip_model(pkg, kv_num_blocks=c * 3 + 2, max_seqs=c, max_tokens=c * plen)
+    rng = np.random.default_rng(162)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    par = modelgen.Parity("qwen3-0.6b-dims-unquantised", cos_min=0.999, rel_max=2e-2)
+    cur = np.array(toks, np.uint32)
+    for oc, i in enumerate(followed):
+        cur[i] = par.check(f"prefill/{i}", om.forward(oc, prompts[i], 0), lg[i], toks[i])
+    for s in range(steps):
+        fed = cur.copy()
+        toks, lg = hm.unified_forward([(i, [int(fed[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+        cur = np.array(toks, np.uint32)
+        for oc, i in enumerate(followed):
+            cur[i] = par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[i]], np.uint32), plen + s), lg[i], toks[i])
+    O.set_threads(1)
+    forms.require("f16_dense_linear")
+    par.finish(max_mismatches=0, max_route_ties=0)
+
+
 def test_gelu_activation_model(pkg):
     from tests import modelgen
     res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=9, decode_steps=2, seed=6, activation=1)

@@ -1086,3 +1086,194 @@ def test_sparse_repetition_penalty_then_argmax(env):
     ref_logits = np.stack([O.repetition_penalty(logits[r], prev[r], float(pens[r])) for r in range(m)])
     assert np.allclose(ld.cpu().numpy(), ref_logits, rtol=1e-6, atol=0)
     assert np.array_equal(got, O.argmax_rows(ref_logits))
+
+
+# ── trait-surface entry points of the bucketed MoE path and the single-sequence paged attention ─────────────────
+@pytest.mark.parametrize("tokens,ne,k,block", [(1, 128, 8, 16), (32, 128, 8, 16), (700, 128, 8, 64), (5, 8, 2, 16), (257, 60, 4, 32)])
+def test_moe_build_pairs_by_token_and_packed_row_align_bit_exact(env, tokens, ne, k, block):
+    """moe_build_pairs_by_token (capabilities.rs:410) and the packed-row moe_align_block_size (capabilities.rs:429): the
+    device plan must equal MoeBucketPlan::rebuild_into (moe/dispatch.rs:1408-1461, restated in the oracle) bit for bit —
+    a STABLE counting sort, where the reference's CUDA kernels leave the order inside an expert to atomicAdd."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens * 131 + ne)
+    ids = np.stack([rng.choice(ne, size=k, replace=False) for _ in range(tokens)]).astype(np.uint32)
+    P = tokens * k
+    off_ref, packed_ref, pairs_ref = O.bucket_plan(ids, tokens, ne, k)
+    ids_d = torch.from_numpy(ids.astype(np.int32).reshape(-1).copy()).cuda()
+    pairs = torch.full((P,), -7, dtype=torch.int32, device="cuda")
+    packed = torch.full((P,), -7, dtype=torch.int32, device="cuda")
+    offs = torch.full((ne + 1,), -7, dtype=torch.int32, device="cuda")
+    B.moe_build_pairs_by_token(ctx, ids_d, pairs, packed, offs, P, ne, k)
+    ctx.sync()
+    assert np.array_equal(offs.cpu().numpy(), np.asarray(off_ref, np.int32))
+    assert np.array_equal(packed.cpu().numpy(), np.asarray(packed_ref, np.int32))
+    assert np.array_equal(pairs.cpu().numpy(), np.asarray(pairs_ref, np.int32))
+    # packed-row align: expert e's padded region holds expert_offsets[e] + 0, 1, …; padding and the unused tail hold P
+    sorted_max = P + ne * block
+    sd = torch.full((sorted_max,), -7, dtype=torch.int32, device="cuda")
+    bd = torch.full((sorted_max // block + 1,), -7, dtype=torch.int32, device="cuda")
+    td = torch.zeros(1, dtype=torch.int32, device="cuda")
+    B.moe_align_block_size(ctx, ids_d, sd, bd, td, P, ne, block, sorted_max)
+    ctx.sync()
+    exp_sorted, exp_blocks = [], []
+    for e in range(ne):
+        cnt = int(off_ref[e + 1] - off_ref[e])
+        pad = -(-cnt // block) * block
+        exp_sorted += [int(off_ref[e]) + i for i in range(cnt)] + [P] * (pad - cnt)
+        exp_blocks += [e] * (pad // block)
+    assert int(td.item()) == len(exp_sorted)
+    got = sd.cpu().numpy()
+    assert np.array_equal(got[:len(exp_sorted)], np.asarray(exp_sorted, np.int32)) and np.all(got[len(exp_sorted):] == P)
+    assert np.array_equal(bd.cpu().numpy()[:len(exp_blocks)], np.asarray(exp_blocks, np.int32))
+    # ids outside [0, E) are skipped: pairs_by_token = −1 (kernels/moe_build_pairs.cu:84-87), the rest unchanged in order
+    bad = ids.astype(np.int32).reshape(-1).copy()
+    bad[::3] = np.where(np.arange(len(bad[::3])) % 2 == 0, -1, ne + 5)
+    pairs.fill_(-7)
+    B.moe_build_pairs_by_token(ctx, torch.from_numpy(bad).cuda(), pairs, packed, offs, P, ne, k)
+    ctx.sync()
+    pr, of = pairs.cpu().numpy(), offs.cpu().numpy()
+    valid = (bad >= 0) & (bad < ne)
+    assert np.all(pr[~valid] == -1) and of[ne] == valid.sum()
+    for e in range(ne):
+        rows = pr[valid & (bad == e)]
+        assert np.array_equal(rows, np.arange(of[e], of[e + 1]))       # ascending pair id inside an expert
+
+
+@pytest.mark.parametrize("tokens,K,H", [(1, 8, 2048), (32, 8, 2048), (7, 2, 1024)])
+def test_moe_combine_by_pairs_and_weighted_sum_batched(env, tokens, K, H):
+    """moe_combine with pairs_by_token (capabilities.rs:684-724: out[b] = Σ_k w[b,k]·packed_down[pairs[b,k]], −1 skipped)
+    and weighted_sum_batched[_offset] (capabilities.rs:560-600), against the trait's own default loop in f32."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens + K + H)
+    P = tokens * K
+    down = f16r(rng.standard_normal((P, H)))
+    w = rng.random((tokens, K)).astype(np.float32)
+    pairs = rng.permutation(P).astype(np.int32).reshape(tokens, K)
+    if tokens > 1:
+        pairs[1, 0] = -1
+    ref = np.zeros((tokens, H), np.float32)
+    for b in range(tokens):
+        for k in range(K):
+            if pairs[b, k] >= 0:
+                ref[b] += w[b, k] * down[pairs[b, k]]
+    out = torch.full((tokens, H), 3.0, dtype=torch.float16, device="cuda")
+    B.moe_combine_pairs(ctx, dev16(torch, down), torch.from_numpy(pairs.reshape(-1).copy()).cuda(), torch.from_numpy(w.reshape(-1).copy()).cuda(),
+                        out, tokens, H, K, P)
+    ctx.sync()
+    assert nmse(ref, host(out)) < NMSE_FP16_TOL
+    # weighted_sum_batched: slots [b, k, h]; the offset form reads weights / writes out at element offsets
+    ref2 = np.einsum("bk,bkh->bh", w, down.reshape(tokens, K, H)).astype(np.float32)
+    out2 = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+    B.weighted_sum_batched(ctx, dev16(torch, down), torch.from_numpy(w.reshape(-1).copy()).cuda(), out2, tokens, K, H)
+    wbig = torch.zeros(16 + P, dtype=torch.float32, device="cuda")
+    wbig[16:] = torch.from_numpy(w.reshape(-1).copy()).cuda()
+    obig = torch.full((2 * H + tokens * H,), 5.0, dtype=torch.float16, device="cuda")
+    B.weighted_sum_batched_offset(ctx, dev16(torch, down), wbig, 16, obig, 2 * H, tokens, K, H)
+    ctx.sync()
+    assert nmse(ref2, host(out2)) < NMSE_FP16_TOL
+    assert torch.equal(obig[2 * H:].reshape(tokens, H), out2) and bool(torch.all(obig[:2 * H] == 5.0))
+
+
+@pytest.mark.parametrize("tokens,E,K,H,I", [(9, 8, 2, 256, 128), (40, 16, 4, 512, 256), (300, 8, 2, 256, 128)])
+def test_gemm_phase_batched_bucketed_dispatch(env, tokens, E, K, H, I):
+    """MarlinExpertStack::gemm_phase_batched (marlin_expert_stack.rs:63): per-expert (m × K)·tile[e] over the expert-bucketed
+    packed rows of the host plan — the reference's bucketed MoE path (moe/dispatch.rs:1558-2192): gather → gemm1 → silu·mul →
+    gemm3 → moe_combine through pairs_by_token — against moe_forward_cpu."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens + E + H)
+    gu = [O.make_synthetic_gptq(H, 2 * I, 128, 300 + e, symmetric=True) for e in range(E)]
+    dn = [O.make_synthetic_gptq(I, H, 128, 400 + e, symmetric=True) for e in range(E)]
+    gu = [(q, f16r(s / (0.28 * np.sqrt(H))), z) for q, s, z in gu]
+    dn = [(q, f16r(s / (0.28 * np.sqrt(I))), z) for q, s, z in dn]
+    x = f16r(rng.standard_normal((tokens, H)))
+    rid, rw = O.route_topk(rng.standard_normal((tokens, E)).astype(np.float32), E, K, True)
+    gw = np.stack([O.dequant_gptq(q, s, z, 128, H, 2 * I) for q, s, z in gu])
+    dw = np.stack([O.dequant_gptq(q, s, z, 128, I, H) for q, s, z in dn])
+    ref = O.moe_forward_cpu(x, H, I, K, rid, rw, gw, dw)
+    P = tokens * K
+    off, packed_idx, pairs = O.bucket_plan(rid, tokens, E, K)
+    xp = dev16(torch, x[np.asarray(packed_idx)])                 # the gather step (embedding_lookup of x into x_packed)
+    disp = [(e, int(off[e]), int(off[e]), int(off[e + 1] - off[e])) for e in range(E)]
+    g_stack = B.load_gptq_stacked([q for q, _, _ in gu], [s for _, s, _ in gu], [z for _, _, z in gu], None, 4, 128, H, 2 * I,
+                                  fuse_gate_up=True)
+    d_stack = B.load_gptq_stacked([q for q, _, _ in dn], [s for _, s, _ in dn], [z for _, _, z in dn], None, 4, 128, I, H)
+    act = torch.zeros(P, I, dtype=torch.float16, device="cuda")
+    g_stack.gemm_phase_batched(ctx, xp, disp, act, H, fused_silu_mul=True)
+    # the down phase writes each expert's rows 3 rows further down (out_row_offset ≠ in_row_offset)
+    down = torch.zeros(P + 3, H, dtype=torch.float16, device="cuda")
+    d_stack.gemm_phase_batched(ctx, act, [(e, i, o + 3, m) for e, i, o, m in disp], down, I)
+    out = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+    B.moe_combine_pairs(ctx, down[3:], torch.from_numpy(np.asarray(pairs, np.int32)).cuda(), torch.from_numpy(rw.reshape(-1).copy()).cuda(),
+                        out, tokens, H, K, P)
+    ctx.sync()
+    assert bool(torch.all(down[:3] == 0))
+    assert nmse(ref, host(out)) < 3e-6
+
+
+@pytest.mark.parametrize("nq,nkv,hd,q_len,ctx_len", [(8, 2, 128, 1, 300), (8, 2, 128, 37, 37), (32, 4, 128, 70, 200), (4, 4, 64, 20, 33)])
+def test_paged_decode_attention_trait_form(env, nq, nkv, hd, q_len, ctx_len):
+    """BackendPagedKv::paged_decode_attention (traits.rs:1719-1738): q_len == 1 over several sequences (token-major), and the
+    single-sequence causal prefill whose q / out are HEAD-major [nq, q_len, hd] with context_lens[0] the final kv length."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(nq + q_len + ctx_len)
+    S = 3 if q_len == 1 else 1
+    kv_lens = [ctx_len, 17, 130][:S]
+    max_blocks = (max(kv_lens) + 15) // 16 + 1
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 2
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used, K, V = 0, [], []
+    for s, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    lens_d = torch.from_numpy(np.array(kv_lens, np.int32)).cuda()
+    if q_len == 1:
+        q = f16r(rng.standard_normal((S, nq, hd)))
+        out = torch.zeros(S, nq, hd, dtype=torch.float16, device="cuda")
+        B.paged_decode_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(tables).cuda(), lens_d, S, nq, nkv, hd, 16, max_blocks, 1)
+        ctx.sync()
+        got = host(out)
+        for s, n in enumerate(kv_lens):
+            assert nmse(_ref_attention(O, q[s:s + 1], K[s], V[s], n - 1, nq, nkv, hd), got[s:s + 1]) < 1e-5, s
+    else:
+        q_tm = f16r(rng.standard_normal((q_len, nq, hd)))        # token-major for the reference …
+        q_hm = np.ascontiguousarray(q_tm.transpose(1, 0, 2))     # … head-major for the call
+        out = torch.zeros(nq, q_len, hd, dtype=torch.float16, device="cuda")
+        B.paged_decode_attention(ctx, dev16(torch, q_hm), ck, cv, out, torch.from_numpy(tables).cuda(), lens_d, 1, nq, nkv, hd, 16, max_blocks, q_len)
+        ctx.sync()
+        ref = _ref_attention(O, q_tm, K[0], V[0], ctx_len - q_len, nq, nkv, hd)
+        assert nmse(ref, host(out).transpose(1, 0, 2)) < 1e-5
+
+
+def test_backend_graph_capture_and_replay(env):
+    """BackendGraph (capabilities.rs:35-70): ops enqueued between begin / end capture are recorded, not run; every replay
+    runs them on the current buffer contents."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(9)
+    x = f16r(rng.standard_normal((5, 1024)))
+    w = f16r(1 + 0.1 * rng.standard_normal(1024))
+    xd, wd = dev16(torch, x), dev16(torch, w)
+    out = torch.zeros(5, 1024, dtype=torch.float16, device="cuda")
+    ctx.sync()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        c2 = B.new_context()                                       # capture needs a non-default stream
+        B.begin_graph_capture(c2)
+        B.rms_norm(c2, xd, wd, 1e-6, out, 5, 1024)
+        g = B.end_graph_capture(c2)
+        c2.sync()
+        assert float(out.abs().max()) == 0.0                       # recorded, not executed
+        B.replay_graph(c2, g)
+        c2.sync()
+        assert nmse(O.rms_norm(x, w, 1e-6), host(out)) < NMSE_FP16_TOL
+        x2 = f16r(rng.standard_normal((5, 1024)))
+        xd.copy_(dev16(torch, x2))
+        c2.sync()
+        B.replay_graph(c2, g)
+        c2.sync()
+        assert nmse(O.rms_norm(x2, w, 1e-6), host(out)) < NMSE_FP16_TOL
+        B.reset_graph(c2, g)
