@@ -229,3 +229,36 @@ def test_host_sampler_chain_matches_restatement(pkg, oracle):
     tok = C.c_uint32()
     assert lib.ferrum_hip_sampler_greedy(tie.ctypes.data_as(fp), 4, C.byref(tok)) == 0 and tok.value == 2
     assert int(oracle.argmax_rows(tie[None])[0]) == 1
+
+
+def test_rust_ffi_crate_matches_the_library(pkg):
+    """crates/ferrum-hip (cannot be compiled here — no Rust toolchain): src/ffi.rs is generated from
+    include/ferrum_hip.h and must (a) be current, (b) declare exactly the library's exported entry points, one to one,
+    and (c) every entry point the hand-written trait impls and TRAIT_MAP name must exist in the library."""
+    gen = os.path.join(ROOT, "tools", "gen_ffi_rs.py")
+    assert subprocess.run(["python", gen, "--check"]).returncode == 0, "ffi.rs is stale: run python tools/gen_ffi_rs.py"
+    crate = os.path.join(ROOT, "crates", "ferrum-hip", "src")
+    ffi = open(os.path.join(crate, "ffi.rs")).read()
+    declared = re.findall(r"pub fn (ferrum_\w+)\(", ffi)
+    assert len(declared) == len(set(declared))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T " in line and line.split()[-1].startswith("ferrum_"))
+    assert sorted(declared) == exported, (sorted(set(exported) - set(declared)), sorted(set(declared) - set(exported)))
+    used = set()
+    for f in os.listdir(crate):
+        if f.endswith(".rs") and f != "ffi.rs":
+            src = open(os.path.join(crate, f)).read()
+            used |= set(re.findall(r"ffi::(ferrum_\w+)", src)) | set(re.findall(r'"(ferrum_hip_\w+)"', src))
+    assert len(used) > 40
+    assert not (used - set(exported)), sorted(used - set(exported))
+    # the #[repr(C)] structs carry every field of the C structs, in order
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ferrum_hip.h")).read(), flags=re.S)
+    for m in re.finditer(r"typedef struct\s*\{(.*?)\}\s*(\w+);", hdr, flags=re.S):
+        names = []
+        for decl in m.group(1).split(";"):
+            decl = re.sub(r"\s+", " ", decl.strip())
+            if decl:                                             # "int32_t a, b, c" / "const char* name": the last word of each declarator
+                first, *rest = decl.split(",")
+                names += [first.split()[-1].lstrip("*")] + [r.strip().lstrip("*") for r in rest]
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % m.group(2), ffi, flags=re.S).group(1)
+        assert re.findall(r"pub (\w+):", body) == names, m.group(2)
