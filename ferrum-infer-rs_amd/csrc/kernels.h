@@ -75,6 +75,9 @@ int f16t_gemm_f32out(const __half* x, const __half* wt, float* out, int m, int n
 
 // ── norms / elementwise (norm.hip) ───────────────────────────────────────────
 int rms_norm_f16(const __half* x, const __half* w, float eps, __half* out, int tokens, int dim, hipStream_t s);
+int embed_rms_norm_f16(const __half* table, const uint32_t* token_ids, float embed_scale, __half* residual, float* residual_f32,
+                       const __half* w, float eps, __half* norm_out, int tokens, int dim, unsigned* zero_words, int n_zero, hipStream_t s);
+int gather_rms_norm_f16(const __half* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int rows, int dim, hipStream_t s);
 int fused_add_rms_norm_f16(__half* residual, const __half* x, const __half* w, float eps, __half* out,
                            int tokens, int dim, hipStream_t s);
 int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, int n_ids, int dim, hipStream_t s);
@@ -186,6 +189,15 @@ int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residu
 // ── sampling (sampling.hip) ──────────────────────────────────────────────────
 int argmax_rows_f16_ws(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                        float* workspace, size_t workspace_bytes, hipStream_t s);
+// Device-side bookkeeping of a decode step, done by the last stage of the greedy argmax (one launch fewer per step):
+// the sampled id of row i becomes the next input token, positions / kv lengths advance, the id is recorded in the history.
+struct DecodeAdvance {
+    uint32_t* tokens = nullptr; uint32_t* pos_offsets = nullptr; uint32_t* kv_lens = nullptr; uint32_t* history = nullptr;
+    int32_t* step_counter = nullptr; unsigned* ticket = nullptr; int n = 0;
+};
+// *fused = 1 when the advance ran inside the argmax launches (two-stage form), 0 when the caller still has to run it
+int argmax_rows_f32_ws_advance(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                               float* workspace, size_t workspace_bytes, const DecodeAdvance* adv, int* fused, hipStream_t s);
 int argmax_rows_f32_ws(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                        float* workspace, size_t workspace_bytes, hipStream_t s);
 int argmax_rows_f16(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,

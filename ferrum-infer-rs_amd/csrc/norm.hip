@@ -92,6 +92,86 @@ int fused_add_rms_norm_f16(__half* residual, const __half* x, const __half* w, f
     return launch_rms<true>(x, residual, w, eps, out, tokens, dim, s);
 }
 
+// Head / tail of a forward in ONE launch each (a dependent launch costs ≈ 4 µs even when trivial; a decode step had nine of
+// them outside the layers): gather a row (embedding row by token id, or residual row by sampled index) → optional scale
+// (fp16 rounding, like scale_inplace) → optional copies of the gathered row (fp16 residual, fp32 residual stream) →
+// rms_norm·w → out.  Same per-element arithmetic as embedding_lookup → scale_inplace → rms_norm.  Block 0 also zeroes
+// `zero_words` (the split router's arrival counters, re-armed per forward).
+template <typename IdxT, int CHUNKS>
+__global__ __launch_bounds__(256) void gather_rms_norm_kernel(const __half* __restrict__ table, const IdxT* __restrict__ ids, float scale,
+                                                              __half* __restrict__ copy_f16, float* __restrict__ copy_f32,
+                                                              const __half* __restrict__ w, float eps, __half* __restrict__ out, int dim,
+                                                              unsigned* __restrict__ zero_words, int n_zero) {
+    __shared__ float smem[4];
+    const long row = blockIdx.x;
+    const long src = (long)ids[row];
+    if (blockIdx.x == 0 && zero_words)
+        for (int i = threadIdx.x; i < n_zero; i += 256) zero_words[i] = 0u;
+    const int nvec = dim >> 3;
+    half8 v[CHUNKS];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            half8 xv = *reinterpret_cast<const half8*>(table + src * dim + i * 8);
+            if (scale != 0.0f) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) xv[j] = (_Float16)((float)xv[j] * scale);
+            }
+            if (copy_f16) *reinterpret_cast<half8*>(copy_f16 + row * dim + i * 8) = xv;
+            if (copy_f32) {
+                float4v lo, hi;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { lo[j] = (float)xv[j]; hi[j] = (float)xv[4 + j]; }
+                float4v* d = reinterpret_cast<float4v*>(copy_f32 + row * dim + i * 8);
+                d[0] = lo;
+                d[1] = hi;
+            }
+            v[c] = xv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)xv[j] * (float)xv[j];
+        }
+    }
+    const float total = block_reduce_sum_256(ss, smem);
+    const float inv = 1.0f / sqrtf(total / (float)dim + eps);
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        const int i = threadIdx.x + c * 256;
+        if (i < nvec) {
+            const half8 wv = *reinterpret_cast<const half8*>(w + i * 8);
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
+            *reinterpret_cast<half8*>(out + row * dim + i * 8) = o;
+        }
+    }
+}
+
+template <typename IdxT>
+static int launch_gather_rms(const __half* table, const IdxT* ids, float scale, __half* copy_f16, float* copy_f32, const __half* w, float eps,
+                             __half* out, int rows, int dim, unsigned* zero_words, int n_zero, hipStream_t s) {
+    if (rows <= 0) return 0;
+    FH_REQUIRE(dim % 8 == 0 && dim <= 8 * 256 * 8, "gather_rms_norm: dim=%d must be a multiple of 8 and <= 16384", dim);
+    const int chunks = cdiv(dim / 8, 256);
+    dim3 grid(rows), block(256);
+#define FH_GRN(C) hipLaunchKernelGGL((gather_rms_norm_kernel<IdxT, C>), grid, block, 0, s, table, ids, scale, copy_f16, copy_f32, w, eps, out, dim, zero_words, n_zero)
+    if (chunks <= 1) FH_GRN(1); else if (chunks <= 2) FH_GRN(2); else if (chunks <= 4) FH_GRN(4); else FH_GRN(8);
+#undef FH_GRN
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+// embedding_lookup (+ scale_inplace) + rms_norm of layer 0, the residual stream written on the way (fp16, and fp32 for
+// sandwich-norm models)
+int embed_rms_norm_f16(const __half* table, const uint32_t* token_ids, float embed_scale, __half* residual, float* residual_f32,
+                       const __half* w, float eps, __half* norm_out, int tokens, int dim, unsigned* zero_words, int n_zero, hipStream_t s) {
+    return launch_gather_rms<uint32_t>(table, token_ids, embed_scale, residual, residual_f32, w, eps, norm_out, tokens, dim, zero_words, n_zero, s);
+}
+// gather_rows + rms_norm on the sampled rows (final norm)
+int gather_rms_norm_f16(const __half* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int rows, int dim, hipStream_t s) {
+    return launch_gather_rms<int32_t>(x, row_idx, 0.0f, nullptr, nullptr, w, eps, out, rows, dim, nullptr, 0, s);
+}
+
 // ── row gathers ──────────────────────────────────────────────────────────────
 template <typename IdxT>
 __global__ void gather_rows_kernel(const __half* __restrict__ table, const IdxT* __restrict__ ids,

@@ -889,7 +889,9 @@ struct GreedyDeviceOpts {          // device pointers, already uploaded on m->st
     const uint8_t* mask = nullptr; int mask_len = 0;
     const uint32_t* row_offsets = nullptr; const uint32_t* token_ids = nullptr; const float* penalties = nullptr;
 };
-int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const GreedyDeviceOpts* gopts = nullptr) {
+int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const GreedyDeviceOpts* gopts = nullptr,
+                    const DecodeAdvance* advance = nullptr, int* advance_fused = nullptr) {
+    if (advance_fused) *advance_fused = 0;
     const FerrumHipModelConfig& c = m->cfg;
     hipStream_t s = m->stream;
     const int T = sh.m_total, H = c.hidden, nq = c.num_heads, nkv = c.num_kv_heads, hd = c.head_dim;
@@ -910,20 +912,14 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         if ((rc = (x))) return rc;                                                   \
         if (trace) FH_CHECK_HIP(hipStreamSynchronize(s));                            \
     } while (0)
-    // arrival counters of the split route kernel: re-armed by the kernel itself, but zeroed per forward as well so that an
-    // aborted launch can never poison the next one (one 256-byte memset node per step)
-    if (m->route_arrive) FH_CHECK_HIP(hipMemsetAsync(m->route_arrive, 0, 64 * sizeof(unsigned), s));
-    RUN(embedding_lookup_f16(m->embed, tokens, m->residual, T, H, s));
-    if (c.embed_scale != 0.0f) RUN(scale_inplace_f16(m->residual, c.embed_scale, (long)T * H, s));   // llama_family.rs:3656
+    // arrival counters of the split route kernel: re-armed by the kernel itself, but zeroed per forward as well (by the head
+    // kernel below) so that an aborted launch can never poison the next one
     const bool sandwich = c.sandwich_norms != 0;
-    // the input norm of layer 0; later layers get theirs fused into the previous layer's tail
-    if (sandwich) {
-        // fp32 residual stream (the reference's device F32 shadow, llama_family.rs:3664-3674): fp16 only feeds the GEMMs
-        hipLaunchKernelGGL(f16_to_f32_kernel, dim3(cdiv((long)T * H, 256)), dim3(256), 0, s, m->residual, m->residual_f32, (long)T * H);
-        RUN(rms_norm_f32_to_f16(m->residual_f32, nullptr, m->layers[0].input_ln, c.rms_eps, m->norm_out, T, H, s));
-    } else {
-        RUN(rms_norm_f16(m->residual, m->layers[0].input_ln, c.rms_eps, m->norm_out, T, H, s));
-    }
+    // head, one launch: embedding_lookup (+ the Gemma embedding scale, llama_family.rs:3656) → residual stream (fp16; for
+    // sandwich-norm models also the fp32 shadow, llama_family.rs:3664-3674) → layer 0's input norm.  Later layers get their
+    // input norm fused into the previous layer's tail.
+    RUN(embed_rms_norm_f16(m->embed, tokens, c.embed_scale, m->residual, sandwich ? m->residual_f32 : nullptr, m->layers[0].input_ln,
+                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 : 0, s));
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
@@ -1150,8 +1146,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         if (sandwich) {
             RUN(rms_norm_f32_to_f16(m->residual_f32, sampled_idx, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
         } else {
-            RUN(gather_rows_f16(m->residual, sampled_idx, m->sampled_hidden, sh.num_sampled, H, s));
-            RUN(rms_norm_f16(m->sampled_hidden, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
+            RUN(gather_rms_norm_f16(m->residual, sampled_idx, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
         }
         RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, c.vocab, H, m->workspace,
                              m->workspace_bytes, s));
@@ -1161,8 +1156,8 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             if (gopts && gopts->row_offsets)
                 RUN(apply_repetition_penalties_sparse_f32(m->logits, gopts->row_offsets, gopts->token_ids, gopts->penalties,
                                                           sh.num_sampled, c.vocab, s));
-            RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, gopts ? gopts->mask : nullptr, gopts ? gopts->mask_len : 0,
-                                   sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, s));
+            RUN(argmax_rows_f32_ws_advance(m->logits, m->out_tokens, gopts ? gopts->mask : nullptr, gopts ? gopts->mask_len : 0,
+                                           sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, advance, advance_fused, s));
         }
     }
 #undef RUN
@@ -1344,14 +1339,21 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
     h_cu[n] = (uint32_t)n;
     size_t used = m->il.block_tables + (size_t)n * m->max_blocks_per_seq * 4;
     FH_CHECK_HIP(hipMemcpyAsync(m->idx_dev, m->idx_host, used, hipMemcpyHostToDevice, m->stream));
-    FH_CHECK_HIP(hipMemsetAsync(m->step_counter, 0, 4, m->stream));
+    FH_CHECK_HIP(hipMemsetAsync(m->step_counter, 0, 8, m->stream));    // step index + the advance ticket
 
     auto enqueue_step = [&]() -> int {
-        if (int rc = enqueue_forward(m, sh, true)) return rc;
-        hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1024), 0, m->stream, m->out_tokens,
-                           idx<uint32_t>(m, m->il.tokens), idx<uint32_t>(m, m->il.pos_offsets),
-                           idx<uint32_t>(m, m->il.kv_lens), m->history, m->step_counter, n);
-        FH_CHECK_LAUNCH();
+        // the step's bookkeeping (sampled id → next input, positions, history) rides in the last stage of the argmax
+        DecodeAdvance adv;
+        adv.tokens = idx<uint32_t>(m, m->il.tokens); adv.pos_offsets = idx<uint32_t>(m, m->il.pos_offsets);
+        adv.kv_lens = idx<uint32_t>(m, m->il.kv_lens); adv.history = m->history; adv.step_counter = m->step_counter;
+        adv.ticket = reinterpret_cast<unsigned*>(m->step_counter + 1); adv.n = n;
+        int fused = 0;
+        if (int rc = enqueue_forward(m, sh, true, nullptr, &adv, &fused)) return rc;
+        if (!fused) {                                            // narrow vocabularies take the single-kernel argmax
+            hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(1024), 0, m->stream, m->out_tokens, adv.tokens, adv.pos_offsets,
+                               adv.kv_lens, m->history, m->step_counter, n);
+            FH_CHECK_LAUNCH();
+        }
         return 0;
     };
 

@@ -123,8 +123,10 @@ __global__ __launch_bounds__(256) void argmax_partial_kernel(const T* __restrict
 }
 
 __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restrict__ pval, const int* __restrict__ pidx,
-                                                          uint32_t* __restrict__ out, int C) {
+                                                          uint32_t* __restrict__ out, int C, DecodeAdvance adv) {
     const long row = blockIdx.x;
+    // decode loop: every row reads the step index before any row can advance it (the LAST row to finish does)
+    const int step = adv.tokens ? *adv.step_counter : 0;
     float best = -INFINITY;
     int best_idx = 0x7fffffff;
     for (int c = threadIdx.x; c < C; c += 64) {
@@ -133,12 +135,27 @@ __global__ __launch_bounds__(64) void argmax_final_kernel(const float* __restric
         if (v > best || (v == best && i < best_idx)) { best = v; best_idx = i; }
     }
     wave_argmax(best, best_idx);
-    if (threadIdx.x == 0) out[row] = best_idx == 0x7fffffff ? 0u : (uint32_t)best_idx;
+    if (threadIdx.x == 0) {
+        const uint32_t id = best_idx == 0x7fffffff ? 0u : (uint32_t)best_idx;
+        out[row] = id;
+        if (adv.tokens && row < adv.n) {
+            adv.tokens[row] = id;
+            adv.pos_offsets[row] += 1;
+            adv.kv_lens[row] += 1;
+            adv.history[(long)step * adv.n + row] = id;
+            const unsigned t = __hip_atomic_fetch_add(adv.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == gridDim.x - 1) {
+                __hip_atomic_store(adv.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *adv.step_counter = step + 1;
+            }
+        }
+    }
 }
 
 template <typename T>
 static int argmax_rows_ws(const T* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
-                          float* workspace, size_t workspace_bytes, hipStream_t s) {
+                          float* workspace, size_t workspace_bytes, hipStream_t s, const DecodeAdvance* adv = nullptr, int* fused = nullptr) {
+    if (fused) *fused = 0;
     if (m <= 0) return 0;
     // Vector form: 2048-element chunks (one 16/32-byte request per thread) when rows stay 16-byte aligned.
     const bool vec = n % 8 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && n >= 4096 &&
@@ -157,9 +174,15 @@ static int argmax_rows_ws(const T* logits, uint32_t* out_ids, const uint8_t* val
     else
         hipLaunchKernelGGL((argmax_partial_kernel<T, false>), dim3(m, C), dim3(256), 0, s, logits, pval, pidx, valid_mask, mask_len, n, chunk);
     FH_CHECK_LAUNCH();
-    hipLaunchKernelGGL(argmax_final_kernel, dim3(m), dim3(64), 0, s, pval, pidx, out_ids, C);
+    const bool adv_ok = adv && adv->tokens && adv->n == m;
+    hipLaunchKernelGGL(argmax_final_kernel, dim3(m), dim3(64), 0, s, pval, pidx, out_ids, C, adv_ok ? *adv : DecodeAdvance());
     FH_CHECK_LAUNCH();
+    if (fused && adv_ok) *fused = 1;
     return 0;
+}
+int argmax_rows_f32_ws_advance(const float* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
+                               float* workspace, size_t workspace_bytes, const DecodeAdvance* adv, int* fused, hipStream_t s) {
+    return argmax_rows_ws(logits, out_ids, valid_mask, mask_len, m, n, workspace, workspace_bytes, s, adv, fused);
 }
 int argmax_rows_f16_ws(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                        float* workspace, size_t workspace_bytes, hipStream_t s) {
