@@ -222,17 +222,33 @@ def cpu_baseline(seed=1, prompt=24, n_dec=16):
             "host_cpus": os.cpu_count()}
 
 
-def tp_decode_case(pkg, torch, dist, model_name, world, rank, c, PL, steps, warm, chunk, try_oneshot=True):
+def _dist_dev(dist):
+    """Device of the tensors handed to torch.distributed: the GPU under nccl (= RCCL), the host under gloo (the one-GPU
+    rehearsal, where every rank shares device 0 and RCCL would refuse the second rank)."""
+    return "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+
+def tp_decode_case(pkg, torch, dist, model_name, world, rank, c, PL, steps, warm, chunk, try_oneshot=True, transport="rccl", layers=None):
     """One tensor-parallel group of `world` ranks (this process = rank `rank`) decoding `c` sequences of a dense model:
-    per-rank shards, RCCL communicator shared through a broadcast unique id, prefill, `warm` + `steps` decode steps through
-    the per-rank hipGraph (all-reduces captured).  Returns the whole-group rate (the slowest rank's time)."""
+    per-rank shards, a communicator per rank (RCCL shared through a broadcast unique id; or, transport "oneshot", only the
+    hand-written peer reduce over hipIpc buffers), prefill, `warm` + `steps` decode steps through the per-rank hipGraph
+    (all-reduces captured).  Returns the whole-group rate (the slowest rank's time)."""
     cfg = shard_cfg(MODELS[model_name], world, rank)
     max_seq_len = ((PL + 2 * (warm + steps) + 8 + 15) // 16) * 16
     t0 = time.perf_counter()
-    model = build_model(pkg, cfg, c, max_seq_len, min(chunk, c * PL), 9271)     # same seed on every rank: replicated tensors agree
+    model = build_model(pkg, cfg, c, max_seq_len, min(chunk, c * PL), 9271, layers=layers)   # same seed on every rank: replicated tensors agree
     comm = None
-    if world > 1:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+    if world > 1 and transport == "oneshot":
+        # decode AND prefill all-reduces go through the peer buffers: they must hold the largest prefill message
+        need = min(chunk, c * PL) * cfg["hidden"] * 2
+        assert need <= (64 << 20), f"one-shot buffer of {need} bytes: lower --prefill-chunk"
+        comm = pkg.Comm.bare(world, rank)
+        hs = [None] * world
+        dist.all_gather_object(hs, comm.oneshot_export(max(need, 1 << 20)))
+        comm.oneshot_attach(hs)
+        model.set_comm(comm)
+    elif world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device=_dist_dev(dist))
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(pkg.Comm.unique_id()), dtype=torch.uint8))
         dist.broadcast(uid, 0)
@@ -262,7 +278,7 @@ def tp_decode_case(pkg, torch, dist, model_name, world, rank, c, PL, steps, warm
         torch.cuda.synchronize()
         t_local = time.perf_counter() - t0
         barrier()
-        t = torch.tensor([t_local, t_prefill], dtype=torch.float64, device="cuda")
+        t = torch.tensor([t_local, t_prefill], dtype=torch.float64, device=_dist_dev(dist) if (dist is not None and world > 1) else "cpu")
         if dist is not None and world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         for sid in ids:
@@ -272,16 +288,24 @@ def tp_decode_case(pkg, torch, dist, model_name, world, rank, c, PL, steps, warm
     t_dec, t_pre, out = run(0)
     res = {"model": model_name, "tp": world, "concurrency": c, "steps": steps, "warmup": warm, "tok_s": round(c * steps / t_dec, 1),
            "ms_per_step": round(t_dec / steps * 1e3, 4), "prefill_ms": round(t_pre * 1e3, 2), "build_s": round(build_s, 1),
-           "allreduce": "RCCL ncclAllReduce fp16, in place, captured in the per-rank decode hipGraph" if world > 1 else "none (TP=1)",
+           "allreduce": ("none (TP=1)" if world == 1 else
+                         "one-shot peer reduce over hipIpc buffers (rank-ordered fp32 sum), captured in the per-rank decode hipGraph" if transport == "oneshot"
+                         else "RCCL ncclAllReduce fp16, in place, captured in the per-rank decode hipGraph"),
            "per_rank_shapes": {"num_heads": cfg["num_heads"], "num_kv_heads": cfg["num_kv_heads"], "intermediate": cfg["intermediate"]}}
     if world > 1:
         # every rank must have sampled the same ids (identical all-reduced activations, replicated lm_head)
-        chk = torch.tensor([int(np.asarray(out, np.int64).sum() % (1 << 31))], dtype=torch.int64, device="cuda")
+        chk = torch.tensor([int(np.asarray(out, np.int64).sum() % (1 << 31))], dtype=torch.int64, device=_dist_dev(dist))
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         res["ranks_agree_on_ids"] = bool(lo.item() == hi.item())
-    if world > 1 and try_oneshot:
+    if world > 1 and transport == "oneshot":
+        st = comm.oneshot_status()
+        tmo = torch.tensor([st["timeouts"]], dtype=torch.int64, device=_dist_dev(dist))
+        dist.all_reduce(tmo, op=dist.ReduceOp.MAX)
+        res["oneshot_timeouts"] = int(tmo.item())
+        res["oneshot_epochs"] = st["epoch"]
+    if world > 1 and try_oneshot and transport == "rccl":
         # the hand-written one-shot peer all-reduce over hipIpc-imported buffers (opt-in: every spin is bounded, a rank that
         # cannot see its peers counts a timeout and the attempt is reported as failed instead of hanging)
         try:
@@ -294,7 +318,7 @@ def tp_decode_case(pkg, torch, dist, model_name, world, rank, c, PL, steps, warm
             model.set_comm(comm)                               # drops the captured graph: the next capture takes the one-shot kernel
             t_dec1, _, out1 = run(10000)
             st = comm.oneshot_status()
-            tmo = torch.tensor([st["timeouts"]], dtype=torch.int64, device="cuda")
+            tmo = torch.tensor([st["timeouts"]], dtype=torch.int64, device=_dist_dev(dist))
             dist.all_reduce(tmo, op=dist.ReduceOp.MAX)
             res["oneshot"] = {"tok_s": round(c * steps / t_dec1, 1), "ms_per_step": round(t_dec1 / steps * 1e3, 4),
                               "timeouts": int(tmo.item()), "ids_equal_to_rccl_run": bool(np.array_equal(out, out1)),
@@ -325,6 +349,8 @@ def main():
                     "(= --gpus) and make that the headline line (\"scaling\": \"strong\")")
     ap.add_argument("--tp-oneshot", action="store_true", help="after the RCCL run, also try the hand-written one-shot peer all-reduce "
                     "over hipIpc buffers (opt-in: unmeasured on multi-GPU hardware so far)")
+    ap.add_argument("--tp-transport", default="rccl", choices=("rccl", "oneshot"), help="all-reduce of the tensor-parallel runs: RCCL over xGMI "
+                    "(default) or only the hand-written one-shot peer reduce over hipIpc buffers")
     ap.add_argument("--no-tp-scaling", action="store_true", help="skip the dense tensor-parallel extra (tp_scaling)")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -391,7 +417,8 @@ def main():
 
     if args.tp:
         # a dense BASELINE config as ONE tensor-parallel group: the headline line of this invocation
-        res = tp_decode_case(pkg, torch, dist, args.model, world, rank, c, PL, K, W, min(chunk, 2048), try_oneshot=args.tp_oneshot)
+        res = tp_decode_case(pkg, torch, dist, args.model, world, rank, c, PL, K, W, min(chunk, 2048), try_oneshot=args.tp_oneshot,
+                             transport=args.tp_transport, layers=args.layers or None)
         if rank == 0:
             mname = {"llama31-8b": "Llama-3.1-8B", "gemma3-27b": "Gemma-3-27B", "llama3-70b": "Llama-3-70B"}[args.model]
             print(json.dumps({
@@ -552,7 +579,7 @@ def main():
         for name in ["llama3-70b"] + (["gemma3-27b"] if world == 2 else []):
             stage(f"tp_scaling {name} tp={world}")
             tps.append(tp_decode_case(pkg, torch, dist, name, world, rank, c, PL, min(K, 32), min(W, 4) if W else 2, 2048,
-                                      try_oneshot=args.tp_oneshot))
+                                      try_oneshot=args.tp_oneshot, transport=args.tp_transport))
         extra["tp_scaling"] = tps
         extra["rccl_ranks"] = world if world > 1 else 0
         num_layers_run = cfg["num_layers"]

@@ -241,6 +241,17 @@ int ferrum_hip_comm_create_rccl(FerrumHipComm** out, int world, int rank, const 
     return 0;
 }
 
+// A rank without a transport yet: the one-shot buffers are attached afterwards (oneshot_export / oneshot_attach).  What a
+// multi-process group uses when it has no RCCL rank — e.g. the ranks of a rehearsal that share ONE GPU (RCCL refuses
+// two ranks on a device), or a deployment that wants only the one-shot path.
+int ferrum_hip_comm_create_bare(FerrumHipComm** out, int world, int rank) {
+    FH_REQUIRE(out && world >= 1 && world <= 8 && rank >= 0 && rank < world, "comm_create_bare: world=%d rank=%d", world, rank);
+    auto* c = new FerrumHipComm();
+    c->world = world; c->rank = rank;
+    *out = c;
+    return 0;
+}
+
 // The ranks of one process (threads of a test on one GPU, or one process driving several GPUs with peer access enabled):
 // `world` communicators whose one-shot buffers see each other directly.  Call with the device of rank r current when the
 // ranks live on different devices (devices[] = NULL: everything on the current device).

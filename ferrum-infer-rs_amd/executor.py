@@ -161,6 +161,14 @@ class Comm:
         return cls(h)
 
     @classmethod
+    def bare(cls, world, rank):
+        """A rank with no transport yet: attach the one-shot buffers with oneshot_export / oneshot_attach."""
+        lib = load_library()
+        h = C.c_void_p()
+        _check(lib.ferrum_hip_comm_create_bare(C.byref(h), world, rank), "comm_create_bare")
+        return cls(h)
+
+    @classmethod
     def local_group(cls, world, max_message_bytes=1 << 20):
         lib = load_library()
         arr = (C.c_void_p * world)()

@@ -550,6 +550,8 @@ typedef struct FerrumHipComm FerrumHipComm;
 int ferrum_hip_comm_unique_id(uint8_t id[128]);
 int ferrum_hip_tp_unique_id(uint8_t id[128]);                       /* same, older name */
 int ferrum_hip_comm_create_rccl(FerrumHipComm** comm, int world, int rank, const uint8_t id[128]);
+/* A rank with no transport yet (one-shot buffers attached afterwards); all_reduce fails until they are. */
+int ferrum_hip_comm_create_bare(FerrumHipComm** comm, int world, int rank);
 /* `world` ranks inside one process (threads of a test on one GPU; devices[] = NULL puts every buffer on the current device). */
 int ferrum_hip_comm_create_local_group(FerrumHipComm** comms, int world, size_t max_message_bytes, const int* devices);
 int ferrum_hip_comm_oneshot_export(FerrumHipComm* comm, size_t max_message_bytes, uint8_t handle[64]);

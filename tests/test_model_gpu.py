@@ -869,3 +869,34 @@ def test_kv_admission_contract(pkg):
         hm.unified_forward([(4, np.zeros(60, np.uint32), 0, True)])
     with pytest.raises(RuntimeError):                            # pos_offset must equal the cached length
         hm.unified_forward([(2, [1], 5, True)])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_process_tensor_parallel_rehearsal_over_hipipc(pkg, world):
+    """The multi-process tensor-parallel path end to end on ONE GPU (tools/tp_rehearsal.py under torch.distributed.run, gloo
+    rendezvous on 127.0.0.1): `world` processes share device 0 and all-reduce through the one-shot peer kernel over
+    hipIpc-imported buffers — RCCL cannot put two ranks on one device, and no xGMI is involved, but everything else is the
+    code a multi-GPU group runs: per-rank shard configs, rank-aware synthetic weights, handle exchange, the per-rank decode
+    hipGraph with its all-reduces inside.  Every all-reduce result is bit-exact against the rank-ordered fp32 sum; all ranks
+    sample the same ids; no rank counts a timeout."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FERRUM_REHEARSAL_C="20", FERRUM_REHEARSAL_LAYERS="3")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "tp_rehearsal.py")], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world"] == world and d["all_reduce"]["bit_exact"] and d["all_reduce"]["timeouts"] == 0
+    tp = d["tp_decode"]
+    assert tp["tp"] == world and tp["ranks_agree_on_ids"] and tp["oneshot_timeouts"] == 0 and tp["oneshot_epochs"] > 0, tp
+    assert tp["per_rank_shapes"]["num_kv_heads"] == 8 // world and tp["tok_s"] > 0

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Multi-process tensor-parallel rehearsal on ONE GPU (development / test aid; no xGMI involved).
+
+`python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/tp_rehearsal.py`
+starts N ranks that all use device 0 and rendezvous over gloo.  RCCL refuses two ranks on one device, so the ranks talk
+through the hand-written one-shot peer all-reduce over hipIpc-imported buffers — the same code path a multi-GPU group
+takes with `--tp-transport oneshot`, minus the fabric.  Checks, and prints one JSON line from rank 0:
+  1. ferrum_hip_all_reduce_f16 on 4 … 1 Mi fp16 elements, eagerly and from a captured + replayed hipGraph, against the
+     rank-ordered fp32 sum of the gathered inputs (bit-exact), 40 calls back to back (buffer parity / epoch logic);
+  2. the bench's own tensor-parallel decode case (per-rank synthetic shards of a dense model, per-rank hipGraph with the
+     all-reduces inside): every rank must sample the same ids, no rank may count a one-shot timeout.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(0)                                   # every rank on the one GPU
+    dist.init_process_group("gloo")
+    import __graft_entry__ as ge
+    import bench
+    pkg = ge.load_package()
+    pkg.load_library()
+    B = pkg.HipBackend
+    out = {"world": world}
+
+    # 1. the collective itself
+    comm = pkg.Comm.bare(world, rank)
+    hs = [None] * world
+    dist.all_gather_object(hs, comm.oneshot_export(4 << 20))
+    comm.oneshot_attach(hs)
+    stream = torch.cuda.Stream()
+    rng = np.random.default_rng(100 + rank)
+    worst, calls = 0.0, 0
+    with torch.cuda.stream(stream):
+        ctx = B.new_context()
+        for it in range(40):
+            n = [4, 4096, 262144, 1 << 20, 52][it % 5] if it % 5 != 4 else 1000
+            x = (rng.standard_normal(n) * (1 + rank)).astype(np.float16)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, x)
+            ref = np.zeros(n, np.float32)
+            for r in range(world):                               # rank order, fp32 accumulate, one rounding
+                ref += gathered[r].astype(np.float32)
+            ref = ref.astype(np.float16)
+            t = torch.from_numpy(x).cuda()
+            if it % 2 == 0:
+                comm.all_reduce(t, n, ctx.stream)
+            else:                                                # the same call recorded in a hipGraph and replayed once
+                ctx.sync()
+                B.begin_graph_capture(ctx)
+                comm.all_reduce(t, n, ctx.stream)
+                g = B.end_graph_capture(ctx)
+                B.replay_graph(ctx, g)
+                ctx.sync()
+                B.reset_graph(ctx, g)
+            ctx.sync()
+            got = t.cpu().numpy()
+            assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (rank, it, n, float(np.max(np.abs(got.astype(np.float32) - ref.astype(np.float32)))))
+            calls += 1
+    st = comm.oneshot_status()
+    assert st["timeouts"] == 0 and st["epoch"] == calls, st
+    out["all_reduce"] = {"calls": calls, "epoch": st["epoch"], "timeouts": st["timeouts"], "bit_exact": True}
+    comm.destroy()
+    dist.barrier()
+
+    # 2. the runner's tensor-parallel decode across processes (graph + one-shot all-reduce inside)
+    res = bench.tp_decode_case(pkg, torch, dist, os.environ.get("FERRUM_REHEARSAL_MODEL", "llama31-8b"), world, rank,
+                               c=int(os.environ.get("FERRUM_REHEARSAL_C", "20")), PL=48, steps=8, warm=2, chunk=96,
+                               try_oneshot=False, transport="oneshot", layers=int(os.environ.get("FERRUM_REHEARSAL_LAYERS", "3")))
+    out["tp_decode"] = res
+    if rank == 0:
+        print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
