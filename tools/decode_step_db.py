@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One steady-state decode step per decode run, cut from a rocprofv3 --kernel-trace results.db (rocpd sqlite):
-a step = the launches between two decode_advance_kernel launches; consecutive steps less than 3 ms apart form a run
+a step = the launches between two argmax_final_kernel launches (the last launch of a decode step: it also advances the
+device-side decode state); consecutive steps with the same launch count form a run
 (bench.py: the c=32 window, then the c=1/4/16 sweep).  Prints, per run, launches per step, wall time of a late step
 and the per-kernel mean durations inside it.  Usage: decode_step_db.py <results.db> [min_steps_in_run]"""
 import collections
@@ -12,7 +13,7 @@ import sys
 def main():
     db = sqlite3.connect(sys.argv[1])
     rows = list(db.execute("select name, start, end, grid_x, grid_y, grid_z, workgroup_x, vgpr_count, accum_vgpr_count from kernels order by start"))
-    adv = [i for i, r in enumerate(rows) if "decode_advance" in r[0]]
+    adv = [i for i, r in enumerate(rows) if "argmax_final" in r[0]]
     min_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     runs, cur = [], [adv[0]]
     for a, b in zip(adv, adv[1:]):
