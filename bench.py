@@ -554,16 +554,23 @@ def main():
             # flight) driven by the C++ continuous-batching loop over the C ABI (csrc/serve_loop.cc) in its own process
             exe = os.path.join(ROOT, "ferrum-infer-rs_amd", "bin", "ferrum_hip_serve")
             import subprocess
-            cmd = [exe, "--requests", "96", "--concurrency", str(c), "--prompt-len", str(PL), "--out-len", "128",
-                   "--max-batched-tokens", str(chunk)] + (["--dense"] if args.model == "llama31-8b" else [])
             # the child is not to be profiled when this process runs under rocprofv3 (its preloaded tool crashed in the
             # child at exit): drop the profiler's environment
             env = {k: v for k, v in os.environ.items()
                    if not (k.startswith(("ROCP", "ROCPROF")) or (k in ("LD_PRELOAD", "HSA_TOOLS_LIB") and "rocprof" in v.lower()))}
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-            if p.returncode != 0:
-                raise RuntimeError(f"ferrum_hip_serve failed: {p.stderr[-500:]}")
-            extra["serve_closed_loop"] = json.loads(p.stdout.strip().splitlines()[0])
+
+            def serve(budget):
+                cmd = [exe, "--requests", "96", "--concurrency", str(c), "--prompt-len", str(PL), "--out-len", "128",
+                       "--max-batched-tokens", str(budget)] + (["--dense"] if args.model == "llama31-8b" else [])
+                p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+                if p.returncode != 0:
+                    raise RuntimeError(f"ferrum_hip_serve failed: {p.stderr[-500:]}")
+                return json.loads(p.stdout.strip().splitlines()[0])
+            # two token budgets per engine iteration: the reference's own default (DEFAULT_MAX_BATCHED_TOKENS = 2048,
+            # ferrum-cli/src/gpu_mem_autosize.rs:25: prompts are admitted 8 at a time, so the median request gets its first
+            # token early) and one forward for all 32 prompts (highest throughput, every request waits for the whole prefill)
+            extra["serve_closed_loop"] = serve(2048)
+            extra["serve_closed_loop_one_prefill_forward"] = serve(chunk)
         if not args.no_cpu_baseline and world == 1:
             stage("cpu baseline")
             extra["cpu_baseline"] = cpu_baseline()

@@ -35,8 +35,15 @@ struct W4Device {
 int w4_repack_host(const int32_t* qweight, const float* scales, const int32_t* qzeros,
                    const int32_t* g_idx, const int32_t* col_perm, int group_size, int k, int n,
                    W4HostPacked* out);
+// Optional prologue of the ≤ 4-row dense projection: the input rows are the MoE combine + residual add + RMSNorm of the
+// previous layer's tail (fused.hip kernel A) computed inside the GEMM launch; `x` is then ignored.
+struct FusedCombineNorm {
+    const __half* down; const float* weights; const __half* residual_in; __half* residual_out; const __half* ln_w;
+    float eps; int top_k;
+};
+bool w4_gemm_dense_can_fuse_combine_norm(const W4Device& w, int m);
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
-                  size_t workspace_bytes, hipStream_t stream);
+                  size_t workspace_bytes, hipStream_t stream, const FusedCombineNorm* fa = nullptr);
 int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int32_t* sorted_token_ids, const int32_t* block_ids,
                      const int32_t* total_post_pad, int num_valid_pairs, int max_blocks, int block_rows, int top_k, int fused_silu,
                      hipStream_t stream);

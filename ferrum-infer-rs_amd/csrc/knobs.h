@@ -74,6 +74,7 @@ enum Form : int {
     FORM_TP_ALLREDUCE_LOOPBACK,
     FORM_TP_ALLREDUCE_ONESHOT,
     FORM_F16_DENSE_LINEAR,      // unquantised projection (DenseLinear)
+    FORM_W4_FUSED_TAIL,         // ≤ 4-row q|k|v GEMM with the previous layer's combine + add + norm as its prologue
     FORM_COUNT
 };
 

@@ -74,6 +74,9 @@ struct FerrumHipModel {
     unsigned* route_arrive = nullptr;     // [T] arrival counters of the split route kernel (zero between launches)
     int route_parts = 4;                  // expert parts per token in the decode route kernel (1 = single-workgroup kernel)
     bool fuse_rope_attn = true;           // decode: QK-norm + RoPE + KV write inside the attention launch
+    int fuse_tail_max_rows = 1;           // MoE decode at ≤ this many rows (≤ 4): a layer's combine + add + norm runs as the prologue of the next
+                                          // q|k|v GEMM (0 = never).  Measured: c=1 430 → 437 tok/s; at 4 rows every workgroup repeating the 4 × 36 KB
+                                          // of L2 reads costs more than the launch saved (c=4 1455 → 1335 tok/s), so only single rows fuse
     int route_gemm_min_tokens = 512;          // from this many tokens the router runs as a GEMM + top-k (3 launches)
     int moe_tile_min_pairs_per_expert = 32;   // average pairs per expert from which MoE GEMMs use 64-row LDS tiles
     int moe_tile32_min_pairs_per_expert = 8;  // … from which (below the 64-row threshold) they use 32-row LDS tiles

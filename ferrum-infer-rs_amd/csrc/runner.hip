@@ -286,6 +286,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     }
     m->alloc.reset(new BlockAllocator((uint32_t)cfg->kv_num_blocks));
     if (const char* e = getenv("FERRUM_HIP_ROUTE_PARTS")) m->route_parts = std::max(1, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_FUSE_TAIL_ROWS")) m->fuse_tail_max_rows = std::max(0, std::min(4, atoi(e)));
     if (const char* e = getenv("FERRUM_HIP_FUSE_ROPE")) m->fuse_rope_attn = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_O_SLABS")) m->o_slabs = std::max(0, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_DENSE_SLABS")) m->dense_slabs = atoi(e) != 0;
@@ -920,11 +921,20 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     // input norm fused into the previous layer's tail.
     RUN(embed_rms_norm_f16(m->embed, tokens, c.embed_scale, m->residual, sandwich ? m->residual_f32 : nullptr, m->layers[0].input_ln,
                            c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 : 0, s));
+    // decode at ≤ 4 rows (MoE models): the tail of layer l — combine + residual add + next input norm — runs as the prologue of
+    // layer l+1's q|k|v GEMM instead of as a launch of its own (every dependent launch costs ≈ 4 µs there)
+    bool pending_tail = false;
+    FusedCombineNorm tail{};
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
         const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
-        RUN(dense_linear(m, L.qkv, m->norm_out, m->qkv_out, T, s));
+        if (pending_tail) {
+            RUN(w4_gemm_dense(L.qkv, nullptr, m->qkv_out, T, m->workspace, m->workspace_bytes, s, &tail));
+            pending_tail = false;
+        } else {
+            RUN(dense_linear(m, L.qkv, m->norm_out, m->qkv_out, T, s));
+        }
         // per-layer attention schedule (llama_layer_attention_schedule, llama_family.rs:1028-1045)
         const int pattern = c.sliding_window_pattern;
         const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
@@ -1006,8 +1016,14 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                                                            m->route_cand, m->route_stats, m->route_arrive, c.norm_topk_prob,
                                                            m->expert_ids, m->expert_w, nullptr, T, H, s));
                     RUN(moe_decode_gemms(m, L, P, max_blocks, s));
-                    RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps,
-                                                     m->norm_out, T, K, H, s));
+                    if (T <= m->fuse_tail_max_rows && next_ln && !m->taps_enabled &&
+                        w4_gemm_dense_can_fuse_combine_norm(m->layers[li + 1].qkv, T)) {
+                        tail = FusedCombineNorm{m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps, K};
+                        pending_tail = true;
+                    } else {
+                        RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps,
+                                                         m->norm_out, T, K, H, s));
+                    }
                 } else {
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, m->o_out, slabs, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
                                                            c.rms_eps, m->norm_out, L.router, E, K, c.norm_topk_prob, m->expert_ids,

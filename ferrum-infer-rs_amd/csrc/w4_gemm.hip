@@ -314,6 +314,15 @@ struct W4Args {
     int route_T, route_Q, route_K, norm_topk;
     int32_t* pub_expert_ids;   // [T·K] merged ids  (published by one workgroup)
     float* pub_expert_w;       // [T·K] combine weights
+    // fused prologue of the ≤ 4-row skinny GEMM (w4_gemm_wgsplit_kernel<…, FUSE_A>): the input rows are not read from `x` but
+    // computed — MoE combine + residual add + RMSNorm of the PREVIOUS layer's tail (fused.hip kernel A)
+    const __half* fa_down;     // [M·top_k, K] expert outputs
+    const float* fa_weights;   // [M·top_k] combine weights
+    const __half* fa_res_in;   // [M, K] residual before the add
+    __half* fa_res_out;        // [M, K] residual after the add (≠ fa_res_in: every workgroup reads, one writes)
+    const __half* fa_ln;       // [K] norm weights
+    float fa_eps;
+    int fa_top_k;
 };
 
 // Align-block-size computed INSIDE the grouped GEMM (P ≤ 1024 pairs): every workgroup derives its
@@ -802,8 +811,14 @@ __global__ void splitk_reduce_bias_kernel(const float* __restrict__ partial, __h
 // The small projections of the decode layer (qkv, o) are latency-bound: a slab split-K needs a second
 // launch (≈5 µs) to reduce.  Here the W waves of a workgroup take K-slices of the same NT column
 // tiles and reduce their fp32 accumulators through LDS, so the GEMM is ONE launch with fp16 output.
-template <int MT, int NT, bool HAS_ZP>
+// FUSE_A (MT = 1, ≤ 4 rows — decode at c ≤ 4, where every dependent launch costs ≈ 4 µs whatever it does): the activation rows
+// are produced by the workgroup itself — residual' = residual + Σ_k w_k·down_k (k ascending, fp32, one fp16 rounding: the
+// arithmetic of moe_combine_add_rmsnorm_kernel), x = rms_norm(residual')·ln — into LDS, after the first weight group has been
+// requested; workgroup 0 also stores residual'.  Every workgroup repeats the ≈ 36 KB per row of L2 reads: cheap at ≤ 4 rows,
+// prohibitive at 32, which is why only the small batches fuse.
+template <int MT, int NT, bool HAS_ZP, bool FUSE_A = false>
 __global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) : 256)) void w4_gemm_wgsplit_kernel(W4Args p) {
+    static_assert(!FUSE_A || MT == 1, "the fused prologue serves one 16-row tile");
     extern __shared__ __attribute__((aligned(16))) float red[];
     const int W = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -814,10 +829,13 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) 
     constexpr int V = MT * NT * 4;
 
     const __half* xrow[MT];
+    const int KP = p.K + 8;                                   // LDS row pitch of the fused rows (16 B of padding: rows on different banks)
+    __half* xs = reinterpret_cast<__half*>(red + (size_t)W * V * 64);
 #pragma unroll
     for (int mt = 0; mt < MT; mt++) {
         int r = rb * 16 * MT + mt * 16 + b;
-        xrow[mt] = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + 8 * a;
+        if (FUSE_A) xrow[mt] = xs + (long)(r < p.M ? r : p.M - 1) * KP + 8 * a;
+        else xrow[mt] = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + 8 * a;
     }
     typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
     const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4 + nt0) * 64 + lane;
@@ -834,24 +852,83 @@ __global__ __launch_bounds__(MT == 1 ? 1024 : (MT == 2 ? (NT == 1 ? 1024 : 512) 
     u32x4g wq[2][NT];
     uint2 scv[2], zpv[2];
     half8 af[2][MT][4];
-    auto issue = [&](int buf, int g) {
+    auto issue_w = [&](int buf, int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) wq[buf][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
         scv[buf] = sc_lane[(long)g * 16];
         if (HAS_ZP) zpv[buf] = zp_lane[(long)g * 16];
+    };
+    auto issue_a = [&](int buf, int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int s = 0; s < 4; s++) af[buf][mt][s] = *reinterpret_cast<const half8*>(xrow[mt] + g * 128 + 32 * s);
     };
+    auto issue = [&](int buf, int g) __attribute__((always_inline)) { issue_w(buf, g); issue_a(buf, g); };
     auto consume = [&](int buf) {
         const unsigned long long sb = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
         const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
         w4_consume_group<MT, NT, HAS_ZP, false>(wq[buf], sb, zb, nt0, af[buf], acc);
     };
 #define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    if (FUSE_A) {
+        if (g0 < g1) issue_w(0, g0);                          // the first weight group travels while the rows are made
+        FH_PIN();
+        float* wred = reinterpret_cast<float*>(xs + (size_t)p.M * KP);     // [W] partial sums of squares
+        const int nvec = p.K >> 3, tk = p.fa_top_k;
+        const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int t = 0; t < p.M; t++) {
+            float ss = 0.f;
+            for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+                float accv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float wk8[8];
+                half8 d8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {                  // the first 8 expert rows are requested together
+                    const int kc = k < tk ? k : tk - 1;
+                    wk8[k] = p.fa_weights[t * tk + kc];
+                    d8[k] = *reinterpret_cast<const half8*>(p.fa_down + ((long)t * tk + kc) * p.K + i * 8);
+                }
+                half8 rv = *reinterpret_cast<const half8*>(p.fa_res_in + (long)t * p.K + i * 8);
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (k < tk) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) accv[j] += wk8[k] * (float)d8[k][j];
+                    }
+                for (int k = 8; k < tk; k++) {
+                    const float wk = p.fa_weights[t * tk + k];
+                    const half8 d = *reinterpret_cast<const half8*>(p.fa_down + ((long)t * tk + k) * p.K + i * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) accv[j] += wk * (float)d[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + accv[j]);
+                if (writer) *reinterpret_cast<half8*>(p.fa_res_out + (long)t * p.K + i * 8) = rv;
+                *reinterpret_cast<half8*>(xs + (long)t * KP + i * 8) = rv;           // un-normalised for now
+#pragma unroll
+                for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
+            }
+            ss = wave_reduce_sum(ss);
+            if (lane == 0) wred[wave] = ss;
+            __syncthreads();
+            float total = 0.f;
+            for (int w = 0; w < W; w++) total += wred[w];
+            const float inv = 1.0f / sqrtf(total / (float)p.K + p.fa_eps);
+            for (int i = threadIdx.x; i < nvec; i += blockDim.x) {
+                half8 rv = *reinterpret_cast<const half8*>(xs + (long)t * KP + i * 8);       // this thread's own store
+                const half8 wv = *reinterpret_cast<const half8*>(p.fa_ln + i * 8);
+#pragma unroll
+                for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] * inv * (float)wv[j]);
+                *reinterpret_cast<half8*>(xs + (long)t * KP + i * 8) = rv;
+            }
+            __syncthreads();
+        }
+        if (g0 < g1) issue_a(0, g0);
+        FH_PIN();
+    }
     if (g0 < g1) {
-        issue(0, g0);
+        if (!FUSE_A) issue(0, g0);
         FH_PIN();
         int g = g0;
         for (; g + 2 <= g1 - 1; g += 2) {
@@ -1504,6 +1581,17 @@ static int launch_ldsa(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stre
 template <int MT, int NT>
 static int launch_wgsplit(const W4Args& a, bool has_zp, dim3 grid, int W, hipStream_t stream) {
     size_t lds = (size_t)W * MT * NT * 4 * 64 * sizeof(float);
+    if constexpr (MT == 1) {
+        if (a.fa_down) {                                       // fused combine + add + norm prologue (≤ 4 rows)
+            lds += (size_t)a.M * (a.K + 8) * sizeof(__half) + 64 * sizeof(float);
+            FH_REQUIRE(lds <= 64 * 1024, "w4_gemm_dense: fused prologue needs %zu bytes of LDS", lds);
+            form_hit(FORM_W4_FUSED_TAIL);
+            if (has_zp) hipLaunchKernelGGL((w4_gemm_wgsplit_kernel<1, NT, true, true>), grid, dim3(W * 64), lds, stream, a);
+            else hipLaunchKernelGGL((w4_gemm_wgsplit_kernel<1, NT, false, true>), grid, dim3(W * 64), lds, stream, a);
+            FH_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (has_zp) hipLaunchKernelGGL((w4_gemm_wgsplit_kernel<MT, NT, true>), grid, dim3(W * 64), lds, stream, a);
     else hipLaunchKernelGGL((w4_gemm_wgsplit_kernel<MT, NT, false>), grid, dim3(W * 64), lds, stream, a);
     FH_CHECK_LAUNCH();
@@ -1543,9 +1631,15 @@ static int launch_w4_slabs(const W4Args& a, int mt, bool has_zp, dim3 grid, hipS
 }
 
 // Dense y[M,N] = x[M,K]·Wᵀ (+bias).  One launch: K is split across the waves of each workgroup.
+bool w4_gemm_dense_can_fuse_combine_norm(const W4Device& w, int m) {
+    return m >= 1 && m <= 4 && w.qw != nullptr && w.f16t == nullptr && w.perm == nullptr && w.k % 8 == 0 && w.k <= 8192;
+}
+
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
-                  size_t workspace_bytes, hipStream_t stream) {
+                  size_t workspace_bytes, hipStream_t stream, const FusedCombineNorm* fa) {
     if (m <= 0) return 0;
+    FH_REQUIRE(!fa || (w4_gemm_dense_can_fuse_combine_norm(w, m) && fa->residual_in != fa->residual_out && fa->top_k >= 1),
+               "w4_gemm_dense: the fused combine + norm prologue needs <= 4 rows of a plain INT4 projection and ping-pong residual buffers");
     if (w.f16t) {                                     // DenseLinear: B::gemm on fp16 weights (linear.rs:109-129)
         form_hit(FORM_F16_DENSE_LINEAR);
         if (int rc = f16t_gemm(x, w.f16t, out, m, w.n, w.k, workspace, workspace_bytes, stream)) return rc;
@@ -1554,6 +1648,10 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp; a.bias = w.bias;
     a.x = x; a.out = out; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n; a.S = 1;
+    if (fa) {
+        a.fa_down = fa->down; a.fa_weights = fa->weights; a.fa_res_in = fa->residual_in; a.fa_res_out = fa->residual_out;
+        a.fa_ln = fa->ln_w; a.fa_eps = fa->eps; a.fa_top_k = fa->top_k;
+    }
     const int mt = m <= 16 ? 1 : (m <= 32 ? 2 : 4);
     const int row_blocks = cdiv(m, 16 * mt);
     // LDS-shared activations (w4_gemm_ldsa_kernel) + fp32 split-K slabs + one reduce launch.  Measured at m = 32 against
