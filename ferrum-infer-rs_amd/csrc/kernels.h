@@ -162,6 +162,9 @@ int moe_align_block_size_packed_rows(const int32_t* expert_ids, int32_t* sorted_
                                      int sorted_max, hipStream_t s);
 int moe_build_pairs_by_token(const int32_t* expert_ids, int32_t* pairs_by_token, int32_t* packed_token_idx,
                              int32_t* expert_offsets, int batch_x_topk, int num_experts, int top_k, hipStream_t s);
+int moe_remap_expert_ids(const int32_t* ids, int32_t* local, int n, int e0, int e_local, hipStream_t s);
+int moe_combine_local_f16(const __half* down, const float* weights, const int32_t* pair_ids, __half* out, int tokens, int top_k,
+                          int hidden, hipStream_t s);
 int moe_combine_pairs_f16(const __half* packed_down, const int32_t* pairs_by_token, const float* pair_weights, __half* out,
                           int batch, int hidden, int top_k, int total_pairs, hipStream_t s);
 int moe_combine_f16(const __half* down, const float* weights, __half* out, int tokens, int top_k, int hidden,

@@ -270,8 +270,26 @@ int moe_combine_pairs_f16(const __half* packed_down, const int32_t* pairs_by_tok
 // out[b] (+)= Σ_k w[b,k]·down[b·top_k + k]   (k ascending, fp32 accumulate; moe_forward_cpu order,
 // ferrum-models/src/moe/dispatch.rs:2277-2283).  accumulate=1 folds the residual add
 // (qwen3_moe_forward_unified_layer.rs:451) into the same pass.
+// Expert parallelism: global expert id → the rank's local id (id − e0), −1 for experts owned by other ranks; every
+// grouped-GEMM form then simply finds no work for those pairs (ids outside [0, E_local) are ignored by the align / the
+// expert-major match), and the combine below skips them.
+__global__ void moe_remap_expert_ids_kernel(const int32_t* __restrict__ ids, int32_t* __restrict__ local, int n, int e0, int e_local) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int v = ids[i] - e0;
+        local[i] = (v >= 0 && v < e_local) ? v : -1;
+    }
+}
+int moe_remap_expert_ids(const int32_t* ids, int32_t* local, int n, int e0, int e_local, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(moe_remap_expert_ids_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, ids, local, n, e0, e_local);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 __global__ void moe_combine_kernel(const __half* __restrict__ down, const float* __restrict__ weights,
-                                   __half* __restrict__ out, int top_k, int hidden, int accumulate) {
+                                   __half* __restrict__ out, int top_k, int hidden, int accumulate,
+                                   const int32_t* __restrict__ pair_ids) {
     const long b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (hidden >> 3)) return;
@@ -287,12 +305,13 @@ __global__ void moe_combine_kernel(const __half* __restrict__ down, const float*
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        if (k < top_k) {
+        if (k < top_k && (!pair_ids || pair_ids[b * top_k + k] >= 0)) {      // pair_ids: rows of other ranks' experts were never written
 #pragma unroll
             for (int j = 0; j < 8; j++) acc[j] += w8[k] * (float)d8[k][j];
         }
     }
     for (int k = 8; k < top_k; k++) {
+        if (pair_ids && pair_ids[b * top_k + k] < 0) continue;
         float w = weights[b * top_k + k];
         half8 d = *reinterpret_cast<const half8*>(down + (b * top_k + k) * hidden + i * 8);
 #pragma unroll
@@ -315,7 +334,18 @@ int moe_combine_f16(const __half* down, const float* weights, __half* out, int t
     if (tokens <= 0) return 0;
     FH_REQUIRE(hidden % 8 == 0, "moe combine: hidden=%d must be a multiple of 8", hidden);
     hipLaunchKernelGGL(moe_combine_kernel, dim3(cdiv(hidden / 8, 256), tokens), dim3(256), 0, s, down, weights, out,
-                       top_k, hidden, accumulate_into_residual);
+                       top_k, hidden, accumulate_into_residual, (const int32_t*)nullptr);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// the rank's PARTIAL MoE output under expert parallelism: Σ over the pairs whose expert is local (pair_ids ≥ 0), k ascending
+int moe_combine_local_f16(const __half* down, const float* weights, const int32_t* pair_ids, __half* out, int tokens, int top_k,
+                          int hidden, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(hidden % 8 == 0 && pair_ids, "moe combine (local): hidden=%d must be a multiple of 8", hidden);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3(cdiv(hidden / 8, 256), tokens), dim3(256), 0, s, down, weights, out,
+                       top_k, hidden, 0, pair_ids);
     FH_CHECK_LAUNCH();
     return 0;
 }

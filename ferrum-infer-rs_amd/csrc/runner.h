@@ -84,6 +84,10 @@ struct FerrumHipModel {
     int moe_em_min_pairs_per_expert = 2;      // decode (P ≤ 1024): average pairs per expert from which the grouped GEMMs run expert-major (0 = never)
     bool dense_slabs = true;              // dense MLP block at 17–32 rows: slab GEMMs reduced by their consumers
     int o_slabs = 8;                      // split-K slabs of the o projection on the decode path (0 = direct)
+    // expert parallelism (cfg.expert_parallel, tp_world > 1): this rank owns experts [ep_e0, ep_e0 + ep_E) of num_experts
+    int ep_e0 = 0, ep_E = 0;
+    int32_t* expert_ids_local = nullptr;  // [T·k] expert id − ep_e0 for the rank's own experts, −1 for the others
+    float* ones = nullptr;                // [max_tokens] 1.0f: the all-reduced MoE output enters the residual like one more "expert row"
     float* router_logits = nullptr;
     int32_t *expert_ids = nullptr, *sorted_ids = nullptr, *block_ids = nullptr, *total_post_pad = nullptr;
     float* expert_w = nullptr;

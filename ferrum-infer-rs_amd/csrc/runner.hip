@@ -254,9 +254,21 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     }
     FH_REQUIRE(!cfg->sandwich_norms || cfg->num_experts == 0, "model_create: sandwich norms are implemented for dense MLP models");
     FH_REQUIRE(cfg->sliding_window_pattern >= 0 && cfg->rope_local_theta >= 0.0, "model_create: bad local-attention schedule");
+    FH_REQUIRE(cfg->expert_parallel >= 0 && cfg->expert_parallel <= 2 && cfg->vocab_parallel >= 0 && cfg->vocab_parallel <= 1,
+               "model_create: expert_parallel=%d vocab_parallel=%d", cfg->expert_parallel, cfg->vocab_parallel);
+    if (cfg->expert_parallel && cfg->tp_world > 1) {
+        FH_REQUIRE(cfg->num_experts > 0 && cfg->num_experts % cfg->tp_world == 0, "model_create: expert_parallel needs num_experts (%d) divisible by the world size (%d)",
+                   cfg->num_experts, cfg->tp_world);
+    }
     auto* m = new FerrumHipModel();
     m->cfg = *cfg;
     if (m->cfg.tp_world < 1) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
+    if (m->cfg.tp_world == 1) { m->cfg.expert_parallel = 0; m->cfg.vocab_parallel = 0; }
+    m->ep_E = m->cfg.num_experts;
+    if (m->cfg.expert_parallel) {
+        m->ep_E = m->cfg.num_experts / m->cfg.tp_world;
+        m->ep_e0 = m->cfg.tp_rank * m->ep_E;
+    }
     m->layers.resize(cfg->num_layers);
     m->max_blocks_per_seq = cdiv(cfg->max_seq_len, KV_BLOCK);
     hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
@@ -316,7 +328,8 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
                     (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
-                    (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch, (void*)m->greedy_opts_dev, (void*)m->tp_tmp})
+                    (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch, (void*)m->greedy_opts_dev, (void*)m->tp_tmp,
+                    (void*)m->expert_ids_local, (void*)m->ones})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -387,6 +400,8 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int exper
     }
     FH_REQUIRE(which == 4 || which == 5, "model_set_gptq: which=%d", which);
     FH_REQUIRE(c.num_experts > 0 && expert >= 0 && expert < c.num_experts, "model_set_gptq: expert=%d of %d", expert, c.num_experts);
+    if (expert < m->ep_e0 || expert >= m->ep_e0 + m->ep_E) return 0;     // expert parallel: another rank's expert (a loader may offer all of them)
+    expert -= m->ep_e0;
     FH_REQUIRE(!g_idx, "model_set_gptq: act-order experts unsupported");
     const bool gu = which == 4;
     if (int rc = gu ? check_shape("expert gate_up", k, n, H, 2 * c.expert_inter) : check_shape("expert down", k, n, c.expert_inter, H)) return rc;
@@ -395,10 +410,10 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int exper
     if (int r = w4_repack_host(qweight, scales, qzeros, nullptr, gu ? perm.data() : nullptr, c.group_size, k, n, &hp)) return r;
     FH_REQUIRE(hp.symmetric, "model_set_gptq: asymmetric expert zero points are not supported by the runner (use the op API)");
     W4Device* w = gu ? &L.exp_gate_up : &L.exp_down;
-    if (int rc = ensure_expert_stack(w, k, n, c.num_experts, gu)) return rc;
+    if (int rc = ensure_expert_stack(w, k, n, m->ep_E, gu)) return rc;
     FH_CHECK_HIP(hipMemcpy(w->qw + (size_t)expert * hp.qw.size(), hp.qw.data(), hp.qw.size() * 4, hipMemcpyHostToDevice));
     FH_CHECK_HIP(hipMemcpy(w->sc + (size_t)expert * hp.sc.size(), hp.sc.data(), hp.sc.size() * 2, hipMemcpyHostToDevice));
-    if (L.exp_loaded.empty()) L.exp_loaded.assign(c.num_experts, 0);
+    if (L.exp_loaded.empty()) L.exp_loaded.assign(m->ep_E, 0);
     L.exp_loaded[expert] |= gu ? 1 : 2;
     return 0;
 }
@@ -493,9 +508,9 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
         if (int rc = synth_w4(&L.o, q_dim(c), c.hidden, 1, false, ls ^ 0x22, s)) return rc;
         if (c.num_experts > 0) {
             if (int rc = alloc_normal(&L.router, (long)c.num_experts * c.hidden, ls0 ^ 0x33, 0.02f)) return rc;
-            if (int rc = synth_w4(&L.exp_gate_up, c.hidden, 2 * c.expert_inter, c.num_experts, true, ls ^ 0x44, s)) return rc;
-            if (int rc = synth_w4(&L.exp_down, c.expert_inter, c.hidden, c.num_experts, false, ls ^ 0x55, s)) return rc;
-            L.exp_loaded.assign(c.num_experts, 3);
+            if (int rc = synth_w4(&L.exp_gate_up, c.hidden, 2 * c.expert_inter, m->ep_E, true, ls ^ 0x44, s)) return rc;
+            if (int rc = synth_w4(&L.exp_down, c.expert_inter, c.hidden, m->ep_E, false, ls ^ 0x55, s)) return rc;
+            L.exp_loaded.assign(m->ep_E, 3);
         } else {
             if (int rc = synth_w4(&L.gate_up, c.hidden, 2 * c.intermediate, 1, false, ls ^ 0x44, s)) return rc;
             if (int rc = synth_w4(&L.down, c.intermediate, c.hidden, 1, false, ls ^ 0x55, s)) return rc;
@@ -522,8 +537,8 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         }
         if (c.num_experts > 0) {
             FH_REQUIRE(L.router && L.exp_gate_up.qw && L.exp_down.qw, "model_finalize: layer %d MoE weights missing", li);
-            for (int e = 0; e < c.num_experts; e++)
-                FH_REQUIRE(L.exp_loaded[e] == 3, "model_finalize: layer %d expert %d incomplete", li, e);
+            for (int e = 0; e < m->ep_E; e++)
+                FH_REQUIRE(L.exp_loaded[e] == 3, "model_finalize: layer %d expert %d incomplete", li, e + m->ep_e0);
         } else {
             FH_REQUIRE(have(L.gate_up) && have(L.down), "model_finalize: layer %d MLP weights missing", li);
         }
@@ -578,6 +593,14 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 64;   // room for 64-row blocks (prefill)
         rc |= dev_alloc(&m->router_logits, T * c.num_experts);
         rc |= dev_alloc(&m->expert_ids, P);
+        if (c.expert_parallel) {
+            rc |= dev_alloc(&m->expert_ids_local, P);
+            if (!rc) {
+                FH_CHECK_HIP(hipMalloc((void**)&m->ones, T * sizeof(float)));
+                std::vector<float> one(T, 1.0f);
+                FH_CHECK_HIP(hipMemcpy(m->ones, one.data(), T * sizeof(float), hipMemcpyHostToDevice));
+            }
+        }
         rc |= dev_alloc(&m->expert_w, P);
         rc |= dev_alloc(&m->sorted_ids, sorted_max);
         rc |= dev_alloc(&m->block_ids, sorted_max / 16 + 1);
@@ -827,14 +850,20 @@ T* idx(FerrumHipModel* m, size_t off) { return reinterpret_cast<T*>(m->idx_dev +
 // input columns are gathered with the same permutation first (like the op-level ferrum_hip_gptq_linear_forward_f16).
 // gate_up (+silu·mul) and down grouped GEMMs of a decode-sized batch (P ≤ 1024 pairs) straight from expert_ids:
 // expert-major when most experts are routed to (no align at all), else block-major with the align computed inside gate_up.
+// Under expert parallelism the kernels see the rank's own experts only: local ids (−1 = another rank's expert, ignored by
+// every form) and the local expert count.
+static const int32_t* moe_ids(const FerrumHipModel* m) { return m->cfg.expert_parallel ? m->expert_ids_local : m->expert_ids; }
+
 static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_blocks, hipStream_t s) {
     const FerrumHipModelConfig& c = m->cfg;
-    const int E = c.num_experts, K = c.top_k;
-    if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * E) {
-        if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, K, 1, s)) return rc;
-        return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, m->expert_ids, E, P, 1, 0, s);
+    const int E = m->ep_E, K = c.top_k;
+    const int32_t* ids = moe_ids(m);
+    // (the expert-major threshold compares pairs per expert: P pairs over num_experts, whatever share of them is local)
+    if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts) {
+        if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, ids, E, P, K, 1, s)) return rc;
+        return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, ids, E, P, 1, 0, s);
     }
-    if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, K, 1,
+    if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, ids, E, P, max_blocks, K, 1,
                                           m->sorted_ids, m->block_ids, m->total_post_pad, s)) return rc;
     return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
 }
@@ -844,29 +873,30 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
 #define FH_TRY(call) do { if (int rc_ = (call)) return rc_; } while (0)
 static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted_max, int max_blocks, hipStream_t s) {
     const FerrumHipModelConfig& c = m->cfg;
-    const int E = c.num_experts, K = c.top_k;
+    const int E = m->ep_E, K = c.top_k, Eg = c.num_experts;     // block shapes are chosen by pairs per expert over ALL experts
+    const int32_t* ids = moe_ids(m);
     if (P <= 1024) {
         FH_TRY(moe_decode_gemms(m, L, P, max_blocks, s));
-    } else if (P >= m->moe_tile_min_pairs_per_expert * E) {
+    } else if (P >= m->moe_tile_min_pairs_per_expert * Eg) {
         // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
         const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
-        FH_TRY(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
+        FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
         FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks64, 64, K, 1, s));
         FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks64, 64, 1, 0, s));
-    } else if (P >= m->moe_tile32_min_pairs_per_expert * E) {
+    } else if (P >= m->moe_tile32_min_pairs_per_expert * Eg) {
         // a few hundred tokens (a fresh prompt riding along with the decode batch, a lone short prefill: 8–31 pairs
         // per expert): 32-row blocks through the LDS-tiled kernel — every expert's weights about once instead of
         // once per 16 pairs
         const int sorted_max32 = P + E * 32, max_blocks32 = std::min(sorted_max32 / 32, P / 32 + std::min(P, E));
-        FH_TRY(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 32, sorted_max32, s));
+        FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 32, sorted_max32, s));
         FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks32, 32, K, 1, s));
         FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks32, 32, 1, 0, s));
     } else {
-        FH_TRY(moe_align_block_size(m->expert_ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
+        FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
         FH_TRY(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                         max_blocks, K, 1, s));
         FH_TRY(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
@@ -983,7 +1013,24 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             const int tiles = (E + 15) / 16;
             int Q = m->route_parts;
             while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
-            const bool tp = c.tp_world > 1;   // attention heads sharded, o_proj row-parallel: all-reduce before the add + norm + route kernel
+            // attention heads sharded, o_proj row-parallel: all-reduce before the add + norm + route kernel (expert_parallel 2 keeps
+            // attention replicated: full heads on every rank, nothing to reduce there)
+            const bool tp = c.tp_world > 1 && c.expert_parallel != 2;
+            const bool ep = c.expert_parallel != 0;
+            // expert parallel: after routing, the pair ids become local ids (−1 = another rank's expert)
+            auto after_route = [&]() -> int {
+                return ep ? moe_remap_expert_ids(m->expert_ids, m->expert_ids_local, P, m->ep_e0, m->ep_E, s) : 0;
+            };
+            // the layer tail: residual_out = residual_in + Σ_k w_k·down_k, then the next input norm.  Expert parallel: the sum over
+            // the rank's own experts is a partial [T, H] that meets the other ranks' in the all-reduce a dense MLP uses, and the
+            // reduced row then enters the residual like a single expert row of weight 1 (the same kernel, top_k = 1)
+            auto moe_tail = [&](const __half* res_in, __half* res_out) -> int {
+                if (!ep)
+                    return moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, K, H, s);
+                if (int rc_ = moe_combine_local_f16(m->moe_down, m->expert_w, m->expert_ids_local, m->mlp_out, T, K, H, s)) return rc_;
+                if (int rc_ = tp_all_reduce(m, m->mlp_out, (size_t)T * H)) return rc_;
+                return moe_combine_add_rms_norm_f16(m->mlp_out, m->ones, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, 1, H, s);
+            };
             const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && Q >= 1 && tiles / Q <= 8 && !L.o.perm;
             const bool o_quant = L.o.qw != nullptr;           // the slab forms are INT4 kernels; an unquantised o_proj takes the direct GEMM
             if (decode_fast) {
@@ -992,7 +1039,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 int S = m->o_slabs, rows_pad = 0, n_pad = 0;
                 if (tp || !o_quant) {
                     RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
-                    RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+                    if (tp) RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                     S = 0;
                 } else if (S > 0 && T > 16 && T <= 32 && !L.o.bias) {
                     // 17–32 rows: activations staged once per workgroup in LDS (a wave fetching its own fragments pulls 2× the
@@ -1015,22 +1062,22 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                                                            n_pad, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K, Q,
                                                            m->route_cand, m->route_stats, m->route_arrive, c.norm_topk_prob,
                                                            m->expert_ids, m->expert_w, nullptr, T, H, s));
+                    RUN(after_route());
                     RUN(moe_decode_gemms(m, L, P, max_blocks, s));
-                    if (T <= m->fuse_tail_max_rows && next_ln && !m->taps_enabled &&
+                    if (T <= m->fuse_tail_max_rows && next_ln && !m->taps_enabled && !ep &&
                         w4_gemm_dense_can_fuse_combine_norm(m->layers[li + 1].qkv, T)) {
                         tail = FusedCombineNorm{m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps, K};
                         pending_tail = true;
                     } else {
-                        RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps,
-                                                         m->norm_out, T, K, H, s));
+                        RUN(moe_tail(m->residual2, m->residual));
                     }
                 } else {
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, m->o_out, slabs, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
                                                            c.rms_eps, m->norm_out, L.router, E, K, c.norm_topk_prob, m->expert_ids,
                                                            m->expert_w, nullptr, T, H, s));
+                    RUN(after_route());
                     RUN(moe_decode_gemms(m, L, P, max_blocks, s));
-                    RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
-                                                     m->norm_out, T, K, H, s));
+                    RUN(moe_tail(m->residual, m->residual));
                 }
             } else if (T >= 64 && T < m->route_gemm_min_tokens && !tp && o_quant && !L.o.perm && !L.o.bias && m->o_slabs > 0) {
                 // short prefill / a prompt riding along with the decode batch: o_proj as fp32 split-K slabs straight into the
@@ -1040,12 +1087,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 RUN(fused_add_rms_norm_route_slabs_f16(m->residual, m->o_out, m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
                                                        c.rms_eps, m->norm_out, L.router, E, K, c.norm_topk_prob, m->expert_ids,
                                                        m->expert_w, nullptr, T, H, s));
+                RUN(after_route());
                 RUN(moe_batch_gemms(m, L, P, sorted_max, max_blocks, s));
-                RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
-                                                 m->norm_out, T, K, H, s));
+                RUN(moe_tail(m->residual, m->residual));
             } else {
                 RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
-                RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
+                if (tp) RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                 form_hit(T >= m->route_gemm_min_tokens ? FORM_ROUTE_GEMM : FORM_ROUTE_FUSED);
                 if (T >= m->route_gemm_min_tokens) {
                     // prefill: one workgroup per token would pull the whole router (E·H·2 B) from L2 per token (2048 tokens:
@@ -1058,9 +1105,9 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,
                                                      c.norm_topk_prob, m->expert_ids, m->expert_w, nullptr, T, H, s));
                 }
+                RUN(after_route());
                 RUN(moe_batch_gemms(m, L, P, sorted_max, max_blocks, s));
-                RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual, m->residual, next_ln, c.rms_eps,
-                                                 m->norm_out, T, K, H, s));
+                RUN(moe_tail(m->residual, m->residual));
             }
         } else {
             const int I = c.intermediate;
@@ -1423,11 +1470,12 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     FH_CHECK_HIP(hipEventCreate(&e0));
     FH_CHECK_HIP(hipEventCreate(&e1));
     int blocks = 0;
-    const int P = T * std::max(c.top_k, 1), E = c.num_experts;
+    const int P = T * std::max(c.top_k, 1), E = c.num_experts > 0 ? m->ep_E : 0;
+    const int32_t* eids = moe_ids(m);
     if (E > 0 && which < 2) {
         FH_REQUIRE(P <= 1024, "time_kernel: MoE timing uses the decode (inline-align) path, pairs=%d > 1024", P);
         std::vector<int32_t> ids(P);
-        FH_CHECK_HIP(hipMemcpyAsync(ids.data(), m->expert_ids, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+        FH_CHECK_HIP(hipMemcpyAsync(ids.data(), eids, (size_t)P * 4, hipMemcpyDeviceToHost, s));
         FH_CHECK_HIP(hipStreamSynchronize(s));
         std::vector<int> cnt(E, 0);
         for (int v : ids) if (v >= 0 && v < E) cnt[v]++;
@@ -1437,17 +1485,17 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     FH_REQUIRE(T <= c.max_tokens, "time_kernel: %d rows > max_tokens %d", T, c.max_tokens);
     const int max_blocks = E > 0 ? std::min((P + E * 16) / 16, P / 16 + std::min(P, E)) : 0;
     int launches = 0, rc = 0;
-    const bool em = E > 0 && m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * E;   // as moe_decode_gemms
+    const bool em = E > 0 && m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts;   // as moe_decode_gemms
     auto one = [&](int li) -> int {
         LayerWeights& L = m->layers[li];
         switch (which) {
         case 0: {
-            if (em) return w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, c.top_k, 1, s);
-            return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, m->expert_ids, E, P, max_blocks, c.top_k, 1,
+            if (em) return w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, eids, E, P, c.top_k, 1, s);
+            return w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, eids, E, P, max_blocks, c.top_k, 1,
                                             m->sorted_ids, m->block_ids, m->total_post_pad, s);
         }
         case 1:
-            if (em) return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, m->expert_ids, E, P, 1, 0, s);
+            if (em) return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, eids, E, P, 1, 0, s);
             return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
         case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),
                                                           idx<uint32_t>(m, m->il.kv_lens), T, max_kv_len, c.num_heads, c.num_kv_heads,

@@ -20,7 +20,8 @@ class ModelConfig(C.Structure):
         ("rms_eps", C.c_float), ("_pad", C.c_float), ("rope_theta", C.c_double), ("rope_p0", C.c_double),
         ("rope_p1", C.c_double), ("rope_p2", C.c_double), ("rope_p3", C.c_double), ("tp_rank", C.c_int32),
         ("tp_world", C.c_int32), ("sliding_window_pattern", C.c_int32), ("sandwich_norms", C.c_int32),
-        ("embed_scale", C.c_float), ("_pad2", C.c_float), ("rope_local_theta", C.c_double)]
+        ("embed_scale", C.c_float), ("_pad2", C.c_float), ("rope_local_theta", C.c_double), ("expert_parallel", C.c_int32),
+        ("vocab_parallel", C.c_int32)]
 
 
 class BatchItem(C.Structure):

@@ -402,6 +402,14 @@ typedef struct {
     float embed_scale;            /* 0 = none; else embedding rows × this (Gemma: bf16-rounded √hidden) */
     float _pad2;
     double rope_local_theta;      /* 0 = one table; else θ of the unscaled table the local layers use */
+    /* Beyond the reference (its MoE config is not sharded, README.md:242, is_ep = 0), with tp_world > 1:
+     * expert_parallel 1 = experts sharded over the ranks (rank r owns experts [r·E/N, (r+1)·E/N); router replicated; each rank
+     * runs the grouped GEMMs of its own experts and the partial MoE outputs meet in the same [T, H] all-reduce a dense MLP
+     * uses) on top of tensor-parallel attention (num_heads / num_kv_heads are per-rank values, all-reduce after o_proj);
+     * 2 = experts sharded, attention replicated (full head counts on every rank, no all-reduce after o_proj — for world
+     * sizes the kv heads do not divide).  vocab_parallel 1 = lm_head rows sharded; per-rank argmax pairs are gathered. */
+    int32_t expert_parallel;
+    int32_t vocab_parallel;
 } FerrumHipModelConfig;
 
 /* One item of a UnifiedBatch (model_executor.rs:354-386). */

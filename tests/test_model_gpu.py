@@ -585,29 +585,38 @@ def _load_tp(pkg):
     return tp
 
 
-def _tp_rank_models(pkg, tm, world, **model_kw):
-    """The `world` rank models of a dense TinyModel: per-rank config (heads, kv heads and intermediate divided by world) and
+def _tp_rank_models(pkg, tm, world, expert_parallel=0, **model_kw):
+    """The `world` rank models of a TinyModel: per-rank config (heads, kv heads and intermediate divided by world) and
     Megatron-style GPTQ shards from tp.py — column-parallel qkv / gate_up, row-parallel o / down, everything else replicated
-    (tensor_parallel.rs:148-340)."""
+    (tensor_parallel.rs:148-340).  MoE models (expert_parallel 1 or 2): every rank is offered every expert and keeps its own
+    E / world of them; with expert_parallel = 2 attention stays whole on every rank."""
     tp = _load_tp(pkg)
     c = tm.cfg
     nq, nkv, hd, I = c["num_heads"], c["num_kv_heads"], c["head_dim"], c["intermediate"]
     qd, kvd = nq * hd, nkv * hd
+    attn_world = 1 if expert_parallel == 2 else world                 # ranks the attention heads are split over
     ranks = []
     for r in range(world):
-        cfg = dict(c, num_heads=nq // world, num_kv_heads=nkv // world, intermediate=I // world, tp_rank=r, tp_world=world)
+        cfg = dict(c, num_heads=nq // attn_world, num_kv_heads=nkv // attn_world, intermediate=I // world, tp_rank=r, tp_world=world,
+                   expert_parallel=expert_parallel)
         m = pkg.HipModel(group_size=128, **model_kw, **cfg)
         for name, data in tm.glob.items():
             m.set_global(name, data)
         for li, L in enumerate(tm.layers):
             for name, data in L["dense"].items():
                 m.set_layer_dense(li, name, data)
+            ar = r if attn_world > 1 else 0
             k, n, qw, sc, qz = L["gptq"]["qkv"]
-            sh = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [qd, kvd, kvd], r, world)
+            sh = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [qd, kvd, kvd], ar, attn_world)
             m.set_gptq(li, "qkv", *sh, k, sh[0].shape[1])
             k, n, qw, sc, qz = L["gptq"]["o"]
-            sh = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, r, world)
-            m.set_gptq(li, "o", *sh, k // world, n)
+            sh = tp.shard_gptq_rows(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), k, 128, ar, attn_world)
+            m.set_gptq(li, "o", *sh, k // attn_world, n)
+            if L["experts"]:
+                for e, d in L["experts"].items():                 # offered to every rank: the runner keeps its own range
+                    for name, (k, n, qw, sc, qz) in d.items():
+                        m.set_gptq(li, name, qw, sc, qz, k, n, expert=e)
+                continue
             k, n, qw, sc, qz = L["gptq"]["gate_up"]
             sh = tp.shard_gptq_columns(qw.reshape(k // 8, n), sc.reshape(k // 128, n), qz.reshape(k // 128, n // 8), [I, I], r, world)
             m.set_gptq(li, "gate_up", *sh, k, sh[0].shape[1])
@@ -803,6 +812,107 @@ def test_tp2_gemma27b_shards_graph_decode_with_oneshot_allreduce(pkg, forms, kno
         assert np.max(np.abs(ref[1][i] - one[0][1][i])) < 1e-2 * np.max(np.abs(ref[1][i]))
     same = sum(int(ref[0][i]) == int(one[0][0][i]) and np.array_equal(ref[2][:, i], one[0][2][:, i]) for i in range(c))
     assert same >= c - 1, same
+
+
+@pytest.mark.parametrize("mode,world", [(1, 2), (2, 2), (2, 4)])
+def test_expert_parallel_matches_single_gpu(pkg, forms, mode, world):
+    """Expert parallelism (not in the reference, whose MoE config is unsharded): experts split over the
+    ranks, router replicated, the partial MoE outputs meet in the [T, H] all-reduce; mode 1 on top of tensor-parallel attention,
+    mode 2 with attention replicated.  Rank models on threads; two ranks meet in the one-shot peer all-reduce inside the
+    per-rank decode hipGraph, four ranks in the host-barrier loopback (eager) — four spinning ranks of ONE process would share
+    the process's hardware queues (one process per rank, as in tools/tp_rehearsal.py, has no such limit).  Prefill (the grouped
+    GEMM forms see only local pairs) and free-running greedy decode against the unsharded model."""
+    import ctypes as C
+    from tests import modelgen
+    tm = modelgen.TinyModel(True, layers=3, hidden=256, nq=4, nkv=2, hd=128, experts=8, top_k=2, expert_inter=128, seed=171)
+    mk = dict(kv_num_blocks=40, max_seqs=8, max_tokens=256)
+    full = tm.hip_model(pkg, **mk)
+    rng = np.random.default_rng(172)
+    V = tm.cfg["vocab"]
+    prompts = [rng.integers(0, V, size=n).astype(np.uint32) for n in (70, 9, 33, 5, 17)]
+    ids, steps = list(range(len(prompts))), 10
+
+    def drive(_r, m):
+        toks, lg = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        return np.array(toks), lg.copy(), m.decode_steps(ids, toks, steps)
+
+    ref = drive(0, full)
+    ranks = _tp_rank_models(pkg, tm, world, expert_parallel=mode, **mk)
+    assert ranks[0].cfg.num_heads == (4 // world if mode == 1 else 4)
+    lib, lb, comms = pkg.load_library(), None, []
+    if world == 2:
+        comms = pkg.Comm.local_group(world, 1 << 20)
+        for m, cm in zip(ranks, comms):
+            m.set_comm(cm)
+    else:
+        lb = C.c_void_p()
+        assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
+        for m in ranks:
+            assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
+    forms.reset()
+    res = _run_ranks(ranks, drive)
+    if world == 2:
+        forms.require("tp_allreduce_oneshot", "graph_replay")
+    else:
+        forms.require("tp_allreduce_loopback")
+    for cm in comms:
+        assert cm.oneshot_status()["timeouts"] == 0
+    for r in range(1, world):
+        for a_, b_ in zip(res[0], res[r]):
+            assert np.array_equal(a_, b_), r                     # ranks agree bit for bit
+    if lb is not None:
+        del ranks
+        lib.ferrum_hip_tp_loopback_destroy(lb)
+    for i in range(len(prompts)):
+        assert modelgen.cosine(ref[1][i], res[0][1][i]) > 0.9999, i
+        assert np.max(np.abs(ref[1][i] - res[0][1][i])) < 1e-2 * np.max(np.abs(ref[1][i])), i
+    assert np.array_equal(ref[0], res[0][0])                     # prefill ids equal to the unsharded model
+    same = sum(np.array_equal(ref[2][:, i], res[0][2][:, i]) for i in range(len(prompts)))
+    assert same >= len(prompts) - 1, same                        # free-running decode: whole histories (one near-tie flip allowed)
+
+
+def test_expert_parallel_qwen3_30b_dims(pkg, forms):
+    """Qwen3-30B-A3B's real layer dimensions (128 experts top-8, expert-I 768, H 2048, 32/4 heads) as a 4-rank expert-parallel
+    group on top of tensor-parallel attention (32 experts, 8 query heads and ONE kv head per rank): a 24-token-per-sequence
+    prefill and three decode steps of 32 rows (expert-major grouped GEMM over the rank's 32 experts), teacher-forced on the
+    unsharded model's ids; host-barrier loopback (eager)."""
+    import ctypes as C
+    tm = _bench_dims_model("qwen3-30b-a3b")
+    world, c, plen, steps = 4, 32, 24, 3
+    mk = dict(kv_num_blocks=c * 3 + 4, max_seqs=c, max_tokens=c * plen)
+    full = tm.hip_model(pkg, **mk)
+    lib = pkg.load_library()
+    lb = C.c_void_p()
+    assert lib.ferrum_hip_tp_loopback_create(C.byref(lb), world) == 0
+    ranks = _tp_rank_models(pkg, tm, world, expert_parallel=1, **mk)
+    assert (ranks[0].cfg.num_heads, ranks[0].cfg.num_kv_heads) == (8, 1)
+    for m in ranks:
+        assert lib.ferrum_hip_model_tp_attach_loopback(m.h, lb) == 0
+    rng = np.random.default_rng(173)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    ref = []
+    toks, lg = full.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    ref.append((np.array(toks), lg.copy()))
+    for s in range(steps):
+        toks, lg = full.unified_forward([(i, [int(ref[-1][0][i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+        ref.append((np.array(toks), lg.copy()))
+
+    def drive(_r, m):
+        out = []
+        toks, lg = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        out.append((np.array(toks), lg.copy()))
+        for s in range(steps):
+            toks, lg = m.unified_forward([(i, [int(ref[s][0][i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+            out.append((np.array(toks), lg.copy()))
+        return out
+
+    forms.reset()
+    res = _run_ranks(ranks, drive)
+    forms.require("tp_allreduce_loopback", "moe_expert_major", "route_split")
+    flips = _tp_vs_single(tm, full, {"ranks": res, "ref": ref}, c, steps, "qwen3-ep4")
+    assert flips <= 2, flips                                     # 128 sampled rows
+    del ranks
+    lib.ferrum_hip_tp_loopback_destroy(lb)
 
 
 def test_greedy_policy_with_token_mask_and_repetition_penalty(pkg):
