@@ -55,7 +55,16 @@ def shard_cfg(cfg, world, rank):
     """Per-rank config of a tensor-parallel group (tensor_parallel.rs:209-262): query heads, kv heads and the MLP
     intermediate are divided by the world size; hidden, vocabulary and norms are replicated."""
     d = dict(cfg)
-    if world > 1:
+    if world > 1 and d["num_experts"] > 0:
+        # MoE (beyond the reference, which does not shard this config): experts split over the ranks; attention tensor-parallel
+        # when the kv heads divide (expert_parallel 1), else replicated on every rank (2)
+        assert d["num_experts"] % world == 0, f"num_experts={d['num_experts']} not divisible by {world}"
+        mode = 1 if d["num_kv_heads"] % world == 0 else 2
+        if mode == 1:
+            d["num_heads"] //= world
+            d["num_kv_heads"] //= world
+        d.update(tp_rank=rank, tp_world=world, expert_parallel=mode)
+    elif world > 1:
         for k in ("num_heads", "num_kv_heads", "intermediate"):
             assert d[k] % world == 0, f"{k}={d[k]} not divisible by tp={world}"
             d[k] //= world
@@ -291,7 +300,8 @@ def tp_decode_case(pkg, torch, dist, model_name, world, rank, c, PL, steps, warm
            "allreduce": ("none (TP=1)" if world == 1 else
                          "one-shot peer reduce over hipIpc buffers (rank-ordered fp32 sum), captured in the per-rank decode hipGraph" if transport == "oneshot"
                          else "RCCL ncclAllReduce fp16, in place, captured in the per-rank decode hipGraph"),
-           "per_rank_shapes": {"num_heads": cfg["num_heads"], "num_kv_heads": cfg["num_kv_heads"], "intermediate": cfg["intermediate"]}}
+           "per_rank_shapes": {"num_heads": cfg["num_heads"], "num_kv_heads": cfg["num_kv_heads"], "intermediate": cfg["intermediate"],
+                               **({"experts": cfg["num_experts"] // world, "expert_parallel": cfg.get("expert_parallel", 0)} if cfg["num_experts"] else {})}}
     if world > 1:
         # every rank must have sampled the same ids (identical all-reduced activations, replicated lm_head)
         chk = torch.tensor([int(np.asarray(out, np.int64).sum() % (1 << 31))], dtype=torch.int64, device=_dist_dev(dist))
@@ -589,6 +599,12 @@ def main():
                                       try_oneshot=args.tp_oneshot, transport=args.tp_transport))
         extra["tp_scaling"] = tps
         extra["rccl_ranks"] = world if world > 1 else 0
+        if world > 1:
+            # beyond the reference: the headline model as ONE expert-parallel group of all ranks — experts
+            # sharded, partial MoE outputs all-reduced — next to the replica headline above
+            stage(f"ep_scaling qwen3-30b-a3b x{world}")
+            extra["ep_scaling"] = tp_decode_case(pkg, torch, dist, "qwen3-30b-a3b", world, rank, c, PL, min(K, 32), min(W, 4) if W else 2, 2048,
+                                                 try_oneshot=False, transport=args.tp_transport)
         num_layers_run = cfg["num_layers"]
     else:
         num_layers_run = model.cfg.num_layers

@@ -1010,3 +1010,5 @@ def test_multi_process_tensor_parallel_rehearsal_over_hipipc(pkg, world):
     tp = d["tp_decode"]
     assert tp["tp"] == world and tp["ranks_agree_on_ids"] and tp["oneshot_timeouts"] == 0 and tp["oneshot_epochs"] > 0, tp
     assert tp["per_rank_shapes"]["num_kv_heads"] == 8 // world and tp["tok_s"] > 0
+    ep = d["ep_decode"]                                           # Qwen3-30B-A3B dims as one expert-parallel group
+    assert ep["ranks_agree_on_ids"] and ep["oneshot_timeouts"] == 0 and ep["per_rank_shapes"]["experts"] == 128 // world, ep

@@ -8,7 +8,8 @@ takes with `--tp-transport oneshot`, minus the fabric.  Checks, and prints one J
   1. ferrum_hip_all_reduce_f16 on 4 … 1 Mi fp16 elements, eagerly and from a captured + replayed hipGraph, against the
      rank-ordered fp32 sum of the gathered inputs (bit-exact), 40 calls back to back (buffer parity / epoch logic);
   2. the bench's own tensor-parallel decode case (per-rank synthetic shards of a dense model, per-rank hipGraph with the
-     all-reduces inside): every rank must sample the same ids, no rank may count a one-shot timeout.
+     all-reduces inside): every rank must sample the same ids, no rank may count a one-shot timeout;
+  3. the same for the MoE model as one expert-parallel group (experts sharded over the ranks).
 """
 import json
 import os
@@ -79,6 +80,10 @@ def main():
                                c=int(os.environ.get("FERRUM_REHEARSAL_C", "20")), PL=48, steps=8, warm=2, chunk=96,
                                try_oneshot=False, transport="oneshot", layers=int(os.environ.get("FERRUM_REHEARSAL_LAYERS", "3")))
     out["tp_decode"] = res
+    # 3. the MoE model as one expert-parallel group (experts sharded, partial MoE outputs all-reduced)
+    if 128 % world == 0:
+        out["ep_decode"] = bench.tp_decode_case(pkg, torch, dist, "qwen3-30b-a3b", world, rank, c=16, PL=48, steps=8, warm=2, chunk=96,
+                                                try_oneshot=False, transport="oneshot", layers=3)
     if rank == 0:
         print(json.dumps(out))
     dist.destroy_process_group()
