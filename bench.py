@@ -63,13 +63,13 @@ def shard_cfg(cfg, world, rank):
         if mode == 1:
             d["num_heads"] //= world
             d["num_kv_heads"] //= world
-        d.update(tp_rank=rank, tp_world=world, expert_parallel=mode)
+        d.update(tp_rank=rank, tp_world=world, expert_parallel=mode, vocab_parallel=1)
     elif world > 1:
         for k in ("num_heads", "num_kv_heads", "intermediate"):
             assert d[k] % world == 0, f"{k}={d[k]} not divisible by tp={world}"
             d[k] //= world
         assert (d["intermediate"] % 128) == 0 and (d["num_heads"] * d["head_dim"]) % 128 == 0, "row-parallel shards must cut on quant groups"
-        d.update(tp_rank=rank, tp_world=world)
+        d.update(tp_rank=rank, tp_world=world, vocab_parallel=1)     # lm_head rows sharded too: per-rank argmax pairs are gathered
     return d
 
 

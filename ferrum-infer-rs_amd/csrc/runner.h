@@ -88,6 +88,10 @@ struct FerrumHipModel {
     int ep_e0 = 0, ep_E = 0;
     int32_t* expert_ids_local = nullptr;  // [T·k] expert id − ep_e0 for the rank's own experts, −1 for the others
     float* ones = nullptr;                // [max_tokens] 1.0f: the all-reduced MoE output enters the residual like one more "expert row"
+    // vocabulary-parallel lm_head (cfg.vocab_parallel, tp_world > 1): this rank scores vocabulary rows [vp_v0, vp_v0 + vp_n)
+    int vp_v0 = 0, vp_n = 0;
+    void* vp_pairs = nullptr;             // [max_seqs] (local winner's logit, global id)
+    void* vp_gathered = nullptr;          // [world][max_seqs]
     float* router_logits = nullptr;
     int32_t *expert_ids = nullptr, *sorted_ids = nullptr, *block_ids = nullptr, *total_post_pad = nullptr;
     float* expert_w = nullptr;

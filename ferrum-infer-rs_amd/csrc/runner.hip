@@ -218,6 +218,24 @@ int loopback_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
     return 0;
 }
 
+// small all-gather through the host-barrier loopback (tests): out[world][bytes] in rank order
+int loopback_all_gather(FerrumHipModel* m, const void* in, void* out, size_t bytes) {
+    FerrumHipTpLoopback* lb = m->tp_loopback;
+    FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    { std::lock_guard<std::mutex> lk(lb->mu); lb->bufs[m->cfg.tp_rank] = reinterpret_cast<const __half*>(in); }
+    lb->barrier();
+    for (int p = 0; p < lb->world; p++)
+        FH_CHECK_HIP(hipMemcpyAsync((uint8_t*)out + (size_t)p * bytes, lb->bufs[p], bytes, hipMemcpyDeviceToDevice, m->stream));
+    FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+    lb->barrier();
+    return 0;
+}
+int tp_all_gather(FerrumHipModel* m, const void* in, void* out, size_t bytes) {
+    if (m->tp_loopback) { form_hit(FORM_TP_ALLREDUCE_LOOPBACK); return loopback_all_gather(m, in, out, bytes); }
+    FH_REQUIRE(m->comm, "vocabulary parallel: no communicator (ferrum_hip_model_tp_init / ferrum_hip_model_set_comm)");
+    return comm_all_gather_bytes(m->comm, in, out, bytes, m->stream);
+}
+
 int tp_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
     if (m->cfg.tp_world <= 1) return 0;
     if (m->tp_loopback) { form_hit(FORM_TP_ALLREDUCE_LOOPBACK); return loopback_all_reduce(m, buf, count); }
@@ -264,6 +282,13 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     m->cfg = *cfg;
     if (m->cfg.tp_world < 1) { m->cfg.tp_world = 1; m->cfg.tp_rank = 0; }
     if (m->cfg.tp_world == 1) { m->cfg.expert_parallel = 0; m->cfg.vocab_parallel = 0; }
+    m->vp_n = m->cfg.vocab;
+    if (m->cfg.vocab_parallel) {
+        const int per = (cdiv(m->cfg.vocab, m->cfg.tp_world) + 15) / 16 * 16;       // whole 16-row tiles per rank
+        m->vp_v0 = std::min(m->cfg.vocab, m->cfg.tp_rank * per);
+        m->vp_n = std::min(m->cfg.vocab, m->vp_v0 + per) - m->vp_v0;
+        FH_REQUIRE(m->vp_n > 0, "model_create: vocab_parallel leaves rank %d of %d without vocabulary rows (V=%d)", m->cfg.tp_rank, m->cfg.tp_world, m->cfg.vocab);
+    }
     m->ep_E = m->cfg.num_experts;
     if (m->cfg.expert_parallel) {
         m->ep_E = m->cfg.num_experts / m->cfg.tp_world;
@@ -329,7 +354,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
                     (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
                     (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch, (void*)m->greedy_opts_dev, (void*)m->tp_tmp,
-                    (void*)m->expert_ids_local, (void*)m->ones})
+                    (void*)m->expert_ids_local, (void*)m->ones, m->vp_pairs, m->vp_gathered})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
     if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -547,8 +572,9 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     // dense fp16 weights that are streamed every step → fragment-major tiles (f16t)
     {
         const __half* head = m->lm_head ? m->lm_head : m->embed;     // tied lm_head (llama_family.rs:969-1001)
-        FH_CHECK_HIP(hipMalloc((void**)&m->lm_head_t, f16t_elems(c.vocab, c.hidden) * 2));
-        if (int rc = f16t_repack(head, m->lm_head_t, c.vocab, c.hidden, m->stream)) return rc;
+        // vocabulary parallel: only this rank's rows [vp_v0, vp_v0 + vp_n) become tiles
+        FH_CHECK_HIP(hipMalloc((void**)&m->lm_head_t, f16t_elems(m->vp_n, c.hidden) * 2));
+        if (int rc = f16t_repack(head + (size_t)m->vp_v0 * c.hidden, m->lm_head_t, m->vp_n, c.hidden, m->stream)) return rc;
         if (m->lm_head) {
             FH_CHECK_HIP(hipStreamSynchronize(m->stream));
             (void)hipFree(m->lm_head);
@@ -587,7 +613,11 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     rc |= dev_alloc(&m->o_out, T * H);
     rc |= dev_alloc(&m->mlp_out, T * H);
     rc |= dev_alloc(&m->sampled_hidden, S * H);
-    rc |= dev_alloc(&m->logits, S * (size_t)c.vocab);
+    rc |= dev_alloc(&m->logits, S * (size_t)m->vp_n);
+    if (c.vocab_parallel) {
+        FH_CHECK_HIP(hipMalloc(&m->vp_pairs, S * 8));
+        FH_CHECK_HIP(hipMalloc(&m->vp_gathered, S * 8 * (size_t)c.tp_world));
+    }
     rc |= dev_alloc(&m->out_tokens, S);
     if (c.num_experts > 0) {
         const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 64;   // room for 64-row blocks (prefill)
@@ -1211,9 +1241,10 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         } else {
             RUN(gather_rms_norm_f16(m->residual, sampled_idx, m->final_norm, c.rms_eps, m->sampled_hidden, sh.num_sampled, H, s));
         }
-        RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, c.vocab, H, m->workspace,
+        const int Vn = m->vp_n, v0 = m->vp_v0;                  // this rank's vocabulary rows (all of them unless vocabulary parallel)
+        RUN(f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, sh.num_sampled, Vn, H, m->workspace,
                              m->workspace_bytes, s));
-        if (greedy) {
+        if (greedy && !c.vocab_parallel) {
             // LogitsReturnPolicy::GreedyArgmax { token_mask, repetition_penalty } (model_executor.rs:109-150): the sparse
             // penalty rewrites the listed logits in place, then raw or masked argmax (traits.rs:1571-1591)
             if (gopts && gopts->row_offsets)
@@ -1221,6 +1252,20 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                                                           sh.num_sampled, c.vocab, s));
             RUN(argmax_rows_f32_ws_advance(m->logits, m->out_tokens, gopts ? gopts->mask : nullptr, gopts ? gopts->mask_len : 0,
                                            sh.num_sampled, c.vocab, m->workspace, m->workspace_bytes, advance, advance_fused, s));
+        } else if (greedy) {
+            // vocabulary parallel: penalty and mask act on the rank's slice (ids / mask bytes shifted by v0), the local first
+            // maximum becomes a (logit, global id) pair, the pairs of all ranks are gathered and the first maximum in rank
+            // order wins — the lowest id among equal logits, as on one GPU.  The merge also advances the decode state.
+            if (gopts && gopts->row_offsets)
+                RUN(apply_repetition_penalties_sparse_f32_shard(m->logits, gopts->row_offsets, gopts->token_ids, gopts->penalties,
+                                                                sh.num_sampled, Vn, v0, s));
+            const uint8_t* mask = gopts && gopts->mask ? gopts->mask + std::min(v0, gopts->mask_len) : nullptr;
+            const int mask_len = gopts && gopts->mask ? std::max(0, gopts->mask_len - v0) : 0;
+            RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, mask, mask_len, sh.num_sampled, Vn, m->workspace, m->workspace_bytes, s));
+            RUN(argmax_pairs_f32(m->logits, m->out_tokens, m->vp_pairs, sh.num_sampled, Vn, v0, s));
+            RUN(tp_all_gather(m, m->vp_pairs, m->vp_gathered, (size_t)sh.num_sampled * 8));
+            RUN(argmax_merge_ranks(m->vp_gathered, m->out_tokens, sh.num_sampled, c.tp_world, advance, s));
+            if (advance && advance_fused) *advance_fused = 1;
         }
     }
 #undef RUN
@@ -1230,6 +1275,13 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
 }  // namespace
 
 extern "C" {
+
+int ferrum_hip_model_local_vocab(const FerrumHipModel* m, int* vocab_start, int* vocab_count) {
+    FH_REQUIRE(m, "model_local_vocab: null");
+    if (vocab_start) *vocab_start = m->vp_v0;
+    if (vocab_count) *vocab_count = m->vp_n;
+    return 0;
+}
 
 int ferrum_hip_model_unified_forward(FerrumHipModel* m, const FerrumHipBatchItem* items, int num_items, int greedy,
                                      uint32_t* out_tokens, float* logits_out) {
@@ -1340,7 +1392,7 @@ int ferrum_hip_model_unified_forward_ex(FerrumHipModel* m, const FerrumHipBatchI
         if (greedy && out_tokens)
             FH_CHECK_HIP(hipMemcpyAsync(out_tokens, m->out_tokens, (size_t)sh.num_sampled * 4, hipMemcpyDeviceToHost, m->stream));
         if (logits_out)
-            FH_CHECK_HIP(hipMemcpyAsync(logits_out, m->logits, (size_t)sh.num_sampled * c.vocab * 4, hipMemcpyDeviceToHost, m->stream));
+            FH_CHECK_HIP(hipMemcpyAsync(logits_out, m->logits, (size_t)sh.num_sampled * m->vp_n * 4, hipMemcpyDeviceToHost, m->stream));
     }
     FH_CHECK_HIP(hipStreamSynchronize(m->stream));
     for (int i = 0; i < num_items; i++) m->seqs[items[i].seq_id].len += items[i].num_q_tokens;
@@ -1504,7 +1556,7 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
         case 4: return w4_gemm_dense(L.o, m->attn_out, m->o_out, T, m->workspace, m->workspace_bytes, s);
         case 6: return w4_gemm_dense(L.gate_up, m->norm_out, m->gate_up_out, T, m->workspace, m->workspace_bytes, s);
         case 7: return w4_gemm_dense(L.down, m->act_out, m->mlp_out, T, m->workspace, m->workspace_bytes, s);
-        case 5: return f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, T, c.vocab, H, m->workspace, m->workspace_bytes, s);
+        case 5: return f16t_gemm_f32out(m->sampled_hidden, m->lm_head_t, m->logits, T, m->vp_n, H, m->workspace, m->workspace_bytes, s);
         }
         fh::set_error("time_kernel: which=%d", which);
         return FERRUM_HIP_INVALID;

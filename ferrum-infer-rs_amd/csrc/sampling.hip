@@ -208,17 +208,65 @@ int argmax_rows_f32(const float* logits, uint32_t* out_ids, const uint8_t* valid
     return 0;
 }
 
+// ── vocabulary-parallel greedy sampling ─────────────────────────────────────
+// Every rank holds the logits of its own vocabulary rows [v0, v0 + n_local) and has taken its local argmax (first maximum).
+// pairs[row] = (local winner's logit, GLOBAL id); after the all-gather the global winner is the first maximum over the ranks
+// in rank order — rank r's ids all lie below rank r+1's, so "strictly greater wins" keeps the lowest id among equal logits,
+// exactly the single-GPU tie-break (traits.rs:1547).
+__global__ void argmax_pairs_kernel(const float* __restrict__ logits, const uint32_t* __restrict__ local_ids, float2* __restrict__ pairs,
+                                    int rows, int n_local, int v0) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) {
+        const uint32_t id = local_ids[r];
+        pairs[r] = make_float2(logits[(long)r * n_local + id], __uint_as_float(id + (uint32_t)v0));
+    }
+}
+__global__ void argmax_merge_ranks_kernel(const float2* __restrict__ gathered, uint32_t* __restrict__ out, int rows, int world, DecodeAdvance adv) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = adv.tokens ? *adv.step_counter : 0;
+    if (r < rows) {
+        float best = -INFINITY;
+        uint32_t best_id = 0;
+        for (int p = 0; p < world; p++) {
+            const float2 v = gathered[(long)p * rows + r];
+            if (v.x > best || p == 0) { best = v.x; best_id = __float_as_uint(v.y); }
+        }
+        out[r] = best_id;
+        if (adv.tokens && r < adv.n) {
+            adv.tokens[r] = best_id;
+            adv.pos_offsets[r] += 1;
+            adv.kv_lens[r] += 1;
+            adv.history[(long)step * adv.n + r] = best_id;
+        }
+    }
+    __syncthreads();                                   // one block (rows ≤ 1024): every row has read `step`
+    if (adv.tokens && threadIdx.x == 0 && blockIdx.x == 0) *adv.step_counter = step + 1;
+}
+int argmax_pairs_f32(const float* logits, const uint32_t* local_ids, void* pairs, int rows, int n_local, int v0, hipStream_t s) {
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(argmax_pairs_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, logits, local_ids, (float2*)pairs, rows, n_local, v0);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+int argmax_merge_ranks(const void* gathered, uint32_t* out, int rows, int world, const DecodeAdvance* adv, hipStream_t s) {
+    if (rows <= 0) return 0;
+    FH_REQUIRE(rows <= 1024, "argmax_merge_ranks: %d rows > 1024", rows);
+    hipLaunchKernelGGL(argmax_merge_ranks_kernel, dim3(1), dim3(1024), 0, s, (const float2*)gathered, out, rows, world, adv ? *adv : DecodeAdvance());
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 // logits[row][id] = v > 0 ? v / p : v · p for every id listed for the row (caller de-duplicates,
 // as the reference host does: ferrum-interfaces/src/sampler.rs:327-345).
 template <typename T>
 __global__ void rep_penalty_kernel(T* __restrict__ logits, const uint32_t* __restrict__ row_offsets,
-                                   const uint32_t* __restrict__ token_ids, const float* __restrict__ penalties, int n) {
+                                   const uint32_t* __restrict__ token_ids, const float* __restrict__ penalties, int n, uint32_t id_offset = 0) {
     const int row = blockIdx.x;
     const uint32_t lo = row_offsets[row], hi = row_offsets[row + 1];
     const float pen = penalties[row];
     if (pen == 1.0f) return;
     for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-        uint32_t id = token_ids[i];
+        uint32_t id = token_ids[i] - id_offset;               // vocabulary shard: ids below the shard wrap to huge values and are skipped
         if (id >= (uint32_t)n) continue;
         float v = (float)logits[(long)row * n + id];
         logits[(long)row * n + id] = (T)(v > 0.f ? v / pen : v * pen);
@@ -236,6 +284,13 @@ int apply_repetition_penalties_sparse_f32(float* logits, const uint32_t* row_off
                                           const float* penalties, int m, int n, hipStream_t s) {
     if (m <= 0) return 0;
     hipLaunchKernelGGL(rep_penalty_kernel<float>, dim3(m), dim3(256), 0, s, logits, row_offsets, token_ids, penalties, n);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+int apply_repetition_penalties_sparse_f32_shard(float* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
+                                                const float* penalties, int m, int n_local, int v0, hipStream_t s) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(rep_penalty_kernel<float>, dim3(m), dim3(256), 0, s, logits, row_offsets, token_ids, penalties, n_local, (uint32_t)v0);
     FH_CHECK_LAUNCH();
     return 0;
 }

@@ -11,4 +11,6 @@ int comm_world(const FerrumHipComm* c);
 // fp16 sum all-reduce in place on `s`: one-shot peer kernel when the message fits and the policy picks it, else RCCL.
 int comm_all_reduce_f16(FerrumHipComm* c, __half* buf, size_t count, hipStream_t s);
 bool comm_oneshot_fits(const FerrumHipComm* c, size_t count);
+// small all-gather: `bytes` (multiple of 8) per rank → out[world][bytes] in rank order
+int comm_all_gather_bytes(FerrumHipComm* c, const void* in, void* out, size_t bytes, hipStream_t s);
 }  // namespace fh

@@ -148,6 +148,49 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_reduce_kernel(OneShotArgs 
     }
 }
 
+// One-shot all-gather of a small record per rank (≤ 64 KB; the per-row argmax pairs of a vocabulary-parallel lm_head): the
+// same buffers, flags, parity and epoch as the all-reduce above (one block, so it is its own last arriver).
+__global__ __launch_bounds__(256) void tp_oneshot_all_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long bytes,
+                                                                    uint8_t* const* peers, unsigned* state, long parity_bytes, int world,
+                                                                    int rank) {
+    const int tid = threadIdx.x;
+    const unsigned epoch = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int parity = (int)(epoch & 1u);
+    const unsigned token = epoch + 1u;
+    const long n8 = bytes / 8;
+    {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(in);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(peers[rank] + ONESHOT_FLAG_BYTES + (size_t)parity * parity_bytes);
+        for (long g = tid; g < n8; g += 256) __hip_atomic_store(&dst[g], src[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int timed_out;
+    if (tid == 0) timed_out = 0;
+    if (tid < world) __hip_atomic_store(oneshot_flag(peers[tid], parity, rank), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+    if (tid < world) {
+        const unsigned* f = oneshot_flag(peers[rank], parity, tid);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ONESHOT_SPIN_TICKS) { timed_out = 1; break; }
+        }
+    }
+    __syncthreads();
+    if (!timed_out)
+        for (int p = 0; p < world; p++) {
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(peers[p] + ONESHOT_FLAG_BYTES + (size_t)parity * parity_bytes);
+            unsigned long long* dst = reinterpret_cast<unsigned long long*>(out + (size_t)p * bytes);
+            for (long g = tid; g < n8; g += 256) dst[g] = __hip_atomic_load(&src[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    __syncthreads();
+    if (tid == 0) {
+        if (timed_out) __hip_atomic_fetch_add(&state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&state[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
 struct FerrumHipComm {
@@ -188,6 +231,28 @@ int comm_all_reduce_f16(FerrumHipComm* c, __half* buf, size_t count, hipStream_t
     // ncclFloat16 = 6, ncclSum = 0 (rccl.h); in place like nccl_comm.rs all_reduce_in_place
     const int rc = g_all_reduce(buf, buf, count, 6, 0, c->nccl, s);
     FH_REQUIRE(rc == 0, "ncclAllReduce failed: %d", rc);
+    form_hit(FORM_TP_ALLREDUCE_RCCL);
+    return 0;
+}
+
+// All-gather of `bytes` (a multiple of 8, small) per rank into out[world][bytes], rank order.
+int comm_all_gather_bytes(FerrumHipComm* c, const void* in, void* out, size_t bytes, hipStream_t s) {
+    if (!c || c->world <= 1) {
+        if (in != out && bytes) FH_CHECK_HIP(hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
+    FH_REQUIRE(bytes % 8 == 0, "all_gather: %zu bytes per rank must be a multiple of 8", bytes);
+    const bool fits = c->oneshot_ready && knobs().tp_oneshot != 0 && bytes <= c->parity_bytes && bytes <= (64u << 10);
+    if (fits && (knobs().tp_oneshot == 1 || c->nccl == nullptr)) {
+        hipLaunchKernelGGL(tp_oneshot_all_gather_kernel, dim3(1), dim3(256), 0, s, (const uint8_t*)in, (uint8_t*)out, (long)bytes, c->peers_dev,
+                           c->state, (long)c->parity_bytes, c->world, c->rank);
+        FH_CHECK_LAUNCH();
+        form_hit(FORM_TP_ALLREDUCE_ONESHOT);
+        return 0;
+    }
+    FH_REQUIRE(c->nccl && g_all_gather, "all_gather: the communicator has neither a fitting one-shot buffer nor an RCCL rank");
+    const int rc = g_all_gather(in, out, bytes, 0 /* ncclInt8 */, c->nccl, s);
+    FH_REQUIRE(rc == 0, "ncclAllGather failed: %d", rc);
     form_hit(FORM_TP_ALLREDUCE_RCCL);
     return 0;
 }
@@ -385,6 +450,21 @@ int ferrum_hip_tp_selftest(int count) {
         for (int i = 0; i < 2 && !graph_rc; i++)
             if (hipGraphLaunch(ge, s) != hipSuccess) { fh::set_error("tp_selftest: graph launch failed"); graph_rc = 1; }
     }
+    // the small all-gather of the vocabulary-parallel sampler through the same communicator (ncclAllGather, bytes as int8)
+    int gather_rc = 0;
+    if (!rc && !graph_rc) {
+        std::vector<uint8_t> gin(256), gout(256, 0);
+        for (int i = 0; i < 256; i++) gin[i] = (uint8_t)(i * 7 + 3);
+        uint8_t *gi = nullptr, *go = nullptr;
+        FH_CHECK_HIP(hipMalloc((void**)&gi, 256));
+        FH_CHECK_HIP(hipMalloc((void**)&go, 512));
+        FH_CHECK_HIP(hipMemcpyAsync(gi, gin.data(), 256, hipMemcpyHostToDevice, s));
+        gather_rc = comm_all_gather_bytes(c, gi, go, 256, s);      // 1-rank communicator: the rank's chunk lands at offset 0
+        (void)hipMemcpyAsync(gout.data(), go, 256, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(gi); (void)hipFree(go);
+        if (!gather_rc && memcmp(gin.data(), gout.data(), 256) != 0) { fh::set_error("tp_selftest: 1-rank all-gather changed the data"); gather_rc = 1; }
+    }
     (void)hipMemcpyAsync(back.data(), dev, (size_t)count * 2, hipMemcpyDeviceToHost, s);
     (void)hipStreamSynchronize(s);
     if (ge) (void)hipGraphExecDestroy(ge);
@@ -395,6 +475,7 @@ int ferrum_hip_tp_selftest(int count) {
     (void)hipFree(dev);
     if (rc) return rc;
     if (graph_rc) return graph_rc;
+    if (gather_rc) return gather_rc;
     FH_REQUIRE(memcmp(host.data(), back.data(), (size_t)count * 2) == 0, "tp_selftest: 1-rank all-reduce changed the data");
     return 0;
 }

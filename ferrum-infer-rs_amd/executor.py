@@ -337,7 +337,7 @@ class HipModel:
             arr[i] = BatchItem(sid, keep[i].ctypes.data_as(C.POINTER(C.c_uint32)), len(keep[i]), pos, int(fin), 0)
             n_final += int(bool(fin))
         toks = np.zeros(max(n_final, 1), np.uint32)
-        logits = np.zeros((max(n_final, 1), self.cfg.vocab), np.float32) if want_logits else None
+        logits = np.zeros((max(n_final, 1), self.local_vocab()[1]), np.float32) if want_logits else None   # this rank's slice when vocab_parallel
         opts, hold = None, []
         if token_mask is not None or repetition_penalties is not None:
             opts = GreedyOptions()
@@ -362,6 +362,12 @@ class HipModel:
             toks.ctypes.data_as(C.POINTER(C.c_uint32)),
             None if logits is None else logits.ctypes.data_as(C.POINTER(C.c_float))), "unified_forward")
         return (toks[:n_final] if greedy else None), (logits[:n_final] if logits is not None else None)
+
+    def local_vocab(self):
+        """(first vocabulary row, row count) this model scores: the whole vocabulary unless cfg.vocab_parallel."""
+        v0, n = C.c_int(), C.c_int()
+        _check(self.lib.ferrum_hip_model_local_vocab(self.h, C.byref(v0), C.byref(n)), "local_vocab")
+        return v0.value, n.value
 
     def decode_steps(self, seq_ids, first_tokens, steps):
         n = len(seq_ids)

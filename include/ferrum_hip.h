@@ -531,6 +531,9 @@ typedef struct {
     const uint32_t* penalty_token_ids;
     const float* penalties;                /* [num_sampled] */
 } FerrumHipGreedyOptions;
+/* With cfg.vocab_parallel, logits_out receives THIS RANK's vocabulary slice, [num_sampled, ferrum_hip_model_local_vocab()] packed
+ * (rows vocab_start … vocab_start + count of the full matrix); out_tokens are global ids, identical on every rank. */
+int ferrum_hip_model_local_vocab(const FerrumHipModel* model, int* vocab_start, int* vocab_count);
 int ferrum_hip_model_unified_forward_ex(FerrumHipModel* model, const FerrumHipBatchItem* items, int num_items, int greedy,
                                         const FerrumHipGreedyOptions* opts, uint32_t* out_tokens, float* logits_out);
 /* Steady-state decode: every listed sequence advances by one token (its last sampled token),

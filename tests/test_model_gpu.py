@@ -585,7 +585,7 @@ def _load_tp(pkg):
     return tp
 
 
-def _tp_rank_models(pkg, tm, world, expert_parallel=0, **model_kw):
+def _tp_rank_models(pkg, tm, world, expert_parallel=0, vocab_parallel=0, **model_kw):
     """The `world` rank models of a TinyModel: per-rank config (heads, kv heads and intermediate divided by world) and
     Megatron-style GPTQ shards from tp.py — column-parallel qkv / gate_up, row-parallel o / down, everything else replicated
     (tensor_parallel.rs:148-340).  MoE models (expert_parallel 1 or 2): every rank is offered every expert and keeps its own
@@ -598,7 +598,7 @@ def _tp_rank_models(pkg, tm, world, expert_parallel=0, **model_kw):
     ranks = []
     for r in range(world):
         cfg = dict(c, num_heads=nq // attn_world, num_kv_heads=nkv // attn_world, intermediate=I // world, tp_rank=r, tp_world=world,
-                   expert_parallel=expert_parallel)
+                   expert_parallel=expert_parallel, vocab_parallel=vocab_parallel)
         m = pkg.HipModel(group_size=128, **model_kw, **cfg)
         for name, data in tm.glob.items():
             m.set_global(name, data)
@@ -869,6 +869,62 @@ def test_expert_parallel_matches_single_gpu(pkg, forms, mode, world):
     assert np.array_equal(ref[0], res[0][0])                     # prefill ids equal to the unsharded model
     same = sum(np.array_equal(ref[2][:, i], res[0][2][:, i]) for i in range(len(prompts)))
     assert same >= len(prompts) - 1, same                        # free-running decode: whole histories (one near-tie flip allowed)
+
+
+@pytest.mark.parametrize("moe,vocab", [(False, 1000), (True, 5003)])
+def test_vocab_parallel_lm_head(pkg, forms, moe, vocab):
+    """Vocabulary-parallel lm_head: every rank scores its own vocabulary rows, takes the local first
+    maximum (after the sparse repetition penalty and the token mask on its slice) and the per-row (logit, global id) pairs
+    are gathered; the first maximum in rank order is the single-GPU result — the lowest id among equal logits.  Two ranks with
+    the one-shot gather inside the decode graph (dense, odd vocabulary: the second slice is ragged; and expert-parallel MoE
+    with the two-stage argmax): ids against the unsharded model — also under a token mask and a repetition penalty — and
+    the logits slices against its logits."""
+    from tests import modelgen
+    world = 2
+    tm = modelgen.TinyModel(moe, layers=2, hidden=256, nq=4, nkv=2, hd=128, inter=256, experts=8, top_k=2, expert_inter=128, vocab=vocab, seed=181)
+    mk = dict(kv_num_blocks=24, max_seqs=4, max_tokens=128)
+    full = tm.hip_model(pkg, **mk)
+    ranks = _tp_rank_models(pkg, tm, world, expert_parallel=1 if moe else 0, vocab_parallel=1, **mk)
+    v0s = [m.local_vocab() for m in ranks]
+    assert v0s[0][0] == 0 and v0s[1][0] == v0s[0][1] and v0s[0][1] % 16 == 0 and v0s[1][0] + v0s[1][1] == vocab
+    comms = pkg.Comm.local_group(world, 1 << 20)
+    for m, cm in zip(ranks, comms):
+        m.set_comm(cm)
+    rng = np.random.default_rng(182)
+    prompts = [rng.integers(0, vocab, size=n).astype(np.uint32) for n in (33, 7, 18)]
+    ids, steps = [0, 1, 2], 8
+    # a token mask and a repetition penalty that change the winners, identical on every rank
+    _, raw = full.unified_forward([(50 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    for i in range(3):
+        full.release(50 + i)
+    mask = np.ones(vocab - 3, np.uint8)
+    mask[int(np.argmax(raw[0]))] = 0
+    pens = [(1.7, np.unique(np.concatenate([p, np.argsort(-raw[i])[:2]])).astype(np.uint32)) for i, p in enumerate(prompts)]
+
+    def drive(_r, m):
+        t0, l0 = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        dec = m.decode_steps(ids, t0, steps)
+        for i in ids:
+            m.release(i)
+        t1, _ = m.unified_forward([(10 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, token_mask=mask, repetition_penalties=pens)
+        return np.array(t0), l0.copy(), dec, np.array(t1)
+
+    ref = drive(0, full)
+    forms.reset()
+    res = _run_ranks(ranks, drive)
+    forms.require("tp_allreduce_oneshot", "graph_replay")
+    for cm in comms:
+        assert cm.oneshot_status()["timeouts"] == 0
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert np.array_equal(ref[0], res[0][0])                     # prefill ids equal to the unsharded model
+    assert np.array_equal(ref[3], res[0][3])                     # … also under the mask and the penalty
+    for r in range(world):
+        v0, n = v0s[r]
+        assert res[r][1].shape == (3, n)
+        for i in range(3):
+            assert modelgen.cosine(ref[1][i, v0:v0 + n], res[r][1][i]) > 0.9999
+    same = sum(np.array_equal(ref[2][:, i], res[0][2][:, i]) for i in range(3))
+    assert same >= 2, same
 
 
 def test_expert_parallel_qwen3_30b_dims(pkg, forms):
