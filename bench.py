@@ -49,6 +49,7 @@ MODELS = {"qwen3-30b-a3b": QWEN3_30B_A3B, "llama31-8b": LLAMA31_8B, "gemma3-27b"
 BASELINE_CFG_INDEX = {"qwen3-30b-a3b": 2, "llama31-8b": 1, "gemma3-27b": 3, "llama3-70b": 4}
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TP_EXTRA_DEADLINE_S = 420   # multi-GPU runs: the tensor- / expert-parallel extras may take this long before the line goes out without them
 
 
 def shard_cfg(cfg, world, rank):
@@ -585,31 +586,9 @@ def main():
             stage("cpu baseline")
             extra["cpu_baseline"] = cpu_baseline()
 
-    # ── tensor-parallel extra (collective: every rank takes part) ────────────
-    if not args.no_tp_scaling and not args.layers and args.model == "qwen3-30b-a3b" and world in (1, 2, 4, 8):
-        for sid in range(50000, 50000 + c):
-            model.release(sid)
-        del model
-        model = None
-        torch.cuda.empty_cache()
-        tps = []
-        for name in ["llama3-70b"] + (["gemma3-27b"] if world == 2 else []):
-            stage(f"tp_scaling {name} tp={world}")
-            tps.append(tp_decode_case(pkg, torch, dist, name, world, rank, c, PL, min(K, 32), min(W, 4) if W else 2, 2048,
-                                      try_oneshot=args.tp_oneshot, transport=args.tp_transport))
-        extra["tp_scaling"] = tps
-        extra["rccl_ranks"] = world if world > 1 else 0
-        if world > 1:
-            # beyond the reference: the headline model as ONE expert-parallel group of all ranks — experts
-            # sharded, partial MoE outputs all-reduced — next to the replica headline above
-            stage(f"ep_scaling qwen3-30b-a3b x{world}")
-            extra["ep_scaling"] = tp_decode_case(pkg, torch, dist, "qwen3-30b-a3b", world, rank, c, PL, min(K, 32), min(W, 4) if W else 2, 2048,
-                                                 try_oneshot=False, transport=args.tp_transport)
-        num_layers_run = cfg["num_layers"]
-    else:
-        num_layers_run = model.cfg.num_layers
+    num_layers_run = model.cfg.num_layers
 
-    if rank == 0:
+    def make_line():
         # BASELINE.md's published c=32 number for this model (RTX 4090, ferrum 0.7.7 gate, `ferrum bench-serve`: output
         # tokens over the whole 256-in/128-out run, i.e. prefill included).  `value` is the decode-loop rate BASELINE.md
         # line 52 defines; `e2e_tok_s` is the serve-like form (prefill of all prompts + 128 decode steps) for a like-for-like ratio.
@@ -646,7 +625,56 @@ def main():
                            "concurrency": c, "prompt_len": PL, "kv_len_range": [PL + W, PL + W + K], "kv_block": 16,
                            "layers": num_layers_run, "parallelism": f"replica x{world}"}}
         line.update(extra)
-        print(json.dumps(line))
+        return line
+
+    emitted = []                                                # the one JSON line, whichever path prints it
+
+    def emit():
+        if rank == 0 and not emitted:
+            emitted.append(1)
+            print(json.dumps(make_line()), flush=True)
+
+    # ── tensor-parallel / expert-parallel extras (collective: every rank takes part) ─────────────
+    # They run AFTER everything the headline needs has been measured, under a watchdog: a multi-GPU collective that never
+    # completes (these paths have not run on a multi-GPU node yet) must cost the extras, not the line — past the deadline rank 0
+    # prints the line without them and every rank leaves.
+    if not args.no_tp_scaling and not args.layers and args.model == "qwen3-30b-a3b" and world in (1, 2, 4, 8):
+        import threading
+
+        def bail_out():
+            extra.setdefault("tp_scaling", {"error": f"the tensor-parallel extra did not finish within {TP_EXTRA_DEADLINE_S} s"})
+            emit()
+            os._exit(0)
+        watchdog = threading.Timer(TP_EXTRA_DEADLINE_S, bail_out) if world > 1 else None
+        if watchdog:
+            watchdog.daemon = True
+            watchdog.start()
+        for sid in range(50000, 50000 + c):
+            model.release(sid)
+        del model
+        model = None
+        torch.cuda.empty_cache()
+        try:
+            tps = []
+            for name in ["llama3-70b"] + (["gemma3-27b"] if world == 2 else []):
+                stage(f"tp_scaling {name} tp={world}")
+                tps.append(tp_decode_case(pkg, torch, dist, name, world, rank, c, PL, min(K, 32), min(W, 4) if W else 2, 2048,
+                                          try_oneshot=args.tp_oneshot, transport=args.tp_transport))
+            extra["tp_scaling"] = tps
+            extra["rccl_ranks"] = world if world > 1 else 0
+            if world > 1:
+                # beyond the reference: the headline model as ONE expert-parallel group of all ranks — experts
+                # sharded, partial MoE outputs all-reduced — next to the replica headline above
+                stage(f"ep_scaling qwen3-30b-a3b x{world}")
+                extra["ep_scaling"] = tp_decode_case(pkg, torch, dist, "qwen3-30b-a3b", world, rank, c, PL, min(K, 32), min(W, 4) if W else 2, 2048,
+                                                     try_oneshot=False, transport=args.tp_transport)
+        except Exception as e:                                  # reported in the line, never fatal to it
+            extra.setdefault("tp_scaling", {"error": str(e)[:400]})
+            extra["tp_extra_error"] = str(e)[:400]
+        if watchdog:
+            watchdog.cancel()
+
+    emit()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -115,6 +115,7 @@ struct FerrumHipModel {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     int graph_n = 0, graph_max_kv = 0;
+    bool graph_refused = false;    // a tensor-parallel step the runtime would not capture: eager from then on
 
     // tensor parallel (RCCL, resolved lazily by dlopen)
     uint8_t* greedy_opts_dev = nullptr;    // token mask + sparse repetition-penalty arrays of the current forward

@@ -1480,20 +1480,35 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
     const bool use_graph = !(c.tp_world > 1 && m->tp_loopback) && !m->taps_enabled && !knobs().no_graph;
     int kv_bucket = cdiv(sh.max_kv_len, 256) * 256;
     sh.max_kv_len = kv_bucket;
-    if (use_graph) {
-        if (!m->graph_exec || m->graph_n != n || m->graph_max_kv != kv_bucket) {
+    bool graph_ok = use_graph && !m->graph_refused;
+    if (graph_ok && (!m->graph_exec || m->graph_n != n || m->graph_max_kv != kv_bucket)) {
+        drop_graph(m);
+        FH_CHECK_HIP(hipStreamSynchronize(m->stream));
+        form_hit(FORM_GRAPH_CAPTURE);
+        // (relaxed mode under tensor parallelism: the collective library may touch the allocator inside the capture window)
+        FH_CHECK_HIP(hipStreamBeginCapture(m->stream, c.tp_world > 1 ? hipStreamCaptureModeRelaxed : hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_step();
+        hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+        if (!rc && e == hipSuccess) e = hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0);
+        if (rc || e != hipSuccess) {
+            // A step with a collective inside that the runtime will not capture (tensor parallel only): run it eagerly from now
+            // on rather than fail — the capture attempt enqueued nothing, so the device state is untouched.
+            (void)hipGetLastError();
             drop_graph(m);
-            FH_CHECK_HIP(hipStreamSynchronize(m->stream));
-            form_hit(FORM_GRAPH_CAPTURE);
-            FH_CHECK_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_step();
-            hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
-            if (rc) return rc;
-            FH_CHECK_HIP(e);
-            FH_CHECK_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+            if (c.tp_world <= 1) {
+                if (rc) return rc;
+                FH_CHECK_HIP(e);
+            }
+            fprintf(stderr, "[ferrum_hip] decode step could not be captured under tensor parallelism (%s): eager launches from here on\n",
+                    rc ? fh::last_error() : hipGetErrorString(e));
+            m->graph_refused = true;
+            graph_ok = false;
+        } else {
             m->graph_n = n;
             m->graph_max_kv = kv_bucket;
         }
+    }
+    if (graph_ok) {
         for (int st = 0; st < steps; st++) { FH_CHECK_HIP(hipGraphLaunch(m->graph_exec, m->stream)); form_hit(FORM_GRAPH_REPLAY); }
     } else {
         for (int st = 0; st < steps; st++)
@@ -1608,6 +1623,7 @@ int ferrum_hip_model_tp_init(FerrumHipModel* m, const uint8_t id[128]) {
     if (m->comm && m->comm_owned) ferrum_hip_comm_destroy(m->comm);
     m->comm = c;
     m->comm_owned = true;
+    m->graph_refused = false;
     drop_graph(m);
     return 0;
 }
@@ -1622,6 +1638,7 @@ int ferrum_hip_model_set_comm(FerrumHipModel* m, FerrumHipComm* comm) {
     if (m->comm && m->comm_owned) ferrum_hip_comm_destroy(m->comm);
     m->comm = comm;
     m->comm_owned = false;
+    m->graph_refused = false;
     drop_graph(m);
     return 0;
 }

@@ -47,7 +47,10 @@ std::mutex g_rccl_mu;
 int load_rccl() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl) return 0;
-    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // an RCCL the process has ALREADY loaded (e.g. the one torch.distributed brought) is preferred over a second copy
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     FH_REQUIRE(h, "tensor parallel: cannot dlopen librccl.so: %s", dlerror());
