@@ -41,6 +41,8 @@ void reload_knobs() {
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
     k.w4_ldsa_nw = env_int("FERRUM_HIP_W4_LDSA_NW", 0);
     k.w4_ldsa_s = env_int("FERRUM_HIP_W4_LDSA_S", 0);
+    k.w4_ldsk = env_int("FERRUM_HIP_W4_LDSK", 0);
+    k.w4_big = env_int("FERRUM_HIP_W4_BIG", 0);
     k.w4_nt = env_int("FERRUM_HIP_W4_NT", 0);
     k.w4_w = env_int("FERRUM_HIP_W4_W", 0);
     k.lds_min_wgs = env_int("FERRUM_HIP_LDS_MIN_WGS", 128);
@@ -61,7 +63,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "attn_split_reduce", "w4_wgsplit", "w4_ldsa", "w4_tilep", "w4_slabs", "w4_slabs_lds", "w4_slabs_tile", "w4_rowsum",
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
-    "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail"};
+    "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "w4_big", "w4_ldsk"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 

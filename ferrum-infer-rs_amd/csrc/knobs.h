@@ -29,6 +29,8 @@ struct Knobs {
     int w4_ldsa = 1;
     int w4_ldsa_nw = 0;
     int w4_ldsa_s = 0;
+    int w4_big = 0;                   // 0 auto, −1 never, 8 / 16 forces w4_gemm_big_kernel's 128- / 256-row tiles
+    int w4_ldsk = 0;                  // development: nw·100 + kw·10 + d forces a w4_gemm_ldsk_kernel form
     int w4_nt = 0;
     int w4_w = 0;
     int lds_min_wgs = 128;
@@ -75,6 +77,8 @@ enum Form : int {
     FORM_TP_ALLREDUCE_ONESHOT,
     FORM_F16_DENSE_LINEAR,      // unquantised projection (DenseLinear)
     FORM_W4_FUSED_TAIL,         // ≤ 4-row q|k|v GEMM with the previous layer's combine + add + norm as its prologue
+    FORM_W4_BIG,                // prefill: 128- / 256-row tiles, scale folded into the fp16 B operand
+    FORM_W4_LDSK,               // 17–64 rows: LDS-shared activations, K split over the waves of a workgroup
     FORM_COUNT
 };
 

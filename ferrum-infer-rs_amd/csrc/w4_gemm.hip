@@ -1115,6 +1115,264 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
         }
 }
 
+// ── dense GEMM for 17–64 rows, small and mid-sized projections: LDS-shared activations AND K split over the waves ─────
+// w4_gemm_ldsa_kernel holds one wave per SIMD with a four-group ring (200 VGPRs) and needs a slab per K split; on the small
+// projections of a decode layer (o_proj 4096→4096: 8 MB of weights, 2048 units of 4 KiB) that leaves three quarters of the CUs
+// without a workgroup.  Here a workgroup is NW column waves × KW K-slice waves: round r hands quant group g0 + r·KW + kw to
+// the waves of slice kw, the KW activation tiles of a round are staged once in LDS (each shared by the NW column waves),
+// the ring is D deep and the KW partial accumulators meet in LDS after the loop — so the same number of slabs puts KW× more
+// waves on the chip, each with 1–2 groups in flight (bytes in flight come from occupancy, not ring depth).
+template <int MT, int NW, int KW, int D, bool HAS_ZP>
+__global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ldsk_kernel(W4Args p) {
+    static_assert(D == 2 || D == 4, "ring depth: LDS buffer parity follows the unrolled slot");
+    static_assert((MT * 4) % NW == 0 && (MT * 16) % KW == 0, "staging / reduction split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][KW][MT·4][64] half8
+    float* red = reinterpret_cast<float*>(lds_raw);            // after the loop: [KW][NW][V][64] fp32
+    constexpr int FRW = MT * 4;                                 // fragment rows (64 × 16 B) per activation tile
+    constexpr int ALD = FRW / NW;                               // fragment rows each wave stages per round
+    constexpr int V = MT * 16;                                  // accumulator floats per lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cw = wave % NW, kw = KW == 1 ? 0 : wave / NW;
+    const int a = lane >> 4, b = lane & 15;
+    const int st_raw = blockIdx.x * NW + cw;
+    const bool st_ok = st_raw < p.n64;
+    const int st = st_ok ? st_raw : p.n64 - 1;
+    const int rb = blockIdx.y, z = blockIdx.z;
+    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+    const int R = (g1 - g0 + KW - 1) / KW;                      // rounds
+    const int gl = g1 - 1;
+
+    // staging: this wave brings fragment rows cw, cw + NW, … of ITS slice's tile (row mt·16 + (l & 15), k = 32 s + 8 (l >> 4))
+    const __half* asrc[ALD];
+#pragma unroll
+    for (int i = 0; i < ALD; i++) {
+        const int fr = cw + i * NW, mt = fr >> 2, s = fr & 3;
+        const int r = rb * 16 * MT + mt * 16 + (lane & 15);
+        asrc[i] = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + 32 * s + 8 * (lane >> 4);
+    }
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp) + ((long)st * p.G) * 16 + b : nullptr;
+
+    float4v acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+
+    u32x4g wq[D][4];
+    uint2 scv[D], zpv[D];
+    half8 areg[D][ALD];
+    auto issue = [&](int slot, int r) {                         // clamped: no load under a runtime condition
+        const int g = min(g0 + r * KW + kw, gl);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[slot] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[slot] = zp_lane[(long)g * 16];
+#pragma unroll
+        for (int i = 0; i < ALD; i++) areg[slot][i] = *reinterpret_cast<const half8*>(asrc[i] + (long)g * 128);
+    };
+    auto store_a = [&](int slot, int buf) {
+#pragma unroll
+        for (int i = 0; i < ALD; i++) lds_a[((buf * KW + kw) * FRW + cw + i * NW) * 64 + lane] = areg[slot][i];
+    };
+    auto consume = [&](int slot, int buf, int r) {
+        if (g0 + r * KW + kw > gl) return;                      // wave-uniform: a ragged last round
+        half8 af[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) af[mt][s] = lds_a[((buf * KW + kw) * FRW + mt * 4 + s) * 64 + lane];
+        const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
+        w4_consume_group<MT, 4, HAS_ZP>(wq[slot], sb, zb, 0, af, acc);
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    if (R > 0) {
+#pragma unroll
+        for (int d = 0; d < D - 1; d++) issue(d, min(d, R - 1));
+        FH_PIN();
+        store_a(0, 0);
+        __syncthreads();
+        int rbase = 0;
+        for (; rbase + D <= R; rbase += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                const int r = rbase + d;
+                issue((d + D - 1) % D, min(r + D - 1, R - 1));
+                FH_PIN();
+                if (D > 2) store_a((d + 1) % D, (d + 1) & 1);   // A(r+1), requested D − 2 rounds ago
+                consume(d, d & 1, r);
+                if (D == 2) store_a((d + 1) % D, (d + 1) & 1);  // A(r+1), requested above: after the MFMAs of this round
+                FH_PIN();
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; d++) {
+            if (rbase + d < R) {
+                if (d + 1 < D - 1) store_a(d + 1, (d + 1) & 1);
+                consume(d, d & 1, rbase + d);
+                __syncthreads();
+            }
+        }
+    }
+#undef FH_PIN
+    // the KW slices meet in LDS (fixed order kw = 0 … KW−1); every wave finishes V / KW of its column wave's accumulators
+    if (KW > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[((kw * NW + cw) * V + (mt * 4 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+        __syncthreads();
+    }
+    if (!st_ok) return;
+    float* slab = p.partial ? p.partial + (long)z * p.rows_pad * p.n_pad : nullptr;
+#pragma unroll
+    for (int i = 0; i < V / KW; i++) {
+        const int v = kw * (V / KW) + i;
+        const int r = v & 3, nt = (v >> 2) & 3, mt = v >> 4;
+        float sum;
+        if (KW > 1) {
+            sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; k++) sum += red[((k * NW + cw) * V + v) * 64 + lane];
+        } else {
+            sum = acc[mt][nt][r];
+        }
+        const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+        const int col = st * 64 + nt * 16 + b;
+        if (slab) {
+            slab[(long)row * p.n_pad + col] = sum;
+        } else if (row < p.M && col < p.N) {
+            if (p.bias) sum += __half2float(p.bias[col]);
+            p.out[(long)row * p.ldo + col] = __float2half(sum);
+        }
+    }
+}
+
+// ── dense GEMM for 17–64 rows: the workgroup's WHOLE activation slice resident in LDS, waves free-running ─────────────
+// At 17–32 rows the ring kernels above are bound by instruction issue, not HBM (≈ 150 VALU + 40 MFMA per 4 KiB of weights and
+// wave), and their per-group barrier keeps the waves of a SIMD in the same phase — all expanding nibbles, then all waiting on
+// the matrix pipe — so vector and matrix work never overlap.  Here the K range of a workgroup is short enough (≤ 128 KiB of
+// fp16 rows) to be staged ONCE, straight from global memory into the fragment-major LDS image (global_load_lds_dwordx4: no
+// VGPR round trip), behind the first weight groups; after that single barrier every wave streams its own weight groups
+// (NW column waves × KW K-slice waves, ring of D) at its own pace and the waves drift apart.  The KW slices meet in LDS at the
+// end (fixed order); K may also be split over grid.z into fp32 slabs.
+template <int MT, int NW, int KW, int D, bool HAS_ZP>
+__global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ares_kernel(W4Args p) {
+    static_assert((MT * 16) % KW == 0, "reduction split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [Gl][MT·4][64] half8
+    float* red = reinterpret_cast<float*>(lds_raw);            // after the loop: [KW][NW][V][64] fp32
+    constexpr int FRW = MT * 4, V = MT * 16, NWAVES = NW * KW;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cw = wave % NW, kw = KW == 1 ? 0 : wave / NW;
+    const int a = lane >> 4, b = lane & 15;
+    const int st_raw = blockIdx.x * NW + cw;
+    const bool st_ok = st_raw < p.n64;
+    const int st = st_ok ? st_raw : p.n64 - 1;
+    const int rb = blockIdx.y, z = blockIdx.z;
+    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+    const int Gl = g1 - g0;
+    const int ni = Gl > kw ? (Gl - kw + KW - 1) / KW : 0;       // this wave's groups: local index kw + i·KW
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc) + ((long)st * p.G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp) + ((long)st * p.G) * 16 + b : nullptr;
+
+    float4v acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    u32x4g wq[D][4];
+    uint2 scv[D], zpv[D];
+    auto issue = [&](int slot, int i) {                         // clamped: no load under a runtime condition
+        const int g = g0 + min(kw + max(min(i, ni - 1), 0) * KW, Gl - 1);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[slot] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[slot] = zp_lane[(long)g * 16];
+    };
+    auto consume = [&](int slot, int i) {
+        const int j = kw + i * KW;
+        half8 af[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) af[mt][s] = lds_a[(j * FRW + mt * 4 + s) * 64 + lane];
+        const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
+        w4_consume_group<MT, 4, HAS_ZP>(wq[slot], sb, zb, 0, af, acc);
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; d++) issue(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    {   // stage the activation slice: fragment row f = (local group, mt, k-step) ← lanes (row mt·16 + (l & 15), k = 32 s + 8 (l >> 4))
+        const int r_lo = rb * 16 * MT + (lane & 15);
+        for (int f = wave; f < Gl * FRW; f += NWAVES) {
+            const int gq = f / FRW, fr = f - gq * FRW, mt = fr >> 2, s = fr & 3;
+            const int r = r_lo + mt * 16;
+            const __half* src = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + (long)(g0 + gq) * 128 + 32 * s + 8 * (lane >> 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds_a + (long)f * 64), 16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    {
+        int ib = 0;
+        for (; ib + D <= ni; ib += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                issue((d + D - 1) % D, ib + d + D - 1);
+                consume(d, ib + d);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; d++)
+            if (ib + d < ni) consume(d, ib + d);
+    }
+    if (KW > 1) {
+        __syncthreads();                                        // every wave is done with the activation image
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) red[((kw * NW + cw) * V + (mt * 4 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
+        __syncthreads();
+    }
+    if (!st_ok) return;
+    float* slab = p.partial ? p.partial + (long)z * p.rows_pad * p.n_pad : nullptr;
+#pragma unroll
+    for (int i = 0; i < V / KW; i++) {
+        const int v = kw * (V / KW) + i;
+        const int r = v & 3, nt = (v >> 2) & 3, mt = v >> 4;
+        float sum;
+        if (KW > 1) {
+            sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < KW; k++) sum += red[((k * NW + cw) * V + v) * 64 + lane];
+        } else {
+            sum = acc[mt][nt][r];
+        }
+        const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
+        const int col = st * 64 + nt * 16 + b;
+        if (slab) {
+            slab[(long)row * p.n_pad + col] = sum;
+        } else if (row < p.M && col < p.N) {
+            if (p.bias) sum += __half2float(p.bias[col]);
+            p.out[(long)row * p.ldo + col] = __float2half(sum);
+        }
+    }
+}
+
 // ── MoE prefill grouped GEMM: 64-row tiles, activations through LDS, 4 waves × 64 columns ──────────────────────
 // For blocks of 64 sorted pairs the skinny kernels re-fetch their A fragments from L2 for every 64-column supertile and
 // spend half their time on it.  Here a workgroup owns 64 rows × 256 columns: every 128-k group's 64×128 activation tile is
@@ -1552,6 +1810,234 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tilep_kernel(W4Args p) {
         }
 }
 
+// ── prefill GEMM, 128- or 256-row tiles: group scale and zero folded into the B operand ───────────────────────────────
+// The 64-row kernels above are bound by vector issue, not by the matrix pipe: every 4-KiB weight group costs a wave ≈ 80
+// VALU of nibble expansion plus one fp32 FMA per accumulator (the per-group scale is applied to a chain result), and the
+// offset removal adds 2 MFMAs to every 8 — all of it amortised over only four row tiles.  Here the expanded nibbles are
+// finished as fp16 weights in registers — (1024 + q) − (1024 + zero) is an exact fp16 integer (v_pk_add_f16), × the group
+// scale is one rounding (v_pk_mul_f16): the fp16 weight the reference's own dequantisation produces — so the MFMAs accumulate
+// straight into their final registers: no chain results, no fold, no offset MFMAs, and the MT·16 accumulators of a wave
+// can live in AGPRs.  With MT = 8 (128 rows) a group costs a wave ≈ 210 VALU against 128 MFMAs, with MT = 16 against 256:
+// the matrix pipe (16 cycles per MFMA, 8 of them holding the issue port) is the bound.  One wave per SIMD; the next
+// k-half's operands are expanded between the MFMAs of the current one; activations global → registers → LDS one group ahead,
+// weights two groups ahead.
+template <int MT, bool HAS_ZP>
+__global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][MT][4 s][64] half8
+    constexpr int FR = MT * 256, ROWS = MT * 16;
+    typedef _Float16 half2v_ __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int st_raw = blockIdx.x * 4 + wave;
+    const bool st_ok = st_raw < p.n64;
+    const int st = st_ok ? st_raw : p.n64 - 1;
+    const int rb = blockIdx.y;
+    uint32_t aoff[MT];                                          // byte offset of this thread's staging rows: scalar base + 32-bit offset
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int r = rb * ROWS + mt * 16 + b;
+        aoff[mt] = ((uint32_t)(r < p.M ? r : p.M - 1) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
+    }
+    const char* qw_wave = reinterpret_cast<const char*>(p.qw) + ((long)st * p.G * 4) * 64 * 16;
+    const char* sc_wave = reinterpret_cast<const char*>(p.sc) + ((long)st * p.G) * 16 * 8;
+    const char* zp_wave = HAS_ZP ? reinterpret_cast<const char*>(p.zp) + ((long)st * p.G) * 16 * 8 : nullptr;
+    const char* x_base = reinterpret_cast<const char*>(p.x);
+    const uint32_t lane16 = lane * 16, b8 = b * 8;
+
+    float4v acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    u32x4g wq[2][4];
+    uint2 scv[2], zpv[2];
+    half8 areg[MT];
+    u32x4g bh[2][4][2];                                         // finished fp16 B operands [k-half parity][column tile][lo, hi]
+    const uint32_t magic = opaque_vgpr(0x64006400u), magic_hi = opaque_vgpr(0x54005400u);
+    const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
+    const int gz0 = (int)((long)p.G * blockIdx.z / p.S), gz1 = (int)((long)p.G * (blockIdx.z + 1) / p.S);
+    const int gl = gz1 - 1;
+    auto issue_w = [&](int sl, int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++)
+            wq[sl][nt] = *reinterpret_cast<const u32x4g*>(qw_wave + ((uint32_t)g * 4096u + lane16) + nt * 1024);
+        scv[sl] = *reinterpret_cast<const uint2*>(sc_wave + ((uint32_t)g * 128u + b8));
+        if (HAS_ZP) zpv[sl] = *reinterpret_cast<const uint2*>(zp_wave + ((uint32_t)g * 128u + b8));
+    };
+    auto issue_a = [&](int mt, int g) __attribute__((always_inline)) {
+        areg[mt] = *reinterpret_cast<const half8*>(x_base + (aoff[mt] + (uint32_t)g * 256u));
+    };
+    auto h2 = [](uint2 v, int i) __attribute__((always_inline)) {   // packed half i of four → both lanes of a half2
+        const uint32_t w = i < 2 ? v.x : v.y;
+        const uint32_t h = (i & 1) ? (w >> 16) : (w & 0xFFFFu);
+        return __builtin_bit_cast(half2v_, h | (h << 16));
+    };
+    // B operands of column tile nt, k-half pr of the group in slot sl — part 0: the lo nibbles (k-step 2·pr), part 1: the hi
+    // nibbles (k-step 2·pr + 1): expand (5 VALU per 8 nibbles), remove the offset (exact), scale (one rounding).  Cut into eight
+    // micro-steps of ≤ 2 VALU so that each rides behind one MFMA (an MFMA holds the issue port for 8 of its 16 cycles).
+    half2v_ s2v[2][4], zlo[2][4], zhi[2][4];
+    const uint32_t off_lo = opaque_vgpr(0xE408E408u), off_hi = opaque_vgpr(0xD480D480u);   // −1032, −72 as half2 in VGPRs (an SGPR operand
+                                                                                           // with op_sel costs a wait state before the multiply)
+    uint32_t tt2[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};    // MT = 16: an operand part spans two row tiles
+    auto prep_scales = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            s2v[sl][nt] = h2(scv[sl], nt);
+            if (HAS_ZP) {
+                const half2v_ z2 = h2(zpv[sl], nt);
+                zlo[sl][nt] = (half2v_){(_Float16)-1024.0f, (_Float16)-1024.0f} - z2;      // exact: integers ≤ 2048
+                zhi[sl][nt] = (half2v_){(_Float16)-64.0f, (_Float16)-64.0f} - z2;
+            }
+        }
+    };
+    auto micro = [&](int pr, int sl, int nt, int part, int step, uint32_t (&tt)[4]) __attribute__((always_inline)) {
+        const uint32_t d0 = wq[sl][nt][2 * pr], d1 = wq[sl][nt][2 * pr + 1];
+        const half2v_ s2 = s2v[sl][nt];
+        half2v_ off;
+        if (HAS_ZP) off = part ? zhi[sl][nt] : zlo[sl][nt];
+        else off = __builtin_bit_cast(half2v_, part ? off_hi : off_lo);
+        const uint32_t ml = part ? m_hi : m_lo, mg = part ? magic_hi : magic;
+        auto addo = [&](uint32_t v) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v_, v) + off); };
+        auto muls = [&](uint32_t v) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v_, v) * s2); };
+        u32x4g& dst = bh[pr][nt][part];
+        switch (step) {
+            case 0: tt[0] = and_or(d0, ml, mg); tt[1] = d0 >> 8; break;
+            case 1: tt[0] = addo(tt[0]); tt[1] = and_or(tt[1], ml, mg); break;
+            case 2: dst[0] = muls(tt[0]); tt[1] = addo(tt[1]); break;
+            case 3: dst[1] = muls(tt[1]); tt[2] = and_or(d1, ml, mg); break;
+            case 4: tt[2] = addo(tt[2]); tt[3] = d1 >> 8; break;
+            case 5: dst[2] = muls(tt[2]); tt[3] = and_or(tt[3], ml, mg); break;
+            case 6: tt[3] = addo(tt[3]); break;
+            default: dst[3] = muls(tt[3]); break;
+        }
+    };
+    auto finish = [&](int pr, int sl, int nt, int part) __attribute__((always_inline)) {
+        uint32_t tt[4];
+#pragma unroll
+        for (int s = 0; s < 8; s++) micro(pr, sl, nt, part, s, tt);
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+#define FH_MFMA(ACC, A, B, T) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+    // one k-half of one group: MT × 8 MFMAs, in place in AGPRs (hipcc otherwise picks three-address MFMAs whose results drift
+    // through the register file and permutes all MT·16 accumulators back at the loop edge: ≈ 90 v_accvgpr moves per group).
+    // Dependent MFMAs are four issue slots apart, B operands were finished ≥ one row tile earlier, A fragments come from ds_read.
+    auto half_step = [&](int pr, int sl, int g) __attribute__((always_inline)) {
+        const half8* at = lds_a + sl * FR;
+        half8 af[2][2];
+        af[0][0] = at[(2 * pr) * 64 + lane];
+        af[0][1] = at[(2 * pr + 1) * 64 + lane];
+        constexpr int MPP = MT / 8;                  // row tiles per operand part (8 parts per k-half: 4 column tiles × lo/hi)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int cp = mt & 1;
+            const int part_id = mt / MPP, sub = mt % MPP;            // part_id: (nt = part_id >> 1, part = part_id & 1)
+            const int spr = pr ^ 1, ssl = pr == 0 ? sl : (sl ^ 1);   // pr 0: this group's second k-half; pr 1: the next group's first
+            uint32_t tt[4];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int nt = k & 3;
+                if (MPP == 1) FH_MFMA(acc[mt][nt], af[cp][k >> 2], bh[pr][nt][k >> 2], tt);
+                else FH_MFMA(acc[mt][nt], af[cp][k >> 2], bh[pr][nt][k >> 2], tt2[part_id & 1]);
+                if (k == 0) {
+                    if (mt + 1 < MT) {
+                        af[cp ^ 1][0] = at[((mt + 1) * 4 + 2 * pr) * 64 + lane];
+                        af[cp ^ 1][1] = at[((mt + 1) * 4 + 2 * pr + 1) * 64 + lane];
+                    }
+                    if (pr == 0) {
+                        lds_a[(sl ^ 1) * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];   // A(g+1) → LDS
+                        issue_a(mt, min(g + 2, gl));                                      // A(g+2) requested
+                    }
+                }
+                // micro-steps of this row tile's share of the operand part
+                if (MPP == 1) micro(spr, ssl, part_id >> 1, part_id & 1, k, tt);
+                else if (MPP == 2) { if ((k & 1) == 1) micro(spr, ssl, part_id >> 1, part_id & 1, sub * 4 + (k >> 1), tt2[part_id & 1]); }
+                FH_PIN();
+            }
+            if (pr == 0 && mt == MT - 1) prep_scales(sl ^ 1);
+        }
+    };
+    auto group = [&](int sl, int g) __attribute__((always_inline)) {
+        half_step(0, sl, g);
+        issue_w(sl, min(g + 2, gl));            // this slot's words are all expanded: group g+2
+        FH_PIN();
+        half_step(1, sl, g);
+        __syncthreads();                        // A(g+1) is in LDS; every wave is done with A(g)
+    };
+    // prologue
+    issue_w(0, gz0);
+    issue_w(1, min(gz0 + 1, gl));
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) issue_a(mt, gz0);
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) lds_a[(mt * 4 + wave) * 64 + lane] = areg[mt];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) issue_a(mt, min(gz0 + 1, gl));
+    prep_scales(0);
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) { finish(0, 0, nt, 0); finish(0, 0, nt, 1); }
+    __syncthreads();
+    FH_PIN();
+    for (int g = gz0; g < gz1; g += 2) {       // an even number of groups per split (the launcher checks)
+#ifdef FH_EXP_TOUCH
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) asm volatile("" : "+a"(acc[mt][nt]));
+#endif
+        group(0, g);
+        group(1, g + 1);
+    }
+#undef FH_PIN
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results before any VALU reads them
+    if (!st_ok) return;
+    // epilogue: every accumulator leaves its AGPR through an explicit read at its point of use (left to the allocator, all
+    // MT·16 of them move to VGPRs at the loop exit and the 256-row form spills 250 registers)
+    auto acc_get = [&](int mt, int nt) __attribute__((always_inline)) {
+        float4v v;
+        asm volatile("v_accvgpr_read_b32 %0, %4\n\tv_accvgpr_read_b32 %1, %5\n\tv_accvgpr_read_b32 %2, %6\n\tv_accvgpr_read_b32 %3, %7"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                     : "a"(acc[mt][nt][0]), "a"(acc[mt][nt][1]), "a"(acc[mt][nt][2]), "a"(acc[mt][nt][3]));
+        return v;
+    };
+    if (p.partial) {
+        float* slab = p.partial + (long)blockIdx.z * p.rows_pad * p.n_pad + (long)(rb * ROWS + 4 * a) * p.n_pad + st * 64 + b;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                const float4v v = acc_get(mt, nt);
+#pragma unroll
+                for (int r = 0; r < 4; r++) slab[(long)(mt * 16 + r) * p.n_pad + nt * 16] = v[r];
+            }
+        return;
+    }
+    __half* out_lane = p.out + (long)(rb * ROWS + 4 * a) * p.ldo + st * 64 + b;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) {
+            const float4v v = acc_get(mt, nt);
+            const int col = st * 64 + nt * 16 + b;
+            const float bias = (p.bias && col < p.N) ? __half2float(p.bias[col]) : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = rb * ROWS + mt * 16 + 4 * a + r;
+                if (row < p.M && col < p.N) out_lane[(long)(mt * 16 + r) * p.ldo + nt * 16] = __float2half(v[r] + bias);
+            }
+        }
+}
+
+template <int MT>
+static int launch_big(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+    const size_t lds = (size_t)2 * MT * 256 * 16;
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_big_kernel<MT, true>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_big_kernel<MT, false>), grid, dim3(256), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 static int launch_tilep(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)2 * 1024 * 16;
     if (has_zp) hipLaunchKernelGGL((w4_gemm_tilep_kernel<true>), grid, dim3(256), lds, stream, a);
@@ -1576,6 +2062,50 @@ static int launch_ldsa(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stre
     else hipLaunchKernelGGL((w4_gemm_ldsa_kernel<MT, NW, false>), grid, dim3(NW * 64), lds, stream, a);
     FH_CHECK_LAUNCH();
     return 0;
+}
+
+template <int MT, int NW, int KW, int D>
+static int launch_ldsk(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+    const size_t lds_a = (size_t)2 * KW * MT * 4 * 64 * 16, lds_r = KW > 1 ? (size_t)KW * NW * MT * 16 * 64 * 4 : 0;
+    const size_t lds = lds_a > lds_r ? lds_a : lds_r;
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_ldsk_kernel<MT, NW, KW, D, true>), grid, dim3(NW * KW * 64), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_ldsk_kernel<MT, NW, KW, D, false>), grid, dim3(NW * KW * 64), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int MT, int NW, int KW, int D>
+static int launch_ares(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+    const int gl = cdiv(a.G, a.S);
+    const size_t lds_a = (size_t)gl * MT * 4 * 64 * 16, lds_r = KW > 1 ? (size_t)KW * NW * MT * 16 * 64 * 4 : 0;
+    const size_t lds = lds_a > lds_r ? lds_a : lds_r;
+    FH_REQUIRE(lds <= 160 * 1024, "w4_gemm_ares: %d groups of %d row tiles need %zu bytes of LDS", gl, MT, lds);
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_ares_kernel<MT, NW, KW, D, true>), grid, dim3(NW * KW * 64), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_ares_kernel<MT, NW, KW, D, false>), grid, dim3(NW * KW * 64), lds, stream, a);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// development: FERRUM_HIP_W4_LDSK = nw·100 + kw·10 + d picks a form of w4_gemm_ldsk_kernel (0 → not compiled in);
+// 1000 + that picks the same shape of w4_gemm_ares_kernel
+static int launch_ldsk_code(int mt, int code, const W4Args& a, bool has_zp, int n64, int row_blocks, hipStream_t stream) {
+    if (code >= 1000) {
+        code -= 1000;
+        const dim3 grid(cdiv(n64, code / 100), row_blocks, a.S);
+#define FH_A(MTV, NWV, KWV, DV) if (mt == MTV && code == NWV * 100 + KWV * 10 + DV) return launch_ares<MTV, NWV, KWV, DV>(a, has_zp, grid, stream)
+        FH_A(2, 4, 1, 2); FH_A(2, 4, 2, 2); FH_A(2, 4, 2, 3); FH_A(2, 4, 4, 2); FH_A(2, 2, 2, 2); FH_A(2, 2, 4, 2); FH_A(2, 8, 1, 2);
+        FH_A(2, 2, 8, 2); FH_A(4, 4, 1, 2); FH_A(4, 4, 2, 2); FH_A(4, 2, 2, 2);
+#undef FH_A
+        return -1;
+    }
+    const int nw = code / 100;
+    const dim3 grid(cdiv(n64, nw), row_blocks, a.S);
+#define FH_K(MTV, NWV, KWV, DV) if (mt == MTV && code == NWV * 100 + KWV * 10 + DV) return launch_ldsk<MTV, NWV, KWV, DV>(a, has_zp, grid, stream)
+    FH_K(2, 4, 1, 4); FH_K(2, 4, 2, 2); FH_K(2, 4, 2, 4); FH_K(2, 4, 4, 2); FH_K(2, 2, 2, 2); FH_K(2, 2, 4, 2); FH_K(2, 2, 4, 4);
+    FH_K(2, 2, 8, 2); FH_K(2, 1, 8, 2);
+    FH_K(4, 4, 1, 2); FH_K(4, 4, 1, 4); FH_K(4, 4, 2, 2); FH_K(4, 2, 2, 2); FH_K(4, 2, 4, 2);
+#undef FH_K
+    return -1;
 }
 
 template <int MT, int NT>
@@ -1661,6 +2191,38 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // skinny kernels' four row tiles re-fetch every activation fragment per 16–64 columns (c=48 decode, Llama-3.1-8B 5.18 →
     // 4.02 ms per step, Gemma-3-27B 15.1 → 11.5; the 2048→5120 / 4096→2048 projections of Qwen3-30B-A3B are faster skinny)
     const Knobs& kn = knobs();
+    // ≥ 128 rows: 128- / 256-row tiles with the group scale folded into the fp16 B operand (w4_gemm_big_kernel) when they fill the
+    // chip.  Cost model in rounds of 256 workgroups (one per CU), unit = one round of 128-row tiles; measured at M = 8192 on
+    // 4096→28672: 64-row tiles 905, 128-row 1171, 256-row 1258 TFLOP/s (tools/exp_prefill_gemm.py).
+    if (kn.w4_big >= 0 && m >= 128 && w.perm == nullptr && w.G % 2 == 0) {
+        const int cols = cdiv(w.n64, 4);
+        const long wgs4 = (long)cols * cdiv(m, 64), wgs8 = (long)cols * cdiv(m, 128), wgs16 = (long)cols * cdiv(m, 256);
+        const double t4 = (double)cdiv(wgs4, 512) * 1.294, t8 = (double)cdiv(wgs8, 256), t16 = (double)cdiv(wgs16, 256) * 1.862;
+        int MTv = 0;
+        if (kn.w4_big == 8 || kn.w4_big == 16) MTv = m >= 16 * kn.w4_big ? kn.w4_big : 0;       // development: forced
+        else if (wgs8 >= 128 && (t8 <= t4 || t16 <= t4)) MTv = (m >= 256 && t16 < t8) ? 16 : 8;
+        if (MTv) {
+            a.S = 1; a.partial = nullptr;
+            form_hit(FORM_W4_BIG);
+            const dim3 grid(cols, cdiv(m, 16 * MTv), 1);
+            return MTv == 16 ? launch_big<16>(a, w.zp != nullptr, grid, stream) : launch_big<8>(a, w.zp != nullptr, grid, stream);
+        }
+    }
+    if (kn.w4_ldsk && mt >= 2 && w.perm == nullptr) {
+        int S = std::max(1, std::min(kn.w4_ldsa_s, w.G));
+        const int rows_pad = row_blocks * 16 * mt, n_pad = w.n64 * 64;
+        FH_REQUIRE(S == 1 || (workspace && (size_t)S * rows_pad * n_pad * sizeof(float) <= workspace_bytes), "ldsk: workspace");
+        a.S = S; a.rows_pad = rows_pad; a.n_pad = n_pad;
+        a.partial = S > 1 ? workspace : nullptr;
+        const int rc = launch_ldsk_code(mt, kn.w4_ldsk, a, w.zp != nullptr, w.n64, row_blocks, stream);
+        FH_REQUIRE(rc >= 0, "FERRUM_HIP_W4_LDSK=%d is not an instantiated form for %d row tiles", kn.w4_ldsk, mt);
+        form_hit(FORM_W4_LDSK);
+        if (rc || S == 1) return rc;
+        hipLaunchKernelGGL(splitk_reduce_bias_kernel, dim3(cdiv(w.n, 256), m), dim3(256), 0, stream, workspace, out, w.bias, S, m,
+                           w.n, rows_pad, n_pad, w.n);
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
     const int tile_min_env = kn.w4_tile_min_m;
     const int tile_min_m = tile_min_env > 0 ? tile_min_env : ((long)w.k * w.n >= (12L << 20) ? 33 : 64);
     if (m >= tile_min_m && w.perm == nullptr) {

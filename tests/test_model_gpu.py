@@ -453,9 +453,9 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
     prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
     forms.reset()
     toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
-    # the forms the 8192-token prefill is meant to take: pipelined 64-row GEMM tiles, LDS-shared K/V attention, and for
-    # the MoE model the router GEMM + 64-pair grouped tiles
-    forms.require("w4_tilep", "attn_flash", *(("route_gemm", "moe_tile64") if moe else ()))
+    # the forms the 8192-token prefill is meant to take: 128- / 256-row GEMM tiles with the scale folded into the fp16 B operand,
+    # LDS-shared K/V attention, and for the MoE model the router GEMM + 64-pair grouped tiles
+    forms.require("w4_big", "attn_flash", *(("route_gemm", "moe_tile64") if moe else ()))
     par = modelgen.Parity(f"bench-workload-{name}", cos_min=0.999, rel_max=5e-2)
     gap = (lambda: om.last_route_gap_rel()) if moe else (lambda: float("inf"))
     cur = np.array(toks, np.uint32)                               # unfollowed rows continue on the device's own ids
@@ -744,7 +744,8 @@ def test_tp8_llama70b_rank_shard_shapes_through_loopback(pkg, forms):
 
     forms.reset()
     res = _run_ranks(ranks, drive)
-    forms.require("tp_allreduce_loopback", "w4_tilep", "dense_slab_chain", "w4_slabs_lds")
+    forms.require("tp_allreduce_loopback", "dense_slab_chain", "w4_slabs_lds")
+    assert forms.hits().get("w4_tilep", 0) + forms.hits().get("w4_big", 0) > 0, forms.hits()      # the prefill's row tiles
     flips = _tp_vs_single(tm, full, {"ranks": res, "ref": ref}, c, steps, "llama70b-tp8")
     assert flips <= 1, flips                                     # 80 sampled rows: ids equal to TP=1 (at most one near-tie flip)
     del ranks

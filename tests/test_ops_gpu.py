@@ -142,7 +142,9 @@ def test_gptq_asymmetric_and_act_order(env, k, n, m):
     # (narrow N), columns not a multiple of 256, asymmetric + bias
     (640, 320, (1024, 1100), True), (2048, 512, (1024,), True), (1024, 1000, (1153,), True), (768, 640, (1025,), False),
     # 33–63 rows of the larger projections (K·N ≥ 12 Mi) take the pipelined tile kernel with one ragged 64-row tile
-    (4096, 4096, (33, 48, 63), True), (2048, 6144, (40,), False)])
+    (4096, 4096, (33, 48, 63), True), (2048, 6144, (40,), False),
+    # enough 128- / 256-row tiles to fill the chip: w4_gemm_big_kernel (ragged last tile; asymmetric)
+    (2048, 5120, (1664, 3100), True), (1024, 4096, (2100,), False)])
 def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym, forms):
     pkg, B, ctx, O, torch = env
     seen = set()
@@ -160,10 +162,11 @@ def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym, forms):
         # the kernel the row count selects (w4_gemm_dense): ≤ 16 rows K-split skinny; ≥ 64 rows (33 on the larger projections)
         # the pipelined tile kernel; in between the LDS-shared-activation kernel on shapes deep or wide enough for it
         h = forms.hits()
-        ran = [f for f in ("w4_wgsplit", "w4_ldsa", "w4_tilep") if h.get(f)]
+        ran = [f for f in ("w4_wgsplit", "w4_ldsa", "w4_tilep", "w4_big") if h.get(f)]
         assert len(ran) == 1, (k, n, m, h)
         big = k * n >= (12 << 20)
         want = "w4_wgsplit" if m <= 16 else ("w4_tilep" if m >= (33 if big else 64) else None)
+        if m >= 1024 and n >= 4096: want = "w4_big"
         assert want is None or ran[0] == want, (k, n, m, h)
         seen.add(ran[0])
         ref = O.gemm(x, w, m, n, k) + (bias[None, :] if bias is not None else 0.0)
@@ -172,6 +175,34 @@ def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym, forms):
         assert np.all(got[m] == 7.0), (k, n, m)
     if (k, n) in ((8192, 2048), (1024, 16384)):
         assert "w4_ldsa" in seen, seen                     # the 17–32-row cases of these shapes are the LDS-A kernel's
+
+
+@pytest.mark.parametrize("mt", [8, 16])
+@pytest.mark.parametrize("sym", [True, False])
+def test_gptq_big_tile_forms(env, mt, sym, knobs, forms):
+    """w4_gemm_big_kernel forced on a small projection: 128- and 256-row tiles, ragged last tile, N = 1000 (a partial 256-column
+    workgroup and a partial 64-column supertile), bias, symmetric and asymmetric zero points.  Its fp16 weights are
+    (q − zero)·scale rounded once — the reference's own dequantisation (`cpu.rs:2283-2315` produces exactly that value in
+    f32; Marlin in fp16) — so the oracle comparison holds at the fp16 tolerance."""
+    pkg, B, ctx, O, torch = env
+    k, n = 1024, 1000
+    qw, sc, qz = O.make_synthetic_gptq(k, n, 128, 99 + mt, symmetric=sym)
+    sc = f16r(sc / (0.28 * np.sqrt(k)))
+    bias = f16r(np.random.default_rng(5).standard_normal(n))
+    lin = pkg.GptqLinear.from_raw(qw, sc, qz, None, bias, 4, 128, k, n)
+    w = O.dequant_gptq(qw, sc, qz, 128, k, n)
+    knobs.set(W4_BIG=mt)
+    for m in (16 * mt, 16 * mt + 37, 3 * 16 * mt - 1):
+        x = f16r(np.random.default_rng(m).standard_normal((m, k)))
+        out = torch.full((m + 1, n), 7.0, dtype=torch.float16, device="cuda")
+        forms.reset()
+        lin.forward(ctx, dev16(torch, x), out, m)
+        ctx.sync()
+        forms.require("w4_big", absent=("w4_tilep", "w4_ldsa", "w4_wgsplit"))
+        ref = O.gemm(x, w, m, n, k) + bias[None, :]
+        got = host(out)
+        assert nmse(ref, got[:m]) < NMSE_FP16_TOL, (mt, sym, m)
+        assert np.all(got[m] == 7.0), (mt, sym, m)
 
 
 def test_gptq_linearity(env):

@@ -29,7 +29,7 @@ def lin(k, n, seed):
 shapes = [(2048, 5120, "q3-qkv"), (4096, 2048, "q3-o"), (4096, 6144, "l8-qkv"), (4096, 4096, "l8-o"),
           (4096, 28672, "l8-gate_up"), (14336, 4096, "l8-down")]
 ms = [2048]
-args = sys.argv[1:]
+args = [a for a in sys.argv[1:] if not a.startswith("-big=")]
 if "-m" in args:
     i = args.index("-m"); ms = [int(x) for x in args[i + 1].split(",")]; del args[i:i + 2]
 for k, n, name in shapes:
@@ -39,4 +39,15 @@ for k, n, name in shapes:
         xin = torch.randn(m, k, device="cuda").half(); out = torch.empty(m, n, dtype=torch.float16, device="cuda")
         us = timeit(lambda i: lins[i % 2].forward(ctx, xin, out, m))
         print(f"{name:11s} K={k:5d} N={n:5d} m={m:5d}: {us:8.2f} us  {2.0 * m * k * n / us / 1e6:7.1f} TFLOP/s", flush=True)
+        bigs = [int(a[5:]) for a in sys.argv[1:] if a.startswith("-big=")]       # -big=8 -big=16: w4_gemm_big_kernel beside the default
+        if bigs:
+            lib = pkg.backend._lib
+            lins[0].forward(ctx, xin, out, m); torch.cuda.synchronize(); ref = out.float().clone()
+            for mtv in bigs:
+                os.environ["FERRUM_HIP_W4_BIG"] = str(mtv); lib.ferrum_hip_debug_reload_knobs()
+                us = timeit(lambda i: lins[i % 2].forward(ctx, xin, out, m))
+                lins[0].forward(ctx, xin, out, m); torch.cuda.synchronize()
+                d = (out.float() - ref); rel = d.norm().item() / ref.norm().item()
+                print(f"    big MT={mtv:2d}: {us:8.2f} us  {2.0 * m * k * n / us / 1e6:7.1f} TFLOP/s   rel L2 diff vs default {rel:.2e}  max {d.abs().max().item():.4f}", flush=True)
+                os.environ.pop("FERRUM_HIP_W4_BIG"); lib.ferrum_hip_debug_reload_knobs()
     del lins

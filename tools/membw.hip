@@ -52,6 +52,22 @@ int main() {
                                   hipLaunchKernelGGL(kern, grid, block, 0, 0, src, sink, bytes_per_wave, nwaves); }, 40);
         printf("%-44s waves=%6ld wg=%4d : %7.2f us  %6.2f TB/s\n", name, nwaves, wg_threads, us, region / us / 1e6);
     };
+    if (getenv("MEMBW_DENSE")) {
+        // one decode-sized dense projection per launch (Llama-3.1-8B gate_up: 58.7 MB): waves × KiB in flight per wave
+        region = 58720256L; nreg = (int)(total / region);
+        printf("58.7 MB per launch\n");
+        for (int wg : {256, 512}) {
+            for (long waves : {896L, 1792L, 3584L, 7168L, 14336L}) {
+                long bpw = region / waves;
+                char nm[64];
+                snprintf(nm, 64, "%ldKB/wave U=2", bpw >> 10); run(stream_waves<2, true>, bpw, wg, nm);
+                snprintf(nm, 64, "%ldKB/wave U=4", bpw >> 10); run(stream_waves<4, true>, bpw, wg, nm);
+                snprintf(nm, 64, "%ldKB/wave U=8", bpw >> 10); if (bpw >= 8192) run(stream_waves<8, true>, bpw, wg, nm);
+                snprintf(nm, 64, "%ldKB/wave U=16", bpw >> 10); if (bpw >= 16384) run(stream_waves<16, true>, bpw, wg, nm);
+            }
+        }
+        return 0;
+    }
     run(stream_waves<4, true>, 64 << 10, 64, "64KB/wave U=4 nt wg64");
     run(stream_waves<4, false>, 64 << 10, 64, "64KB/wave U=4 plain wg64");
     run(stream_waves<8, true>, 64 << 10, 64, "64KB/wave U=8 nt wg64");
