@@ -79,6 +79,9 @@ struct FerrumHipModel {
                                           // of L2 reads costs more than the launch saved (c=4 1455 → 1335 tok/s), so only single rows fuse
     int route_gemm_min_tokens = 512;          // from this many tokens the router runs as a GEMM + top-k (3 launches)
     int moe_tile_min_pairs_per_expert = 32;   // average pairs per expert from which MoE GEMMs use 64-row LDS tiles
+    int moe_tile128_min_pairs_per_expert = 1 << 30;   // … from which they would use 128-row blocks through w4_gemm_big_kernel: off —
+                                                      // at K = 2048 / 768 (16 / 6 groups per tile, one workgroup per CU) padding and the
+                                                      // un-overlapped prologue / epilogue cost more than the schedule gains (§3)
     int moe_tile32_min_pairs_per_expert = 8;  // … from which (below the 64-row threshold) they use 32-row LDS tiles
     int attn_flash_min_rows = 512;            // query rows (tokens × GQA group) per prompt from which attention takes the LDS-shared K/V form
     int moe_em_min_pairs_per_expert = 2;      // decode (P ≤ 1024): average pairs per expert from which the grouped GEMMs run expert-major (0 = never)

@@ -331,6 +331,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
     if (knobs().attn_flash_min_rows_set) m->attn_flash_min_rows = std::max(1, (int)knobs().attn_flash_min_rows);   // as the launcher reads it
+    if (const char* e = getenv("FERRUM_HIP_MOE_TILE128_PAIRS")) m->moe_tile128_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE32_PAIRS")) m->moe_tile32_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
     return 0;
@@ -620,7 +621,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     }
     rc |= dev_alloc(&m->out_tokens, S);
     if (c.num_experts > 0) {
-        const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 64;   // room for 64-row blocks (prefill)
+        const size_t P = T * c.top_k, sorted_max = P + (size_t)c.num_experts * 128;  // room for 128-row blocks (prefill)
         rc |= dev_alloc(&m->router_logits, T * c.num_experts);
         rc |= dev_alloc(&m->expert_ids, P);
         if (c.expert_parallel) {
@@ -907,6 +908,15 @@ static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted
     const int32_t* ids = moe_ids(m);
     if (P <= 1024) {
         FH_TRY(moe_decode_gemms(m, L, P, max_blocks, s));
+    } else if (P >= (long)m->moe_tile128_min_pairs_per_expert * Eg && L.exp_gate_up.G % 2 == 0 && L.exp_down.G % 2 == 0) {
+        // long prefill: 128-row blocks through w4_gemm_big_kernel (group scale folded into the fp16 B operand: the matrix pipe, not
+        // vector issue, bounds it; twice the padding of 64-row blocks, hence only from a few hundred pairs per expert)
+        const int sorted_max128 = P + E * 128, max_blocks128 = std::min(sorted_max128 / 128, P / 128 + std::min(P, E));
+        FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 128, sorted_max128, s));
+        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks128, 128, K, 1, s));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks128, 128, 1, 0, s));
     } else if (P >= m->moe_tile_min_pairs_per_expert * Eg) {
         // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
         const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));

@@ -1821,7 +1821,9 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tilep_kernel(W4Args p) {
 // the matrix pipe (16 cycles per MFMA, 8 of them holding the issue port) is the bound.  One wave per SIMD; the next
 // k-half's operands are expanded between the MFMAs of the current one; activations global → registers → LDS one group ahead,
 // weights two groups ahead.
-template <int MT, bool HAS_ZP>
+// MODE 0 dense; 1 / 2 the MoE grouped GEMM over MT·16-row align blocks (rows gathered through sorted_token_ids, the block's
+// expert from block_ids; 2 = gate_up with the silu·mul epilogue), tiles dealt to the XCDs like w4_gemm_tile_kernel's.
+template <int MT, bool HAS_ZP, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][MT][4 s][64] half8
@@ -1830,19 +1832,43 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
     typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int st_raw = blockIdx.x * 4 + wave;
+    int ct = blockIdx.x, rb = blockIdx.y;
+    if (MODE != 0) {        // each XCD walks a contiguous range of (column tile, row block), row block fastest: one expert's blocks meet its weights in one L2
+        const int nwg = gridDim.x * gridDim.y, lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = lin & 7, virt = xcd * (nwg >> 3) + min(xcd, nwg & 7) + (lin >> 3);
+        ct = virt / (int)gridDim.y;
+        rb = virt % (int)gridDim.y;
+    }
+    const int st_raw = ct * 4 + wave;
     const bool st_ok = st_raw < p.n64;
     const int st = st_ok ? st_raw : p.n64 - 1;
-    const int rb = blockIdx.y;
+    const uint32_t* qw = p.qw;
+    const __half* sc = p.sc;
+    const __half* zp = p.zp;
     uint32_t aoff[MT];                                          // byte offset of this thread's staging rows: scalar base + 32-bit offset
+    int row_out_l[MODE != 0 ? MT : 1];                          // MoE: output row (pair id) of tile row mt·16 + b, −1 = padding
+    if (MODE != 0) {
+        if (rb * ROWS >= *p.total_post_pad) return;
+        const int e = p.block_ids[rb];
+        qw += (long)e * p.expert_stride_qw;
+        sc += (long)e * p.expert_stride_sc;
+        if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
 #pragma unroll
-    for (int mt = 0; mt < MT; mt++) {
-        const int r = rb * ROWS + mt * 16 + b;
-        aoff[mt] = ((uint32_t)(r < p.M ? r : p.M - 1) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
+        for (int mt = 0; mt < MT; mt++) {
+            const int id = p.sorted_token_ids[rb * ROWS + mt * 16 + b];
+            row_out_l[mt] = id < p.M ? id : -1;
+            aoff[mt] = ((uint32_t)(id < p.M ? id / p.top_k : 0) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int r = rb * ROWS + mt * 16 + b;
+            aoff[mt] = ((uint32_t)(r < p.M ? r : p.M - 1) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
+        }
     }
-    const char* qw_wave = reinterpret_cast<const char*>(p.qw) + ((long)st * p.G * 4) * 64 * 16;
-    const char* sc_wave = reinterpret_cast<const char*>(p.sc) + ((long)st * p.G) * 16 * 8;
-    const char* zp_wave = HAS_ZP ? reinterpret_cast<const char*>(p.zp) + ((long)st * p.G) * 16 * 8 : nullptr;
+    const char* qw_wave = reinterpret_cast<const char*>(qw) + ((long)st * p.G * 4) * 64 * 16;
+    const char* sc_wave = reinterpret_cast<const char*>(sc) + ((long)st * p.G) * 16 * 8;
+    const char* zp_wave = HAS_ZP ? reinterpret_cast<const char*>(zp) + ((long)st * p.G) * 16 * 8 : nullptr;
     const char* x_base = reinterpret_cast<const char*>(p.x);
     const uint32_t lane16 = lane * 16, b8 = b * 8;
 
@@ -2001,6 +2027,35 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
                      : "a"(acc[mt][nt][0]), "a"(acc[mt][nt][1]), "a"(acc[mt][nt][2]), "a"(acc[mt][nt][3]));
         return v;
     };
+    if (MODE != 0) {        // D row 4a + r of tile mt ↔ block row mt·16 + 4a + r, whose pair id lives in lane (·, b = 4a + r)
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            int orow[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) orow[r] = __shfl(row_out_l[mt], 4 * a + r, 64);
+            if (MODE == 2) {
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const float4v gt = acc_get(mt, jj), up = acc_get(mt, 2 + jj);
+                    const int col = st * 32 + jj * 16 + b;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (orow[r] >= 0 && col < p.ldo)
+                            p.out[(long)orow[r] * p.ldo + col] = __float2half((gt[r] / (1.0f + __expf(-gt[r]))) * up[r]);
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) {
+                    const float4v v = acc_get(mt, nt);
+                    const int col = st * 64 + nt * 16 + b;
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if (orow[r] >= 0 && col < p.N) p.out[(long)orow[r] * p.ldo + col] = __float2half(v[r]);
+                }
+            }
+        }
+        return;
+    }
     if (p.partial) {
         float* slab = p.partial + (long)blockIdx.z * p.rows_pad * p.n_pad + (long)(rb * ROWS + 4 * a) * p.n_pad + st * 64 + b;
 #pragma unroll
@@ -2029,11 +2084,11 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
         }
 }
 
-template <int MT>
+template <int MT, int MODE = 0>
 static int launch_big(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)2 * MT * 256 * 16;
-    if (has_zp) hipLaunchKernelGGL((w4_gemm_big_kernel<MT, true>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((w4_gemm_big_kernel<MT, false>), grid, dim3(256), lds, stream, a);
+    if (has_zp) hipLaunchKernelGGL((w4_gemm_big_kernel<MT, true, MODE>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_big_kernel<MT, false, MODE>), grid, dim3(256), lds, stream, a);
     FH_CHECK_LAUNCH();
     return 0;
 }
@@ -2491,7 +2546,8 @@ int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int3
                      const int32_t* total_post_pad, int num_valid_pairs, int max_blocks, int block_rows, int top_k, int fused_silu,
                      hipStream_t stream) {
     if (num_valid_pairs <= 0 || max_blocks <= 0) return 0;
-    FH_REQUIRE(block_rows == 64 || block_rows == 32, "w4_gemm_moe_tile: block_rows=%d (64 or 32)", block_rows);
+    FH_REQUIRE(block_rows == 128 || block_rows == 64 || block_rows == 32, "w4_gemm_moe_tile: block_rows=%d (128, 64 or 32)", block_rows);
+    FH_REQUIRE(block_rows != 128 || w.G % 2 == 0, "w4_gemm_moe_tile: 128-row blocks need an even number of quant groups (K=%d)", w.k);
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
     a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
@@ -2503,7 +2559,8 @@ int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int3
     a.top_k = top_k;
     dim3 grid(cdiv(w.n64, 4), max_blocks, 1);
     const bool zp = w.zp != nullptr;
-    form_hit(block_rows == 64 ? FORM_MOE_TILE64 : FORM_MOE_TILE32);
+    form_hit(block_rows == 128 ? FORM_MOE_TILE128 : (block_rows == 64 ? FORM_MOE_TILE64 : FORM_MOE_TILE32));
+    if (block_rows == 128) return fused_silu ? launch_big<8, 2>(a, zp, grid, stream) : launch_big<8, 1>(a, zp, grid, stream);
     if (block_rows == 64) return fused_silu ? launch_tile<2, 4>(a, zp, grid, stream) : launch_tile<1, 4>(a, zp, grid, stream);
     return fused_silu ? launch_tile<2, 2>(a, zp, grid, stream) : launch_tile<1, 2>(a, zp, grid, stream);
 }
