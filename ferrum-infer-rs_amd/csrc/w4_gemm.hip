@@ -1824,7 +1824,7 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tilep_kernel(W4Args p) {
 // MODE 0 dense; 1 / 2 the MoE grouped GEMM over MT·16-row align blocks (rows gathered through sorted_token_ids, the block's
 // expert from block_ids; 2 = gate_up with the silu·mul epilogue), tiles dealt to the XCDs like w4_gemm_tile_kernel's.
 template <int MT, bool HAS_ZP, int MODE = 0>
-__global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
+__global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void w4_gemm_big_kernel(W4Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][MT][4 s][64] half8
     constexpr int FR = MT * 256, ROWS = MT * 16;
@@ -1880,7 +1880,7 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
     u32x4g wq[2][4];
     uint2 scv[2], zpv[2];
     half8 areg[MT];
-    u32x4g bh[2][4][2];                                         // finished fp16 B operands [k-half parity][column tile][lo, hi]
+    u32x4g bq[2][4];                                            // finished fp16 B operands [k-step parity][column tile]
     const uint32_t magic = opaque_vgpr(0x64006400u), magic_hi = opaque_vgpr(0x54005400u);
     const uint32_t m_lo = opaque_sgpr(0x000F000Fu), m_hi = opaque_sgpr(0x00F000F0u);
     const int gz0 = (int)((long)p.G * blockIdx.z / p.S), gz1 = (int)((long)p.G * (blockIdx.z + 1) / p.S);
@@ -1906,7 +1906,6 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
     half2v_ s2v[2][4], zlo[2][4], zhi[2][4];
     const uint32_t off_lo = opaque_vgpr(0xE408E408u), off_hi = opaque_vgpr(0xD480D480u);   // −1032, −72 as half2 in VGPRs (an SGPR operand
                                                                                            // with op_sel costs a wait state before the multiply)
-    uint32_t tt2[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};    // MT = 16: an operand part spans two row tiles
     auto prep_scales = [&](int sl) __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < 4; nt++) {
@@ -1927,7 +1926,7 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
         const uint32_t ml = part ? m_hi : m_lo, mg = part ? magic_hi : magic;
         auto addo = [&](uint32_t v) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v_, v) + off); };
         auto muls = [&](uint32_t v) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v_, v) * s2); };
-        u32x4g& dst = bh[pr][nt][part];
+        u32x4g& dst = bq[part][nt];             // k-step 2·pr + part: parity = part
         switch (step) {
             case 0: tt[0] = and_or(d0, ml, mg); tt[1] = d0 >> 8; break;
             case 1: tt[0] = addo(tt[0]); tt[1] = and_or(tt[1], ml, mg); break;
@@ -1946,49 +1945,53 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
     };
 #define FH_PIN() __builtin_amdgcn_sched_barrier(0)
 #define FH_MFMA(ACC, A, B, T) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
-    // one k-half of one group: MT × 8 MFMAs, in place in AGPRs (hipcc otherwise picks three-address MFMAs whose results drift
-    // through the register file and permutes all MT·16 accumulators back at the loop edge: ≈ 90 v_accvgpr moves per group).
-    // Dependent MFMAs are four issue slots apart, B operands were finished ≥ one row tile earlier, A fragments come from ds_read.
-    auto half_step = [&](int pr, int sl, int g) __attribute__((always_inline)) {
+    // one k-step (32 k) of one group: MT × 4 MFMAs, in place in AGPRs (hipcc otherwise picks three-address MFMAs whose results
+    // drift through the register file and permutes all MT·16 accumulators back at the loop edge: ≈ 90 v_accvgpr moves per group).
+    // Dependent MFMAs are MT·4 issue slots apart, B operands were finished one k-step earlier, A fragments come from ds_read.
+    // Side work of k-step s: the four operand parts of k-step s + 1 (32 micro-steps spread over the MT·4 MFMAs); k-steps 0 / 1 also
+    // move A(g+1) from its staging registers to LDS and request A(g+2).
+    uint32_t tt[4];
+    half8 af[2];
+    auto k_step = [&](int ks, int sl, int g) __attribute__((always_inline)) {
         const half8* at = lds_a + sl * FR;
-        half8 af[2][2];
-        af[0][0] = at[(2 * pr) * 64 + lane];
-        af[0][1] = at[(2 * pr + 1) * 64 + lane];
-        constexpr int MPP = MT / 8;                  // row tiles per operand part (8 parts per k-half: 4 column tiles × lo/hi)
+        constexpr int NM = MT * 4;                   // MFMAs per k-step
+        const int nks = (ks + 1) & 3, npr = nks >> 1, nsl = ks == 3 ? (sl ^ 1) : sl;     // the k-step whose operands are built now
+        static_assert(MT % 2 == 0, "the A-fragment ping-pong returns to slot 0 at every k-step");
+        if (ks == 0) af[0] = at[lane];               // (the group's barrier has just been passed)
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
             const int cp = mt & 1;
-            const int part_id = mt / MPP, sub = mt % MPP;            // part_id: (nt = part_id >> 1, part = part_id & 1)
-            const int spr = pr ^ 1, ssl = pr == 0 ? sl : (sl ^ 1);   // pr 0: this group's second k-half; pr 1: the next group's first
-            uint32_t tt[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int nt = k & 3;
-                if (MPP == 1) FH_MFMA(acc[mt][nt], af[cp][k >> 2], bh[pr][nt][k >> 2], tt);
-                else FH_MFMA(acc[mt][nt], af[cp][k >> 2], bh[pr][nt][k >> 2], tt2[part_id & 1]);
-                if (k == 0) {
-                    if (mt + 1 < MT) {
-                        af[cp ^ 1][0] = at[((mt + 1) * 4 + 2 * pr) * 64 + lane];
-                        af[cp ^ 1][1] = at[((mt + 1) * 4 + 2 * pr + 1) * 64 + lane];
-                    }
-                    if (pr == 0) {
-                        lds_a[(sl ^ 1) * FR + (mt * 4 + wave) * 64 + lane] = areg[mt];   // A(g+1) → LDS
-                        issue_a(mt, min(g + 2, gl));                                      // A(g+2) requested
+            for (int nt = 0; nt < 4; nt++) {
+                const int q = mt * 4 + nt;
+                FH_MFMA(acc[mt][nt], af[cp], bq[ks & 1][nt], tt);
+                if (nt == 0) {
+                    if (mt + 1 < MT) af[cp ^ 1] = at[((mt + 1) * 4 + ks) * 64 + lane];
+                    else if (ks < 3) af[cp ^ 1] = at[(ks + 1) * 64 + lane];          // first fragment of the next k-step
+                    if (ks < 2) {                    // staging rows mt' = ks·MT/2 … of this k-step's share
+                        constexpr int HM = (MT + 1) / 2;
+                        const int smt = ks * HM + mt;
+                        if (mt < HM && smt < MT) {
+                            lds_a[(sl ^ 1) * FR + (smt * 4 + wave) * 64 + lane] = areg[smt];   // A(g+1) → LDS
+                            issue_a(smt, min(g + 2, gl));                                      // A(g+2) requested
+                        }
                     }
                 }
-                // micro-steps of this row tile's share of the operand part
-                if (MPP == 1) micro(spr, ssl, part_id >> 1, part_id & 1, k, tt);
-                else if (MPP == 2) { if ((k & 1) == 1) micro(spr, ssl, part_id >> 1, part_id & 1, sub * 4 + (k >> 1), tt2[part_id & 1]); }
+#pragma unroll
+                for (int ms = q * 32 / NM; ms < (q + 1) * 32 / NM; ms++)
+                    micro(npr, nsl, ms >> 3, nks & 1, ms & 7, tt);      // part ms/8 = column tile, of k-step nks (lo / hi nibbles)
                 FH_PIN();
             }
-            if (pr == 0 && mt == MT - 1) prep_scales(sl ^ 1);
         }
     };
     auto group = [&](int sl, int g) __attribute__((always_inline)) {
-        half_step(0, sl, g);
+        k_step(0, sl, g);
+        k_step(1, sl, g);
+        k_step(2, sl, g);
+        prep_scales(sl ^ 1);
         issue_w(sl, min(g + 2, gl));            // this slot's words are all expanded: group g+2
         FH_PIN();
-        half_step(1, sl, g);
+        k_step(3, sl, g);
         __syncthreads();                        // A(g+1) is in LDS; every wave is done with A(g)
     };
     // prologue
@@ -2002,7 +2005,7 @@ __global__ __launch_bounds__(256, 1) void w4_gemm_big_kernel(W4Args p) {
     for (int mt = 0; mt < MT; mt++) issue_a(mt, min(gz0 + 1, gl));
     prep_scales(0);
 #pragma unroll
-    for (int nt = 0; nt < 4; nt++) { finish(0, 0, nt, 0); finish(0, 0, nt, 1); }
+    for (int nt = 0; nt < 4; nt++) finish(0, 0, nt, 0);            // operands of k-step 0 of the first group
     __syncthreads();
     FH_PIN();
     for (int g = gz0; g < gz1; g += 2) {       // an even number of groups per split (the launcher checks)
@@ -2246,20 +2249,25 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // skinny kernels' four row tiles re-fetch every activation fragment per 16–64 columns (c=48 decode, Llama-3.1-8B 5.18 →
     // 4.02 ms per step, Gemma-3-27B 15.1 → 11.5; the 2048→5120 / 4096→2048 projections of Qwen3-30B-A3B are faster skinny)
     const Knobs& kn = knobs();
-    // ≥ 128 rows: 128- / 256-row tiles with the group scale folded into the fp16 B operand (w4_gemm_big_kernel) when they fill the
-    // chip.  Cost model in rounds of 256 workgroups (one per CU), unit = one round of 128-row tiles; measured at M = 8192 on
-    // 4096→28672: 64-row tiles 905, 128-row 1171, 256-row 1258 TFLOP/s (tools/exp_prefill_gemm.py).
-    if (kn.w4_big >= 0 && m >= 128 && w.perm == nullptr && w.G % 2 == 0) {
+    // ≥ 96 rows: 96- / 128- / 256-row tiles with the group scale folded into the fp16 B operand (w4_gemm_big_kernel) when they
+    // fill the chip.  Deep K (≥ 24 groups): the tallest tile whose last round of 256 workgroups is ≥ 70 % full — 4096→28672 at
+    // M = 8192: 64-row tiles 905, 96-row 1204, 128-row 1171, 256-row 1277 TFLOP/s (tools/exp_prefill_gemm.py, a throttled
+    // back-to-back loop; one prefill of Llama-3.1-8B: 133 → 101 ms).  Shallow K: the 96-row form, two workgroups per CU, whose
+    // prologues and epilogues overlap (2048→5120 at M = 8192: 852 / 924 TFLOP/s for 128 / 256 rows, 962 for 96).
+    if (kn.w4_big >= 0 && m >= 96 && w.perm == nullptr && w.G % 2 == 0) {
         const int cols = cdiv(w.n64, 4);
-        const long wgs4 = (long)cols * cdiv(m, 64), wgs8 = (long)cols * cdiv(m, 128), wgs16 = (long)cols * cdiv(m, 256);
-        const double t4 = (double)cdiv(wgs4, 512) * 1.294, t8 = (double)cdiv(wgs8, 256), t16 = (double)cdiv(wgs16, 256) * 1.862;
+        const long wgs6 = (long)cols * cdiv(m, 96), wgs8 = (long)cols * cdiv(m, 128), wgs16 = (long)cols * cdiv(m, 256);
+        auto fill = [](long wgs) { return (double)wgs / (double)(cdiv(wgs, 256) * 256); };
         int MTv = 0;
-        if (kn.w4_big == 8 || kn.w4_big == 16) MTv = m >= 16 * kn.w4_big ? kn.w4_big : 0;       // development: forced
-        else if (wgs8 >= 128 && (t8 <= t4 || t16 <= t4)) MTv = (m >= 256 && t16 < t8) ? 16 : 8;
+        if (kn.w4_big == 6 || kn.w4_big == 8 || kn.w4_big == 16) MTv = m >= 16 * kn.w4_big ? kn.w4_big : 0;       // development: forced
+        else if (w.G >= 24 && m >= 256 && wgs16 >= 192 && fill(wgs16) >= 0.7) MTv = 16;
+        else if (w.G >= 24 && m >= 128 && wgs8 >= 192 && fill(wgs8) >= 0.7) MTv = 8;
+        else if (wgs6 >= 128) MTv = 6;
         if (MTv) {
             a.S = 1; a.partial = nullptr;
             form_hit(FORM_W4_BIG);
             const dim3 grid(cols, cdiv(m, 16 * MTv), 1);
+            if (MTv == 6) return launch_big<6>(a, w.zp != nullptr, grid, stream);
             return MTv == 16 ? launch_big<16>(a, w.zp != nullptr, grid, stream) : launch_big<8>(a, w.zp != nullptr, grid, stream);
         }
     }

@@ -177,7 +177,7 @@ def test_gptq_row_regimes_and_edge_shapes(env, k, n, ms, sym, forms):
         assert "w4_ldsa" in seen, seen                     # the 17–32-row cases of these shapes are the LDS-A kernel's
 
 
-@pytest.mark.parametrize("mt", [8, 16])
+@pytest.mark.parametrize("mt", [6, 8, 16])
 @pytest.mark.parametrize("sym", [True, False])
 def test_gptq_big_tile_forms(env, mt, sym, knobs, forms):
     """w4_gemm_big_kernel forced on a small projection: 128- and 256-row tiles, ragged last tile, N = 1000 (a partial 256-column
