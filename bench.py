@@ -526,7 +526,8 @@ def main():
             us, _ = model.time_kernel("qkv", chunk, kv_end, reps=2)
             kk, nn = cfg["hidden"], (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * cfg["head_dim"]
             tf = 2.0 * chunk * kk * nn / us / 1e6
-            ns["int4_gemm_prefill"] = {"kernel": f"w4_gemm_tilep_kernel qkv {kk}->{nn}, M={chunk}", "avg_us": round(us, 2),
+            ns["int4_gemm_prefill"] = {"kernel": f"w4_gemm_big_kernel (96/128/256-row tiles, scale folded into the fp16 B operand) qkv {kk}->{nn}, M={chunk}",
+                                       "avg_us": round(us, 2),
                                        "tflops": round(tf, 1), "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
             mp = os.path.join(ROOT, "profiles", "pmc_mfma_busy.json")
             if os.path.exists(mp):

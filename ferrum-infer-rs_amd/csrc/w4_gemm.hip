@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ldsk_kernel(W4Args p) {
 // VGPR round trip), behind the first weight groups; after that single barrier every wave streams its own weight groups
 // (NW column waves × KW K-slice waves, ring of D) at its own pace and the waves drift apart.  The KW slices meet in LDS at the
 // end (fixed order); K may also be split over grid.z into fp32 slabs.
-template <int MT, int NW, int KW, int D, bool HAS_ZP>
+template <int MT, int NW, int KW, int D, bool HAS_ZP, bool ILV = (NW * KW <= 8)>
 __global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ares_kernel(W4Args p) {
     static_assert((MT * 16) % KW == 0, "reduction split");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -1308,7 +1308,7 @@ __global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ares_kernel(W4Args p) {
             for (int s = 0; s < 4; s++) af[mt][s] = lds_a[(j * FRW + mt * 4 + s) * 64 + lane];
         const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
         const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
-        w4_consume_group<MT, 4, HAS_ZP>(wq[slot], sb, zb, 0, af, acc);
+        w4_consume_group<MT, 4, HAS_ZP, ILV>(wq[slot], sb, zb, 0, af, acc);
     };
 #pragma unroll
     for (int d = 0; d < D - 1; d++) issue(d, d);
