@@ -35,6 +35,7 @@ void reload_knobs() {
     k.attn_rs_min_wgs = env_int("FERRUM_HIP_ATTN_RS_MIN_WGS", 512);
     k.attn_no_rs = env_flag("FERRUM_HIP_ATTN_NO_RS");
     k.attn_narrow = env_flag("FERRUM_HIP_ATTN_NARROW");
+    k.attn_flash32 = env_flag("FERRUM_HIP_ATTN_FLASH32");
     k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 8);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);

@@ -618,6 +618,248 @@ __global__ __launch_bounds__(256, HD <= 128 ? 2 : 1) void paged_prefill_attn_ker
     }
 }
 
+// ── flash form, 64 keys per step ─────────────────────────────────────────────────────────────────────────────────────
+// paged_prefill_attn_kernel above pays its softmax bookkeeping (row maximum and its cross-lane reduce, α, the rescale test, the
+// row sum and ITS reduce, one barrier) once per 32 keys, and that vector work — not its 32 MFMAs — sets its pace.  Here a step is
+// TWO block pairs (64 keys): one maximum / α / rescale per 64 keys, the row sums come out of the matrix pipe (an all-ones A
+// operand against Pᵀ: every lane's accumulator then holds Σ_keys P of its query row, rescaled by α like O), and steps whose 64
+// keys are visible to every row of a tile (all but the diagonal ones) run a mask-free body.  Same staging, tile layout and
+// per-row arithmetic otherwise (Sᵀ = K·Qᵀ, lane-local exp2, Oᵀ += Vᵀ·Pᵀ); l is the sum of the fp16 P the numerator uses.
+template <int HD>
+__global__ __launch_bounds__(256, 2) void paged_prefill_attn64_kernel(AttnArgs p) {
+    constexpr int NW = 4, MT = 2, DT = HD / 16, KS = HD / 32, TILE = 16 * HD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half* lds_kv = reinterpret_cast<__half*>(smem);          // [2 stages][2 pairs][K0, K1, V0, V1][TILE]; reused by the epilogue
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int kvh = blockIdx.y;
+    const int G = p.nq / p.nkv;
+    int seq = -1, unit = 0;
+    {
+        const int w = gridDim.x - 1 - blockIdx.x;       // launch order reversed: the longest key ranges (last units of a causal prompt) start first
+        int base = 0;
+        for (int s0 = 0; s0 < p.num_seqs; s0 += 64) {
+            const int s = s0 + lane;
+            int units = 0;
+            if (s < p.num_seqs) {
+                const int tiles = ((int)(p.cu_seqlens_q[s + 1] - p.cu_seqlens_q[s]) * G + 15) >> 4;
+                units = (tiles + NW * MT - 1) / (NW * MT);
+            }
+            int incl = units;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            const int total = __shfl(incl, 63, 64);
+            if (w < base + total) {
+                const unsigned long long hit = __ballot(w < base + incl);
+                const int src = __ffsll((long long)hit) - 1;
+                seq = s0 + src;
+                unit = w - (base + __shfl(incl - units, src, 64));
+                break;
+            }
+            base += total;
+        }
+        if (seq < 0) return;
+        seq = __builtin_amdgcn_readfirstlane(seq);          // wave-uniform by construction: scalar table reads below
+        unit = __builtin_amdgcn_readfirstlane(unit);
+    }
+    const int tok0 = (int)p.cu_seqlens_q[seq];
+    const int q_len = (int)p.cu_seqlens_q[seq + 1] - tok0;
+    const int rows_total = q_len * G, tiles_s = (rows_total + 15) >> 4;
+    const int pos0 = (int)p.pos_offsets[seq];
+
+    int row_pos[MT], win_lo[MT];
+    bool row_ok[MT];
+    int vis_hi[MT], vis_lo[MT];
+    half8 qf[MT][KS];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        const int tile = (unit * NW + wave) * MT + mt;
+        const bool full = tile * 16 + 15 < rows_total;
+        const int tmin = pos0 + (tile * 16) / G, tmax = pos0 + (tile * 16 + 15) / G;
+        vis_hi[mt] = full ? tmin : -1;
+        vis_lo[mt] = p.sliding_window > 0 ? max(0, tmax + 1 - p.sliding_window) : 0;
+        const int rho = tile * 16 + b;
+        row_ok[mt] = rho < rows_total;
+        const int t_local = row_ok[mt] ? rho / G : 0, g = row_ok[mt] ? rho % G : 0;
+        row_pos[mt] = pos0 + t_local;
+        win_lo[mt] = p.sliding_window > 0 ? max(0, row_pos[mt] + 1 - p.sliding_window) : 0;
+        const long q_off = ((long)(tok0 + t_local) * p.nq + kvh * G + g) * HD;
+#pragma unroll
+        for (int s = 0; s < KS; s++) qf[mt][s] = *reinterpret_cast<const half8*>(p.q + q_off + 32 * s + 8 * a);
+    }
+    const int tile_first = unit * NW * MT, tile_last = min(tile_first + NW * MT, tiles_s) - 1;
+    const int t_first = (tile_first * 16) / G, t_last = min(q_len - 1, (tile_last * 16 + 15) / G);
+    const int kv_end = pos0 + t_last + 1;
+    const int kv_begin = p.sliding_window > 0 ? max(0, pos0 + t_first + 1 - p.sliding_window) : 0;
+    const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
+    const int step_lo = (kv_begin / KV_BLOCK) / 4, step_hi = (nblocks + 3) / 4;       // steps of four blocks
+
+    // staging: wave w moves tile w (0: K block 0, 1: K block 1, 2: V block 0, 3: V block 1) of both pairs of a step.  No load
+    // sits under a condition (a conditional load makes hipcc drain vmcnt at the next use of ANY loaded register — here the Q
+    // fragments, i.e. a full memory round trip inside every step): the prefetch index is clamped to the last step instead, and
+    // the block ids are scalar loads (uniform address: lgkmcnt, not vmcnt).
+    const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
+    const __half* pool = wave < 2 ? p.k_pool : p.v_pool;
+    half8 st[2][KS];
+    int phys_next[2];                                    // physical blocks of the step to be requested next (read one step ahead)
+    auto lookup = [&](int sp) {
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+            phys_next[j] = bt[min(4 * sp + 2 * j + (wave & 1), nblocks - 1)];    // past the end: a copy of the last block (finite data), masked below
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const __half* src = pool + ((long)phys_next[j] * p.nkv + kvh) * (long)TILE + lane * 8;
+#pragma unroll
+            for (int s = 0; s < KS; s++) st[j][s] = *reinterpret_cast<const half8*>(src + s * 512);
+        }
+    };
+    // K tiles keep their fragment order; the two V tiles of a pair are interleaved so that the PV A operand of d-tile 2·ld + sub —
+    // the 8-byte half `sub` of the lane's fragment of block 0 followed by the same half of block 1 — is ONE conflict-free
+    // ds_read_b128: 16-byte slot ((sub·KS + ld)·64 + lane) of the pair's V region, block i in its half i
+    auto stash = [&](int stage) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            if (wave < 2) {
+                __half* dst = lds_kv + ((stage * 2 + j) * 4 + wave) * TILE + lane * 8;
+#pragma unroll
+                for (int s = 0; s < KS; s++) *reinterpret_cast<half8*>(dst + s * 512) = st[j][s];
+            } else {
+                __half* dst = lds_kv + ((stage * 2 + j) * 4 + 2) * TILE + lane * 8 + (wave & 1) * 4;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const uint4 w4 = __builtin_bit_cast(uint4, st[j][s]);
+                    *reinterpret_cast<uint2*>(dst + s * 512) = make_uint2(w4.x, w4.y);                 // sub 0
+                    *reinterpret_cast<uint2*>(dst + (KS + s) * 512) = make_uint2(w4.z, w4.w);          // sub 1
+                }
+            }
+        }
+    };
+
+    const float sl2 = p.scale * 1.4426950408889634f;
+    float m_run[MT];
+    float4v o_acc[MT][DT], l_acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+        m_run[mt] = -INFINITY;
+        l_acc[mt] = (float4v){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) o_acc[mt][dt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    }
+    const half8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    if (step_lo < step_hi) {
+        lookup(step_lo);
+        issue();
+        lookup(min(step_lo + 1, step_hi - 1));
+        stash(0);
+    }
+    __syncthreads();
+    for (int sp = step_lo; sp < step_hi; sp++) {
+        const int cur = (sp - step_lo) & 1;
+        issue();                                         // step sp + 1 (clamped), whose block ids arrived during the previous step
+        lookup(min(sp + 2, step_hi - 1));
+        __builtin_amdgcn_sched_barrier(0);
+        const __half* kb = lds_kv + (cur * 8) * TILE + lane * 8;
+        // Sᵀ[key][row]: s[mt][2·j + i] = block i of pair j
+        float4v sv[MT][4];
+        const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const half8 kf = *reinterpret_cast<const half8*>(kb + ((q >> 1) * 4 + (q & 1)) * TILE + s * 512);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+                    sv[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[mt][s], s == 0 ? zero4 : sv[mt][q], 0, 0, 0);
+            }
+        }
+        half8 pf[MT][2];
+        const int key0 = sp * 4 * KV_BLOCK;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const bool clear = key0 + 4 * KV_BLOCK - 1 <= vis_hi[mt] && key0 >= vis_lo[mt];      // wave-uniform
+            if (!clear) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int kp = key0 + q * KV_BLOCK + 4 * a + r;
+                        const bool ok = row_ok[mt] && kp <= row_pos[mt] && kp >= win_lo[mt];
+                        sv[mt][q][r] = ok ? sv[mt][q][r] : -INFINITY;
+                    }
+            }
+            float mx = fmaxf(fmaxf(sv[mt][0][0], sv[mt][0][1]), fmaxf(sv[mt][0][2], sv[mt][0][3]));
+#pragma unroll
+            for (int q = 1; q < 4; q++) mx = fmaxf(mx, fmaxf(fmaxf(sv[mt][q][0], sv[mt][q][1]), fmaxf(sv[mt][q][2], sv[mt][q][3])));
+            mx = rows_reduce_max(mx * sl2);                       // sl2 > 0: the maximum commutes with the scaling
+            const float m_new = fmaxf(m_run[mt], mx);
+            const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+            if (__ballot(m_new != m_run[mt]) != 0) {              // wave-uniform: some row's maximum moved
+                const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_safe);
+#pragma unroll
+                for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o_acc[mt][dt][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; r++) l_acc[mt][r] *= alpha;
+                m_run[mt] = m_new;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        pf[mt][j][4 * i + r] = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[mt][2 * j + i][r], sl2, -m_safe));
+        }
+        // Oᵀ[d][row] += Vᵀ[d][key]·Pᵀ[key][row]; the row sums ride along as one more "d tile" whose A operand is all ones
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const __half* vb = kb + (j * 4 + 2) * TILE;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) l_acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[mt][j], l_acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int ld = 0; ld < KS; ld++) {
+#pragma unroll
+                for (int sub = 0; sub < 2; sub++) {
+                    const half8 vfrag = *reinterpret_cast<const half8*>(vb + (sub * KS + ld) * 512);
+                    const int dt = 2 * ld + sub;
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+                        o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfrag, pf[mt][j], o_acc[mt][dt], 0, 0, 0);
+                }
+            }
+        }
+        stash(cur ^ 1);
+        __syncthreads();
+    }
+    float* lo = reinterpret_cast<float*>(smem) + wave * 16 * HD;
+    const int row = lane >> 2, dl = lane & 3;
+    constexpr int DPL = HD / 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; mt++) {
+#pragma unroll
+        for (int dt = 0; dt < DT; dt++) *reinterpret_cast<float4v*>(&lo[b * HD + dt * 16 + 4 * a]) = o_acc[mt][dt];
+        const float l_row = __shfl(l_acc[mt][0], row, 64);
+        const int rho_o = ((unit * NW + wave) * MT + mt) * 16 + row;
+        if (rho_o < rows_total) {
+            const float inv = l_row > 0.f ? 1.0f / l_row : 0.f;
+            __half* o = p.out + ((long)(tok0 + rho_o / G) * p.nq + kvh * G + rho_o % G) * HD + dl * DPL;
+#pragma unroll
+            for (int i = 0; i < DPL; i += 8) {
+                half8 h;
+#pragma unroll
+                for (int j = 0; j < 8; j++) h[j] = (_Float16)(lo[row * HD + dl * DPL + i + j] * inv);
+                *reinterpret_cast<half8*>(o + i) = h;
+            }
+        }
+    }
+}
+
 // merge grid.z partials: one thread per (row, dim)
 template <int HD>
 __global__ void paged_attn_reduce_kernel(AttnArgs p) {
@@ -715,7 +957,15 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
             }                                                                                                          \
             hipLaunchKernelGGL((paged_prefill_attn_kernel<HDV, MTV>), grid, dim3(256), lds, s, a);                     \
         }
-        if (head_dim == 128) FH_FLASH(128, 2) else if (head_dim == 64) FH_FLASH(64, 2) else FH_FLASH(256, 1)
+        if (head_dim == 128 && !kn.attn_flash32) {           // 64 keys per step: two pairs per stage
+            const size_t lds64 = 2 * lds;
+            static bool attr64 = false;
+            if (!attr64) {
+                FH_CHECK_HIP(hipFuncSetAttribute((const void*)paged_prefill_attn64_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+                attr64 = true;
+            }
+            hipLaunchKernelGGL((paged_prefill_attn64_kernel<128>), grid, dim3(256), lds64, s, a);
+        } else if (head_dim == 128) FH_FLASH(128, 2) else if (head_dim == 64) FH_FLASH(64, 2) else FH_FLASH(256, 1)
 #undef FH_FLASH
         FH_CHECK_LAUNCH();
         form_hit(FORM_ATTN_FLASH);

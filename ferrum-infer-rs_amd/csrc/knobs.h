@@ -22,6 +22,7 @@ struct Knobs {
     long attn_rs_min_wgs = 512;
     bool attn_no_rs = false;
     bool attn_narrow = false;
+    bool attn_flash32 = false;        // the flash form with 32-key steps (paged_prefill_attn_kernel) for head_dim 128 too
     // INT4 GEMMs (w4_gemm.hip)
     int moe_kw_pairs = 8;
     int w4_tile_min_m = 0;
