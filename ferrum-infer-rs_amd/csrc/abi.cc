@@ -62,7 +62,7 @@ void form_hit(Form f) { g_form_hits[f].fetch_add(1, std::memory_order_relaxed); 
 static const char* const g_form_names[FORM_COUNT] = {
     "attn_flash", "attn_row_split", "attn_kv_wide", "attn_kv_narrow", "attn_fused_qkv_wide", "attn_fused_qkv_narrow",
     "attn_split_reduce", "w4_wgsplit", "w4_ldsa", "w4_tilep", "w4_slabs", "w4_slabs_lds", "w4_slabs_tile", "w4_rowsum",
-    "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile128", "moe_merge_route", "route_split",
+    "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "w4_big", "w4_ldsk"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
@@ -391,12 +391,12 @@ int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input,
                                   void* stream) {
     FH_REQUIRE(stack && input && sorted_token_ids && expert_ids && num_tokens_past_padded && output,
                "moe_gemm_phase: null argument");
-    if (moe_block_size != 16 && moe_block_size != 32 && moe_block_size != 64 && moe_block_size != 128) {
-        fh::set_error("moe_gemm_phase: moe_block_size=%d unsupported (16, 32, 64 or 128)", moe_block_size);
+    if (moe_block_size != 16 && moe_block_size != 32 && moe_block_size != 64 && moe_block_size != 96 && moe_block_size != 128) {
+        fh::set_error("moe_gemm_phase: moe_block_size=%d unsupported (16, 32, 64, 96 or 128)", moe_block_size);
         return FERRUM_HIP_UNSUPPORTED;
     }
-    if (moe_block_size == 128 && stack->dev.G % 2 != 0) {
-        fh::set_error("moe_gemm_phase: 128-row blocks need an even number of 128-wide quant groups (K=%d)", stack->dev.k);
+    if (moe_block_size >= 96 && stack->dev.G % 2 != 0) {
+        fh::set_error("moe_gemm_phase: 96- / 128-row blocks need an even number of 128-wide quant groups (K=%d)", stack->dev.k);
         return FERRUM_HIP_UNSUPPORTED;
     }
     FH_REQUIRE(top_k >= 1, "moe_gemm_phase: top_k=%d", top_k);

@@ -66,7 +66,7 @@ enum Form : int {
     FORM_MOE_BLOCK16,
     FORM_MOE_TILE64,
     FORM_MOE_TILE32,
-    FORM_MOE_TILE128,           // prefill: 128-pair blocks through w4_gemm_big_kernel
+    FORM_MOE_TILE_BIG,          // prefill: 96- or 128-pair blocks through w4_gemm_big_kernel
     FORM_MOE_MERGE_ROUTE,
     FORM_ROUTE_SPLIT,           // add + norm + router split over Q parts per token, merge in the launch
     FORM_ROUTE_FUSED,           // add + norm + router + top-k, one workgroup per token

@@ -79,6 +79,7 @@ struct FerrumHipModel {
                                           // of L2 reads costs more than the launch saved (c=4 1455 → 1335 tok/s), so only single rows fuse
     int route_gemm_min_tokens = 512;          // from this many tokens the router runs as a GEMM + top-k (3 launches)
     int moe_tile_min_pairs_per_expert = 32;   // average pairs per expert from which MoE GEMMs use 64-row LDS tiles
+    int moe_tile96_min_pairs_per_expert = 32;         // … from which (even group counts) they use 96-row blocks through w4_gemm_big_kernel<6>
     int moe_tile128_min_pairs_per_expert = 1 << 30;   // … from which they would use 128-row blocks through w4_gemm_big_kernel: off —
                                                       // at K = 2048 / 768 (16 / 6 groups per tile, one workgroup per CU) padding and the
                                                       // un-overlapped prologue / epilogue cost more than the schedule gains (§3)

@@ -331,6 +331,7 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
     if (knobs().attn_flash_min_rows_set) m->attn_flash_min_rows = std::max(1, (int)knobs().attn_flash_min_rows);   // as the launcher reads it
+    if (const char* e = getenv("FERRUM_HIP_MOE_TILE96_PAIRS")) m->moe_tile96_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE128_PAIRS")) m->moe_tile128_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE32_PAIRS")) m->moe_tile32_min_pairs_per_expert = std::max(1, atoi(e));
     *model = m;
@@ -908,6 +909,16 @@ static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted
     const int32_t* ids = moe_ids(m);
     if (P <= 1024) {
         FH_TRY(moe_decode_gemms(m, L, P, max_blocks, s));
+    } else if (P >= (long)m->moe_tile96_min_pairs_per_expert * Eg && L.exp_gate_up.G % 2 == 0 && L.exp_down.G % 2 == 0) {
+        // long prefill: 96-row blocks through w4_gemm_big_kernel<6> (two workgroups per CU; group scale folded into the fp16 B operand)
+        const int sorted_max96 = P + E * 96, max_blocks96 = std::min(sorted_max96 / 96, P / 96 + std::min(P, E));
+        FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 96, sorted_max96, s));
+        {
+            FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                                 max_blocks96, 96, K, 1, s));
+        }
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+                             max_blocks96, 96, 1, 0, s));
     } else if (P >= (long)m->moe_tile128_min_pairs_per_expert * Eg && L.exp_gate_up.G % 2 == 0 && L.exp_down.G % 2 == 0) {
         // long prefill: 128-row blocks through w4_gemm_big_kernel (group scale folded into the fp16 B operand: the matrix pipe, not
         // vector issue, bounds it; twice the padding of 64-row blocks, hence only from a few hundred pairs per expert)

@@ -2554,8 +2554,8 @@ int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int3
                      const int32_t* total_post_pad, int num_valid_pairs, int max_blocks, int block_rows, int top_k, int fused_silu,
                      hipStream_t stream) {
     if (num_valid_pairs <= 0 || max_blocks <= 0) return 0;
-    FH_REQUIRE(block_rows == 128 || block_rows == 64 || block_rows == 32, "w4_gemm_moe_tile: block_rows=%d (128, 64 or 32)", block_rows);
-    FH_REQUIRE(block_rows != 128 || w.G % 2 == 0, "w4_gemm_moe_tile: 128-row blocks need an even number of quant groups (K=%d)", w.k);
+    FH_REQUIRE(block_rows == 128 || block_rows == 96 || block_rows == 64 || block_rows == 32, "w4_gemm_moe_tile: block_rows=%d (128, 96, 64 or 32)", block_rows);
+    FH_REQUIRE(block_rows < 96 || w.G % 2 == 0, "w4_gemm_moe_tile: 96- / 128-row blocks need an even number of quant groups (K=%d)", w.k);
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
     a.expert_stride_qw = (long)w.n64 * w.G * 4 * 64 * 4;
@@ -2567,8 +2567,9 @@ int w4_gemm_moe_tile(const W4Device& w, const __half* x, __half* out, const int3
     a.top_k = top_k;
     dim3 grid(cdiv(w.n64, 4), max_blocks, 1);
     const bool zp = w.zp != nullptr;
-    form_hit(block_rows == 128 ? FORM_MOE_TILE128 : (block_rows == 64 ? FORM_MOE_TILE64 : FORM_MOE_TILE32));
+    form_hit(block_rows >= 96 ? FORM_MOE_TILE_BIG : (block_rows == 64 ? FORM_MOE_TILE64 : FORM_MOE_TILE32));
     if (block_rows == 128) return fused_silu ? launch_big<8, 2>(a, zp, grid, stream) : launch_big<8, 1>(a, zp, grid, stream);
+    if (block_rows == 96) return fused_silu ? launch_big<6, 2>(a, zp, grid, stream) : launch_big<6, 1>(a, zp, grid, stream);
     if (block_rows == 64) return fused_silu ? launch_tile<2, 4>(a, zp, grid, stream) : launch_tile<1, 4>(a, zp, grid, stream);
     return fused_silu ? launch_tile<2, 2>(a, zp, grid, stream) : launch_tile<1, 2>(a, zp, grid, stream);
 }

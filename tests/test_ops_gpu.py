@@ -847,7 +847,7 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
         B.moe_combine(ctx, down, wd, out, tokens, K, H)
         ctx.sync()
         assert nmse(ref, host(out)) < 3e-6, fused            # three fp16 roundings (act, down, out)
-        for blk in ((64, 32) + ((128,) if I % 256 == 0 and H % 256 == 0 else ()) if fused and P >= 64 else ()):
+        for blk in ((64, 32) + ((128, 96) if I % 256 == 0 and H % 256 == 0 else ()) if fused and P >= 64 else ()):
             # 64- and 32-row blocks through the prefill tile kernel: same maths, different block shape; 128-row blocks through
             # w4_gemm_big_kernel: the group scale folded into fp16 weights (one more rounding per weight, like the reference's own
             # fp16 dequantisation), so equal within the tolerance, not bit for bit
@@ -863,7 +863,7 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
             outb = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
             B.moe_combine(ctx, downb, wd, outb, tokens, K, H)
             ctx.sync()
-            if blk != 128: assert torch.equal(actb, act), blk    # per-row sums are independent of the block shape
+            if blk < 96: assert torch.equal(actb, act), blk      # per-row sums are independent of the block shape
             else: assert nmse(host(act), host(actb)) < 1e-6, blk
             assert nmse(ref, host(outb)) < 3e-6, blk
         # expert-major grid straight from the raw expert ids (no align arrays): bit-identical outputs; experts with more
