@@ -1866,6 +1866,15 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void w4_gemm_big_kernel(W4Arg
             aoff[mt] = ((uint32_t)(r < p.M ? r : p.M - 1) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
         }
     }
+    // MoE: the valid rows of an align block are a prefix; 16-row tiles that hold only padding are skipped (their MFMAs, not the
+    // side work riding behind them): at ≈ 512 pairs per expert 96-row blocks carry ≈ 19 % padding rows, 16-row granularity ≈ 2 %
+    int mt_valid = MT;
+    if (MODE != 0) {
+        mt_valid = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) mt_valid += __ballot(row_out_l[mt] >= 0) != 0 ? 1 : 0;
+        mt_valid = __builtin_amdgcn_readfirstlane(mt_valid);
+    }
     const char* qw_wave = reinterpret_cast<const char*>(qw) + ((long)st * p.G * 4) * 64 * 16;
     const char* sc_wave = reinterpret_cast<const char*>(sc) + ((long)st * p.G) * 16 * 8;
     const char* zp_wave = HAS_ZP ? reinterpret_cast<const char*>(zp) + ((long)st * p.G) * 16 * 8 : nullptr;
@@ -1952,26 +1961,29 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void w4_gemm_big_kernel(W4Arg
     // move A(g+1) from its staging registers to LDS and request A(g+2).
     uint32_t tt[4];
     half8 af[2];
-    auto k_step = [&](int ks, int sl, int g) __attribute__((always_inline)) {
+    // AT = row tiles that hold real rows (MoE: the valid rows of an align block are a prefix; at ≈ 512 pairs per expert 96-row
+    // blocks carry ≈ 19 % padding rows — a block whose tail tiles are all padding runs the 2- or 4-tile body instead)
+    auto k_step = [&](auto at_c, int ks, int sl, int g) __attribute__((always_inline)) {
+        constexpr int AT = decltype(at_c)::value;
+        static_assert(AT % 2 == 0 && AT <= MT, "the A-fragment ping-pong returns to slot 0 at every k-step");
         const half8* at = lds_a + sl * FR;
-        constexpr int NM = MT * 4;                   // MFMAs per k-step
+        constexpr int NM = AT * 4;                   // MFMAs per k-step
         const int nks = (ks + 1) & 3, npr = nks >> 1, nsl = ks == 3 ? (sl ^ 1) : sl;     // the k-step whose operands are built now
-        static_assert(MT % 2 == 0, "the A-fragment ping-pong returns to slot 0 at every k-step");
         if (ks == 0) af[0] = at[lane];               // (the group's barrier has just been passed)
 #pragma unroll
-        for (int mt = 0; mt < MT; mt++) {
+        for (int mt = 0; mt < AT; mt++) {
             const int cp = mt & 1;
 #pragma unroll
             for (int nt = 0; nt < 4; nt++) {
                 const int q = mt * 4 + nt;
                 FH_MFMA(acc[mt][nt], af[cp], bq[ks & 1][nt], tt);
                 if (nt == 0) {
-                    if (mt + 1 < MT) af[cp ^ 1] = at[((mt + 1) * 4 + ks) * 64 + lane];
+                    if (mt + 1 < AT) af[cp ^ 1] = at[((mt + 1) * 4 + ks) * 64 + lane];
                     else if (ks < 3) af[cp ^ 1] = at[(ks + 1) * 64 + lane];          // first fragment of the next k-step
-                    if (ks < 2) {                    // staging rows mt' = ks·MT/2 … of this k-step's share
-                        constexpr int HM = (MT + 1) / 2;
+                    if (ks < 2) {                    // staging rows mt' = ks·AT/2 … of this k-step's share
+                        constexpr int HM = (AT + 1) / 2;
                         const int smt = ks * HM + mt;
-                        if (mt < HM && smt < MT) {
+                        if (mt < HM && smt < AT) {
                             lds_a[(sl ^ 1) * FR + (smt * 4 + wave) * 64 + lane] = areg[smt];   // A(g+1) → LDS
                             issue_a(smt, min(g + 2, gl));                                      // A(g+2) requested
                         }
@@ -1984,14 +1996,14 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void w4_gemm_big_kernel(W4Arg
             }
         }
     };
-    auto group = [&](int sl, int g) __attribute__((always_inline)) {
-        k_step(0, sl, g);
-        k_step(1, sl, g);
-        k_step(2, sl, g);
+    auto group = [&](auto at_c, int sl, int g) __attribute__((always_inline)) {
+        k_step(at_c, 0, sl, g);
+        k_step(at_c, 1, sl, g);
+        k_step(at_c, 2, sl, g);
         prep_scales(sl ^ 1);
         issue_w(sl, min(g + 2, gl));            // this slot's words are all expanded: group g+2
         FH_PIN();
-        k_step(3, sl, g);
+        k_step(at_c, 3, sl, g);
         __syncthreads();                        // A(g+1) is in LDS; every wave is done with A(g)
     };
     // prologue
@@ -2008,16 +2020,13 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void w4_gemm_big_kernel(W4Arg
     for (int nt = 0; nt < 4; nt++) finish(0, 0, nt, 0);            // operands of k-step 0 of the first group
     __syncthreads();
     FH_PIN();
-    for (int g = gz0; g < gz1; g += 2) {       // an even number of groups per split (the launcher checks)
-#ifdef FH_EXP_TOUCH
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++) asm volatile("" : "+a"(acc[mt][nt]));
-#endif
-        group(0, g);
-        group(1, g + 1);
-    }
+    auto run = [&](auto at_c) __attribute__((always_inline)) {
+        for (int g = gz0; g < gz1; g += 2) {   // an even number of groups per split (the launcher checks)
+            group(at_c, 0, g);
+            group(at_c, 1, g + 1);
+        }
+    };
+    run(std::integral_constant<int, MT>{});
 #undef FH_PIN
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results before any VALU reads them
     if (!st_ok) return;
