@@ -115,32 +115,70 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t*
                                                                   int32_t* __restrict__ pairs_by_token,
                                                                   int32_t* __restrict__ packed_token_idx,
                                                                   int32_t* __restrict__ expert_offsets, int top_k) {
+    // One workgroup per expert.  Every thread keeps CH = 64 CONSECUTIVE pair ids in registers (all 16 loads of a trip in flight
+    // at once; a trip covers 65 536 pairs — an 8192-token prefill of a top-8 model is one trip), so the histogram and the ordered
+    // compaction (ascending pair id = thread order, then element order) both run from registers with ONE workgroup scan per
+    // trip.  (Before: 64 serialised load → LDS-atomic round trips for the histogram and 16 scan trips of two barriers each:
+    // 52 µs per layer at 8192 tokens.)
     __shared__ int counts[MAX_EXPERTS];
     __shared__ int wave_cnt[ALIGN_THREADS / 64];
     __shared__ int s_offset, s_total, s_unpadded;
-    constexpr int NT = ALIGN_THREADS, NWV = ALIGN_THREADS / 64;
+    constexpr int NT = ALIGN_THREADS, NWV = ALIGN_THREADS / 64, CH = 64, TRIP = NT * CH;
     const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < num_experts; i += NT) counts[i] = 0;
     __syncthreads();
-    for (int p = tid; p < n_pairs; p += NT) {
-        int x = expert_ids[p];
-        if (x >= 0 && x < num_experts) atomicAdd(&counts[x], 1);
-        else if (MODE == 2 && e == 0) pairs_by_token[p] = -1;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(expert_ids) & 15) == 0;
+    int ids[CH];
+    auto load_trip = [&](int trip0) {
+        const int p = trip0 + tid * CH;
+        if (vec_ok && p + CH <= n_pairs) {
+#pragma unroll
+            for (int q = 0; q < CH / 4; q++) {
+                const int4 v = *reinterpret_cast<const int4*>(expert_ids + p + 4 * q);
+                ids[4 * q] = v.x; ids[4 * q + 1] = v.y; ids[4 * q + 2] = v.z; ids[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < CH; jj++) ids[jj] = p + jj < n_pairs ? expert_ids[p + jj] : -2;      // −2: beyond the input
+        }
+    };
+    const int ntrips = (n_pairs + TRIP - 1) / TRIP;
+    for (int t = 0; t < ntrips; t++) {
+        load_trip(t * TRIP);
+        const int p = t * TRIP + tid * CH;
+#pragma unroll
+        for (int jj = 0; jj < CH; jj++) {
+            const int x = ids[jj];
+            if (x >= 0 && x < num_experts) atomicAdd(&counts[x], 1);
+            else if (MODE == 2 && e == 0 && x != -2) pairs_by_token[p + jj] = -1;
+        }
     }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0, mine = 0, uacc = 0, umine = 0;
-        for (int i = 0; i < num_experts; i++) {
-            if (i == e) { mine = acc; umine = uacc; }
-            if (MODE == 2 && e == 0) expert_offsets[i] = uacc;
-            acc += ((counts[i] + block_size - 1) / block_size) * block_size;
-            uacc += counts[i];
+    if (wave == 0) {        // exclusive scans over the experts (padded and unpadded), lanes take contiguous runs of experts
+        const int per = (num_experts + 63) / 64, i0 = lane * per;
+        int pad_sum = 0, raw_sum = 0;
+        for (int i = i0; i < min(i0 + per, num_experts); i++) {
+            pad_sum += ((counts[i] + block_size - 1) / block_size) * block_size;
+            raw_sum += counts[i];
         }
-        s_offset = mine;
-        s_total = acc;
-        s_unpadded = umine;
-        if (MODE != 2 && e == 0) total_post_pad[0] = acc;
-        if (MODE == 2 && e == 0) expert_offsets[num_experts] = uacc;
+        int pad_incl = pad_sum, raw_incl = raw_sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int tp = __shfl_up(pad_incl, off, 64), tr = __shfl_up(raw_incl, off, 64);
+            if (lane >= off) { pad_incl += tp; raw_incl += tr; }
+        }
+        int pad_acc = pad_incl - pad_sum, raw_acc = raw_incl - raw_sum;
+        for (int i = i0; i < min(i0 + per, num_experts); i++) {
+            if (i == e) { s_offset = pad_acc; s_unpadded = raw_acc; }
+            if (MODE == 2 && e == 0) expert_offsets[i] = raw_acc;
+            pad_acc += ((counts[i] + block_size - 1) / block_size) * block_size;
+            raw_acc += counts[i];
+        }
+        if (lane == 63) {
+            s_total = pad_incl;
+            if (MODE != 2 && e == 0) total_post_pad[0] = pad_incl;
+            if (MODE == 2 && e == 0) expert_offsets[num_experts] = raw_incl;
+        }
     }
     __syncthreads();
     const int offset = MODE == 2 ? s_unpadded : s_offset, total = s_total;
@@ -156,23 +194,19 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t*
         for (int i = tid; i < cnt; i += NT) sorted_token_ids[offset + i] = s_unpadded + i;
         return;
     }
-    // ordered compaction, 4 consecutive pairs per thread and 4096 per trip (ascending pair id is kept: thread order,
-    // then element order); a prefill batch has tens of thousands of pairs, so barrier trips matter
+    // ordered compaction: one workgroup scan per trip
     int base = 0;
-    for (int p0 = 0; p0 < n_pairs; p0 += NT * 4) {
-        const int p = p0 + tid * 4;
-        bool mine[4];
+    for (int t = 0; t < ntrips; t++) {
+        if (ntrips > 1) load_trip(t * TRIP);        // (a single trip is still in registers)
+        const int p = t * TRIP + tid * CH;
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            mine[j] = p + j < n_pairs && expert_ids[p + j] == e;
-            c += mine[j] ? 1 : 0;
-        }
+        for (int jj = 0; jj < CH; jj++) c += ids[jj] == e ? 1 : 0;
         int incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            int t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
+            const int tv = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += tv;
         }
         if (lane == 63) wave_cnt[wave] = incl;
         __syncthreads();
@@ -184,17 +218,19 @@ __global__ __launch_bounds__(ALIGN_THREADS) void moe_align_kernel(const int32_t*
             chunk_total += wc;
         }
         int pos = offset + base + before + incl - c;
+        if (c > 0) {
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (mine[j]) {
-                if (MODE == 2) {
-                    pairs_by_token[p + j] = pos;
-                    packed_token_idx[pos] = (p + j) / top_k;
-                    pos++;
-                } else {
-                    sorted_token_ids[pos++] = p + j;
+            for (int jj = 0; jj < CH; jj++)
+                if (ids[jj] == e) {
+                    if (MODE == 2) {
+                        pairs_by_token[p + jj] = pos;
+                        packed_token_idx[pos] = (p + jj) / top_k;
+                        pos++;
+                    } else {
+                        sorted_token_ids[pos++] = p + jj;
+                    }
                 }
-            }
+        }
         base += chunk_total;
         __syncthreads();
     }
