@@ -124,7 +124,8 @@ int ferrum_hip_gptq_info(const FerrumHipGptq* handle, int* k, int* n, int* num_e
 int ferrum_hip_gptq_linear_forward_f16(const FerrumHipGptq* handle, const void* in, void* out, int m,
                                        FerrumHipWorkspace* ws, void* stream);
 /* One launch over the align-block routing arrays (moe_block_size 16: one-wave decode kernel; 32 or 64: LDS-tiled prefill
- * kernel; anything else → FERRUM_HIP_UNSUPPORTED): for every valid sorted id p,
+ * kernel; 96 or 128: the tall-tile prefill kernel — K must be a multiple of 256 — whose fp16 weights are (q − zero)·scale
+ * rounded once, like the reference's own dequantisation; anything else → FERRUM_HIP_UNSUPPORTED): for every valid sorted id p,
  * out[p] = in[p / top_k]·W[block expert]ᵀ; with fused_silu_mul the stack must have been loaded with
  * fuse_gate_up and out[p] = silu(gate)·up ([T·k, N/2]).  prob_m = number of valid pair ids. */
 int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input, const int32_t* sorted_token_ids,
