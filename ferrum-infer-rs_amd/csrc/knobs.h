@@ -31,7 +31,7 @@ struct Knobs {
     int w4_ldsa_nw = 0;
     int w4_ldsa_s = 0;
     int w4_big = 0;                   // 0 auto, −1 never, 8 / 16 forces w4_gemm_big_kernel's 128- / 256-row tiles
-    int w4_ldsk = 0;                  // development: nw·100 + kw·10 + d forces a w4_gemm_ldsk_kernel form
+    int w4_ldsk = 0;                  // EXPERIMENTS=1 builds only: nw·100 + kw·10 + d forces a w4_gemm_ldsk_kernel form (+1000: ares)
     int w4_nt = 0;
     int w4_w = 0;
     int lds_min_wgs = 128;

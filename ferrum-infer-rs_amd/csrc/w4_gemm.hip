@@ -1115,263 +1115,9 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
         }
 }
 
-// ── dense GEMM for 17–64 rows, small and mid-sized projections: LDS-shared activations AND K split over the waves ─────
-// w4_gemm_ldsa_kernel holds one wave per SIMD with a four-group ring (200 VGPRs) and needs a slab per K split; on the small
-// projections of a decode layer (o_proj 4096→4096: 8 MB of weights, 2048 units of 4 KiB) that leaves three quarters of the CUs
-// without a workgroup.  Here a workgroup is NW column waves × KW K-slice waves: round r hands quant group g0 + r·KW + kw to
-// the waves of slice kw, the KW activation tiles of a round are staged once in LDS (each shared by the NW column waves),
-// the ring is D deep and the KW partial accumulators meet in LDS after the loop — so the same number of slabs puts KW× more
-// waves on the chip, each with 1–2 groups in flight (bytes in flight come from occupancy, not ring depth).
-template <int MT, int NW, int KW, int D, bool HAS_ZP>
-__global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ldsk_kernel(W4Args p) {
-    static_assert(D == 2 || D == 4, "ring depth: LDS buffer parity follows the unrolled slot");
-    static_assert((MT * 4) % NW == 0 && (MT * 16) % KW == 0, "staging / reduction split");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [2][KW][MT·4][64] half8
-    float* red = reinterpret_cast<float*>(lds_raw);            // after the loop: [KW][NW][V][64] fp32
-    constexpr int FRW = MT * 4;                                 // fragment rows (64 × 16 B) per activation tile
-    constexpr int ALD = FRW / NW;                               // fragment rows each wave stages per round
-    constexpr int V = MT * 16;                                  // accumulator floats per lane
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int cw = wave % NW, kw = KW == 1 ? 0 : wave / NW;
-    const int a = lane >> 4, b = lane & 15;
-    const int st_raw = blockIdx.x * NW + cw;
-    const bool st_ok = st_raw < p.n64;
-    const int st = st_ok ? st_raw : p.n64 - 1;
-    const int rb = blockIdx.y, z = blockIdx.z;
-    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
-    const int R = (g1 - g0 + KW - 1) / KW;                      // rounds
-    const int gl = g1 - 1;
-
-    // staging: this wave brings fragment rows cw, cw + NW, … of ITS slice's tile (row mt·16 + (l & 15), k = 32 s + 8 (l >> 4))
-    const __half* asrc[ALD];
-#pragma unroll
-    for (int i = 0; i < ALD; i++) {
-        const int fr = cw + i * NW, mt = fr >> 2, s = fr & 3;
-        const int r = rb * 16 * MT + mt * 16 + (lane & 15);
-        asrc[i] = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + 32 * s + 8 * (lane >> 4);
-    }
-    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
-    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4) * 64 + lane;
-    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc) + ((long)st * p.G) * 16 + b;
-    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp) + ((long)st * p.G) * 16 + b : nullptr;
-
-    float4v acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
-
-    u32x4g wq[D][4];
-    uint2 scv[D], zpv[D];
-    half8 areg[D][ALD];
-    auto issue = [&](int slot, int r) {                         // clamped: no load under a runtime condition
-        const int g = min(g0 + r * KW + kw, gl);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
-        scv[slot] = sc_lane[(long)g * 16];
-        if (HAS_ZP) zpv[slot] = zp_lane[(long)g * 16];
-#pragma unroll
-        for (int i = 0; i < ALD; i++) areg[slot][i] = *reinterpret_cast<const half8*>(asrc[i] + (long)g * 128);
-    };
-    auto store_a = [&](int slot, int buf) {
-#pragma unroll
-        for (int i = 0; i < ALD; i++) lds_a[((buf * KW + kw) * FRW + cw + i * NW) * 64 + lane] = areg[slot][i];
-    };
-    auto consume = [&](int slot, int buf, int r) {
-        if (g0 + r * KW + kw > gl) return;                      // wave-uniform: a ragged last round
-        half8 af[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) af[mt][s] = lds_a[((buf * KW + kw) * FRW + mt * 4 + s) * 64 + lane];
-        const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
-        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
-        w4_consume_group<MT, 4, HAS_ZP>(wq[slot], sb, zb, 0, af, acc);
-    };
-#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
-    if (R > 0) {
-#pragma unroll
-        for (int d = 0; d < D - 1; d++) issue(d, min(d, R - 1));
-        FH_PIN();
-        store_a(0, 0);
-        __syncthreads();
-        int rbase = 0;
-        for (; rbase + D <= R; rbase += D) {
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                const int r = rbase + d;
-                issue((d + D - 1) % D, min(r + D - 1, R - 1));
-                FH_PIN();
-                if (D > 2) store_a((d + 1) % D, (d + 1) & 1);   // A(r+1), requested D − 2 rounds ago
-                consume(d, d & 1, r);
-                if (D == 2) store_a((d + 1) % D, (d + 1) & 1);  // A(r+1), requested above: after the MFMAs of this round
-                FH_PIN();
-                __syncthreads();
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D - 1; d++) {
-            if (rbase + d < R) {
-                if (d + 1 < D - 1) store_a(d + 1, (d + 1) & 1);
-                consume(d, d & 1, rbase + d);
-                __syncthreads();
-            }
-        }
-    }
-#undef FH_PIN
-    // the KW slices meet in LDS (fixed order kw = 0 … KW−1); every wave finishes V / KW of its column wave's accumulators
-    if (KW > 1) {
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) red[((kw * NW + cw) * V + (mt * 4 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
-        __syncthreads();
-    }
-    if (!st_ok) return;
-    float* slab = p.partial ? p.partial + (long)z * p.rows_pad * p.n_pad : nullptr;
-#pragma unroll
-    for (int i = 0; i < V / KW; i++) {
-        const int v = kw * (V / KW) + i;
-        const int r = v & 3, nt = (v >> 2) & 3, mt = v >> 4;
-        float sum;
-        if (KW > 1) {
-            sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < KW; k++) sum += red[((k * NW + cw) * V + v) * 64 + lane];
-        } else {
-            sum = acc[mt][nt][r];
-        }
-        const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
-        const int col = st * 64 + nt * 16 + b;
-        if (slab) {
-            slab[(long)row * p.n_pad + col] = sum;
-        } else if (row < p.M && col < p.N) {
-            if (p.bias) sum += __half2float(p.bias[col]);
-            p.out[(long)row * p.ldo + col] = __float2half(sum);
-        }
-    }
-}
-
-// ── dense GEMM for 17–64 rows: the workgroup's WHOLE activation slice resident in LDS, waves free-running ─────────────
-// At 17–32 rows the ring kernels above are bound by instruction issue, not HBM (≈ 150 VALU + 40 MFMA per 4 KiB of weights and
-// wave), and their per-group barrier keeps the waves of a SIMD in the same phase — all expanding nibbles, then all waiting on
-// the matrix pipe — so vector and matrix work never overlap.  Here the K range of a workgroup is short enough (≤ 128 KiB of
-// fp16 rows) to be staged ONCE, straight from global memory into the fragment-major LDS image (global_load_lds_dwordx4: no
-// VGPR round trip), behind the first weight groups; after that single barrier every wave streams its own weight groups
-// (NW column waves × KW K-slice waves, ring of D) at its own pace and the waves drift apart.  The KW slices meet in LDS at the
-// end (fixed order); K may also be split over grid.z into fp32 slabs.
-template <int MT, int NW, int KW, int D, bool HAS_ZP, bool ILV = (NW * KW <= 8)>
-__global__ __launch_bounds__(NW * KW * 64) void w4_gemm_ares_kernel(W4Args p) {
-    static_assert((MT * 16) % KW == 0, "reduction split");
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    half8* lds_a = reinterpret_cast<half8*>(lds_raw);          // [Gl][MT·4][64] half8
-    float* red = reinterpret_cast<float*>(lds_raw);            // after the loop: [KW][NW][V][64] fp32
-    constexpr int FRW = MT * 4, V = MT * 16, NWAVES = NW * KW;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int cw = wave % NW, kw = KW == 1 ? 0 : wave / NW;
-    const int a = lane >> 4, b = lane & 15;
-    const int st_raw = blockIdx.x * NW + cw;
-    const bool st_ok = st_raw < p.n64;
-    const int st = st_ok ? st_raw : p.n64 - 1;
-    const int rb = blockIdx.y, z = blockIdx.z;
-    const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
-    const int Gl = g1 - g0;
-    const int ni = Gl > kw ? (Gl - kw + KW - 1) / KW : 0;       // this wave's groups: local index kw + i·KW
-    typedef uint32_t u32x4g __attribute__((ext_vector_type(4)));
-    const u32x4g* qw_lane = reinterpret_cast<const u32x4g*>(p.qw) + ((long)st * p.G * 4) * 64 + lane;
-    const uint2* sc_lane = reinterpret_cast<const uint2*>(p.sc) + ((long)st * p.G) * 16 + b;
-    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(p.zp) + ((long)st * p.G) * 16 + b : nullptr;
-
-    float4v acc[MT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
-    u32x4g wq[D][4];
-    uint2 scv[D], zpv[D];
-    auto issue = [&](int slot, int i) {                         // clamped: no load under a runtime condition
-        const int g = g0 + min(kw + max(min(i, ni - 1), 0) * KW, Gl - 1);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) wq[slot][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
-        scv[slot] = sc_lane[(long)g * 16];
-        if (HAS_ZP) zpv[slot] = zp_lane[(long)g * 16];
-    };
-    auto consume = [&](int slot, int i) {
-        const int j = kw + i * KW;
-        half8 af[MT][4];
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int s = 0; s < 4; s++) af[mt][s] = lds_a[(j * FRW + mt * 4 + s) * 64 + lane];
-        const unsigned long long sb = ((unsigned long long)scv[slot].y << 32) | scv[slot].x;
-        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[slot].y << 32) | zpv[slot].x) : 0ull;
-        w4_consume_group<MT, 4, HAS_ZP, ILV>(wq[slot], sb, zb, 0, af, acc);
-    };
-#pragma unroll
-    for (int d = 0; d < D - 1; d++) issue(d, d);
-    __builtin_amdgcn_sched_barrier(0);
-    {   // stage the activation slice: fragment row f = (local group, mt, k-step) ← lanes (row mt·16 + (l & 15), k = 32 s + 8 (l >> 4))
-        const int r_lo = rb * 16 * MT + (lane & 15);
-        for (int f = wave; f < Gl * FRW; f += NWAVES) {
-            const int gq = f / FRW, fr = f - gq * FRW, mt = fr >> 2, s = fr & 3;
-            const int r = r_lo + mt * 16;
-            const __half* src = p.x + (long)(r < p.M ? r : p.M - 1) * p.K + (long)(g0 + gq) * 128 + 32 * s + 8 * (lane >> 4);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(lds_a + (long)f * 64), 16, 0, 0);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    {
-        int ib = 0;
-        for (; ib + D <= ni; ib += D) {
-#pragma unroll
-            for (int d = 0; d < D; d++) {
-                issue((d + D - 1) % D, ib + d + D - 1);
-                consume(d, ib + d);
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D - 1; d++)
-            if (ib + d < ni) consume(d, ib + d);
-    }
-    if (KW > 1) {
-        __syncthreads();                                        // every wave is done with the activation image
-#pragma unroll
-        for (int mt = 0; mt < MT; mt++)
-#pragma unroll
-            for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) red[((kw * NW + cw) * V + (mt * 4 + nt) * 4 + r) * 64 + lane] = acc[mt][nt][r];
-        __syncthreads();
-    }
-    if (!st_ok) return;
-    float* slab = p.partial ? p.partial + (long)z * p.rows_pad * p.n_pad : nullptr;
-#pragma unroll
-    for (int i = 0; i < V / KW; i++) {
-        const int v = kw * (V / KW) + i;
-        const int r = v & 3, nt = (v >> 2) & 3, mt = v >> 4;
-        float sum;
-        if (KW > 1) {
-            sum = 0.f;
-#pragma unroll
-            for (int k = 0; k < KW; k++) sum += red[((k * NW + cw) * V + v) * 64 + lane];
-        } else {
-            sum = acc[mt][nt][r];
-        }
-        const int row = rb * 16 * MT + mt * 16 + 4 * a + r;
-        const int col = st * 64 + nt * 16 + b;
-        if (slab) {
-            slab[(long)row * p.n_pad + col] = sum;
-        } else if (row < p.M && col < p.N) {
-            if (p.bias) sum += __half2float(p.bias[col]);
-            p.out[(long)row * p.ldo + col] = __float2half(sum);
-        }
-    }
-}
+#ifdef FERRUM_HIP_EXPERIMENTS
+#include "experiments_w4_decode_forms.inc"
+#endif
 
 // ── MoE prefill grouped GEMM: 64-row tiles, activations through LDS, 4 waves × 64 columns ──────────────────────
 // For blocks of 64 sorted pairs the skinny kernels re-fetch their A fragments from L2 for every 64-column supertile and
@@ -2131,49 +1877,9 @@ static int launch_ldsa(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stre
     return 0;
 }
 
-template <int MT, int NW, int KW, int D>
-static int launch_ldsk(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
-    const size_t lds_a = (size_t)2 * KW * MT * 4 * 64 * 16, lds_r = KW > 1 ? (size_t)KW * NW * MT * 16 * 64 * 4 : 0;
-    const size_t lds = lds_a > lds_r ? lds_a : lds_r;
-    if (has_zp) hipLaunchKernelGGL((w4_gemm_ldsk_kernel<MT, NW, KW, D, true>), grid, dim3(NW * KW * 64), lds, stream, a);
-    else hipLaunchKernelGGL((w4_gemm_ldsk_kernel<MT, NW, KW, D, false>), grid, dim3(NW * KW * 64), lds, stream, a);
-    FH_CHECK_LAUNCH();
-    return 0;
-}
-
-template <int MT, int NW, int KW, int D>
-static int launch_ares(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
-    const int gl = cdiv(a.G, a.S);
-    const size_t lds_a = (size_t)gl * MT * 4 * 64 * 16, lds_r = KW > 1 ? (size_t)KW * NW * MT * 16 * 64 * 4 : 0;
-    const size_t lds = lds_a > lds_r ? lds_a : lds_r;
-    FH_REQUIRE(lds <= 160 * 1024, "w4_gemm_ares: %d groups of %d row tiles need %zu bytes of LDS", gl, MT, lds);
-    if (has_zp) hipLaunchKernelGGL((w4_gemm_ares_kernel<MT, NW, KW, D, true>), grid, dim3(NW * KW * 64), lds, stream, a);
-    else hipLaunchKernelGGL((w4_gemm_ares_kernel<MT, NW, KW, D, false>), grid, dim3(NW * KW * 64), lds, stream, a);
-    FH_CHECK_LAUNCH();
-    return 0;
-}
-
-// development: FERRUM_HIP_W4_LDSK = nw·100 + kw·10 + d picks a form of w4_gemm_ldsk_kernel (0 → not compiled in);
-// 1000 + that picks the same shape of w4_gemm_ares_kernel
-static int launch_ldsk_code(int mt, int code, const W4Args& a, bool has_zp, int n64, int row_blocks, hipStream_t stream) {
-    if (code >= 1000) {
-        code -= 1000;
-        const dim3 grid(cdiv(n64, code / 100), row_blocks, a.S);
-#define FH_A(MTV, NWV, KWV, DV) if (mt == MTV && code == NWV * 100 + KWV * 10 + DV) return launch_ares<MTV, NWV, KWV, DV>(a, has_zp, grid, stream)
-        FH_A(2, 4, 1, 2); FH_A(2, 4, 2, 2); FH_A(2, 4, 2, 3); FH_A(2, 4, 4, 2); FH_A(2, 2, 2, 2); FH_A(2, 2, 4, 2); FH_A(2, 8, 1, 2);
-        FH_A(2, 2, 8, 2); FH_A(4, 4, 1, 2); FH_A(4, 4, 2, 2); FH_A(4, 2, 2, 2);
-#undef FH_A
-        return -1;
-    }
-    const int nw = code / 100;
-    const dim3 grid(cdiv(n64, nw), row_blocks, a.S);
-#define FH_K(MTV, NWV, KWV, DV) if (mt == MTV && code == NWV * 100 + KWV * 10 + DV) return launch_ldsk<MTV, NWV, KWV, DV>(a, has_zp, grid, stream)
-    FH_K(2, 4, 1, 4); FH_K(2, 4, 2, 2); FH_K(2, 4, 2, 4); FH_K(2, 4, 4, 2); FH_K(2, 2, 2, 2); FH_K(2, 2, 4, 2); FH_K(2, 2, 4, 4);
-    FH_K(2, 2, 8, 2); FH_K(2, 1, 8, 2);
-    FH_K(4, 4, 1, 2); FH_K(4, 4, 1, 4); FH_K(4, 4, 2, 2); FH_K(4, 2, 2, 2); FH_K(4, 2, 4, 2);
-#undef FH_K
-    return -1;
-}
+#ifdef FERRUM_HIP_EXPERIMENTS
+#include "experiments_w4_decode_launchers.inc"
+#endif
 
 template <int MT, int NT>
 static int launch_wgsplit(const W4Args& a, bool has_zp, dim3 grid, int W, hipStream_t stream) {
@@ -2280,6 +1986,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
             return MTv == 16 ? launch_big<16>(a, w.zp != nullptr, grid, stream) : launch_big<8>(a, w.zp != nullptr, grid, stream);
         }
     }
+#ifdef FERRUM_HIP_EXPERIMENTS
     if (kn.w4_ldsk && mt >= 2 && w.perm == nullptr) {
         int S = std::max(1, std::min(kn.w4_ldsa_s, w.G));
         const int rows_pad = row_blocks * 16 * mt, n_pad = w.n64 * 64;
@@ -2295,6 +2002,9 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
         FH_CHECK_LAUNCH();
         return 0;
     }
+#else
+    FH_REQUIRE(kn.w4_ldsk == 0, "FERRUM_HIP_W4_LDSK: the experimental decode GEMM forms are not compiled in (make EXPERIMENTS=1)");
+#endif
     const int tile_min_env = kn.w4_tile_min_m;
     const int tile_min_m = tile_min_env > 0 ? tile_min_env : ((long)w.k * w.n >= (12L << 20) ? 33 : 64);
     if (m >= tile_min_m && w.perm == nullptr) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sweep of w4_gemm_ldsk_kernel forms (FERRUM_HIP_W4_LDSK = nw·100 + kw·10 + d, FERRUM_HIP_W4_LDSA_S = slabs) against the
 default dense path at decode shapes: µs per launch (events over rotating weight copies) and max |Δ| vs the default.
-Development aid."""
+Development aid; needs the library built with `make -C ferrum-infer-rs_amd/csrc EXPERIMENTS=1` (the forms are not in the product build)."""
 import os, sys
 import numpy as np
 import torch
