@@ -1155,15 +1155,19 @@ __global__ __launch_bounds__(256, 2) void w4_gemm_tile_kernel(W4Args p) {
     // mt·16 + b of its lane; the epilogue needs rows mt·16 + 4a + r
     int row_in[MTN], row_out_l[MTN];
     {
+        // (independent reads, in bounds for every launched row block: requested together — one round trip, not three)
         const int total = *p.total_post_pad;
-        if (rb * ROWS >= total) return;
         const int e = p.block_ids[rb];
+        int ids[MTN];
+#pragma unroll
+        for (int mt = 0; mt < MTN; mt++) ids[mt] = p.sorted_token_ids[rb * ROWS + mt * 16 + b];
+        if (rb * ROWS >= total) return;
         qw += (long)e * p.expert_stride_qw;
         sc += (long)e * p.expert_stride_sc;
         if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
 #pragma unroll
         for (int mt = 0; mt < MTN; mt++) {
-            const int id = p.sorted_token_ids[rb * ROWS + mt * 16 + b];
+            const int id = ids[mt];
             row_out_l[mt] = id < p.M ? id : -1;
             row_in[mt] = id < p.M ? id / p.top_k : 0;
         }
@@ -1594,14 +1598,20 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void w4_gemm_big_kernel(W4Arg
     uint32_t aoff[MT];                                          // byte offset of this thread's staging rows: scalar base + 32-bit offset
     int row_out_l[MODE != 0 ? MT : 1];                          // MoE: output row (pair id) of tile row mt·16 + b, −1 = padding
     if (MODE != 0) {
-        if (rb * ROWS >= *p.total_post_pad) return;
+        // the three reads a tile starts with are independent and in bounds for every launched row block (padding blocks hold
+        // sentinels): request them together, then decide — one memory round trip instead of three before the first A row
+        const int total = *p.total_post_pad;
         const int e = p.block_ids[rb];
+        int ids[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) ids[mt] = p.sorted_token_ids[rb * ROWS + mt * 16 + b];
+        if (rb * ROWS >= total) return;
         qw += (long)e * p.expert_stride_qw;
         sc += (long)e * p.expert_stride_sc;
         if (HAS_ZP) zp += (long)e * p.expert_stride_sc;
 #pragma unroll
         for (int mt = 0; mt < MT; mt++) {
-            const int id = p.sorted_token_ids[rb * ROWS + mt * 16 + b];
+            const int id = ids[mt];
             row_out_l[mt] = id < p.M ? id : -1;
             aoff[mt] = ((uint32_t)(id < p.M ? id / p.top_k : 0) * (uint32_t)p.K + 32 * wave + 8 * a) * 2u;
         }
