@@ -127,7 +127,9 @@ int ferrum_hip_gptq_linear_forward_f16(const FerrumHipGptq* handle, const void* 
  * kernel; 96 or 128: the tall-tile prefill kernel — K must be a multiple of 256 — whose fp16 weights are (q − zero)·scale
  * rounded once, like the reference's own dequantisation; anything else → FERRUM_HIP_UNSUPPORTED): for every valid sorted id p,
  * out[p] = in[p / top_k]·W[block expert]ᵀ; with fused_silu_mul the stack must have been loaded with
- * fuse_gate_up and out[p] = silu(gate)·up ([T·k, N/2]).  prob_m = number of valid pair ids. */
+ * fuse_gate_up and out[p] = silu(gate)·up ([T·k, N/2]).  prob_m = number of valid pair ids.  sorted_token_ids and expert_ids hold
+ * max_blocks·moe_block_size and max_blocks entries (vLLM's max_num_tokens_padded sizing): a launched block reads its ids before
+ * it compares against num_tokens_past_padded. */
 int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input, const int32_t* sorted_token_ids,
                                   const int32_t* expert_ids, const int32_t* num_tokens_past_padded, void* output,
                                   int prob_m, int moe_block_size, int top_k, int max_blocks, int fused_silu_mul,
