@@ -36,6 +36,8 @@ void reload_knobs() {
     k.attn_no_rs = env_flag("FERRUM_HIP_ATTN_NO_RS");
     k.attn_narrow = env_flag("FERRUM_HIP_ATTN_NARROW");
     k.attn_flash32 = env_flag("FERRUM_HIP_ATTN_FLASH32");
+    k.attn_no_resident = env_flag("FERRUM_HIP_ATTN_NO_RESIDENT");
+    k.attn_resident_min_wgs = env_int("FERRUM_HIP_ATTN_RESIDENT_MIN_WGS", 128);
     k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 8);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
@@ -64,7 +66,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "attn_split_reduce", "w4_wgsplit", "w4_ldsa", "w4_tilep", "w4_slabs", "w4_slabs_lds", "w4_slabs_tile", "w4_rowsum",
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
-    "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "w4_big", "w4_ldsk"};
+    "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 

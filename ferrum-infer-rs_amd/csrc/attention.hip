@@ -860,6 +860,193 @@ __global__ __launch_bounds__(256, 2) void paged_prefill_attn64_kernel(AttnArgs p
     }
 }
 
+// ── short prompts: the sequence's whole K/V resident in LDS ─────────────────────────────────────────────────────────────
+// A 256-token prompt is ≤ 4 steps of 64 keys per workgroup of the flash form, most of them on the diagonal: its prologue (unit
+// scan, Q, first stage, barrier) and epilogue are most of its time (32 × 256 tokens: 79 µs for 17 GFLOP).  When a sequence's
+// keys fit — kv ≤ 256 at head_dim 128: 2 × 64 KiB — ONE copy of its K/V tiles is staged per workgroup (pairs of V tiles
+// interleaved as in the 64-key form), one barrier, and then the 8 waves walk the sequence's row tiles two at a time with
+// no further synchronisation: wave w of workgroup j ∈ {0, 1} takes tile pairs 2·(w + 8·i) + j … (interleaved, so the causal
+// work is balanced).  PV runs with the operands swapped — A = P (the lane's row b, keys (a, j)), B = the V fragment (the very
+// registers that serve as A for Oᵀ) — so the result is O[row 4a + r][d = b]: output rows are stored straight from the
+// accumulators, no transposition through LDS (there is none left).  Row maxima live in the S layout (lane column b = row); α
+// reaches the O layout (row 4a + r) by four lane broadcasts, only when a maximum moved.
+template <int HD>
+__global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(AttnArgs p) {
+    constexpr int NW = 8, MT = 2, DT = HD / 16, KS = HD / 32, TILE = 16 * HD, MAXB = 256 / KV_BLOCK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half* lds_k = reinterpret_cast<__half*>(smem);            // [MAXB][TILE]
+    __half* lds_v = lds_k + MAXB * TILE;                        // [MAXB / 2 pairs][2·TILE], interleaved
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int seq = blockIdx.x >> 1, jpar = blockIdx.x & 1, kvh = blockIdx.y;
+    const int G = p.nq / p.nkv;
+    const int tok0 = (int)p.cu_seqlens_q[seq];
+    const int q_len = (int)p.cu_seqlens_q[seq + 1] - tok0;
+    const int rows_total = q_len * G, tiles_s = (rows_total + 15) >> 4;
+    const int pos0 = (int)p.pos_offsets[seq];
+    const int kv_end = pos0 + q_len;
+    const int nblocks = cdiv_dev(kv_end, KV_BLOCK);             // ≤ MAXB (the launcher checks)
+    // stage K and V of every block: tile t of the pool → LDS (V: 8-byte halves of a pair's two blocks side by side)
+    {
+        const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
+        for (int t = wave; t < 2 * nblocks; t += NW) {
+            const int blk = t >> 1, isv = t & 1;
+            const long phys = bt[blk];
+            const __half* src = (isv ? p.v_pool : p.k_pool) + (phys * p.nkv + kvh) * (long)TILE + lane * 8;
+            half8 st[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s++) st[s] = *reinterpret_cast<const half8*>(src + s * 512);
+            if (!isv) {
+                __half* dst = lds_k + blk * TILE + lane * 8;
+#pragma unroll
+                for (int s = 0; s < KS; s++) *reinterpret_cast<half8*>(dst + s * 512) = st[s];
+            } else {
+                __half* dst = lds_v + (blk >> 1) * 2 * TILE + lane * 8 + (blk & 1) * 4;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    const uint4 w4 = __builtin_bit_cast(uint4, st[s]);
+                    *reinterpret_cast<uint2*>(dst + s * 512) = make_uint2(w4.x, w4.y);
+                    *reinterpret_cast<uint2*>(dst + (KS + s) * 512) = make_uint2(w4.z, w4.w);
+                }
+            }
+        }
+        // a step spans four blocks: V of the blocks between the context's end and the step boundary must read as zeros (their
+        // P is 0, but 0 × a stale Inf / NaN is NaN); stale K only yields scores that the masks discard
+        for (int blk = nblocks + wave; blk < min(MAXB, (nblocks + 3) & ~3); blk += NW) {
+            __half* dst = lds_v + (blk >> 1) * 2 * TILE + lane * 8 + (blk & 1) * 4;
+#pragma unroll
+            for (int s = 0; s < 2 * KS; s++) *reinterpret_cast<uint2*>(dst + s * 512) = make_uint2(0u, 0u);
+        }
+    }
+    __syncthreads();
+    const float sl2 = p.scale * 1.4426950408889634f;
+    const half8 ones = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+    const float4v zero4 = {0.f, 0.f, 0.f, 0.f};
+    // this wave's passes: tile pair index tp = jpar + 2·(wave + NW·i) → tiles 2·tp, 2·tp + 1
+    for (int tp = jpar + 2 * wave; 2 * tp < tiles_s; tp += 2 * NW) {
+        int row_pos[MT], win_lo[MT], vis_hi[MT], vis_lo[MT];
+        bool row_ok[MT];
+        half8 qf[MT][KS];
+        int t_last = 0;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            const int tile = 2 * tp + mt;
+            const bool full = tile * 16 + 15 < rows_total;
+            const int tmin = pos0 + (tile * 16) / G, tmax = pos0 + min(tile * 16 + 15, rows_total - 1) / G;
+            vis_hi[mt] = full ? tmin : -1;
+            vis_lo[mt] = p.sliding_window > 0 ? max(0, tmax + 1 - p.sliding_window) : 0;
+            const int rho = tile * 16 + b;
+            row_ok[mt] = rho < rows_total;
+            const int t_local = row_ok[mt] ? rho / G : 0, g = row_ok[mt] ? rho % G : 0;
+            row_pos[mt] = pos0 + t_local;
+            win_lo[mt] = p.sliding_window > 0 ? max(0, row_pos[mt] + 1 - p.sliding_window) : 0;
+            const long q_off = ((long)(tok0 + t_local) * p.nq + kvh * G + g) * HD;
+#pragma unroll
+            for (int s = 0; s < KS; s++) qf[mt][s] = *reinterpret_cast<const half8*>(p.q + q_off + 32 * s + 8 * a);
+            if (tile * 16 < rows_total) t_last = max(t_last, tmax);
+        }
+        const int kv_hi = t_last + 1;                                           // keys [0, kv_hi) matter to this pass
+        const int kv_lo = p.sliding_window > 0 ? max(0, pos0 + (2 * tp * 16) / G + 1 - p.sliding_window) : 0;
+        const int step_lo = (kv_lo / KV_BLOCK) / 4, step_hi = (cdiv_dev(kv_hi, KV_BLOCK) + 3) / 4;
+        float m_run[MT];
+        float4v o_acc[MT][DT], l_acc[MT];                                       // O[row 4a + r][d = dt·16 + b], Σ P in the same layout
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            m_run[mt] = -INFINITY;
+            l_acc[mt] = zero4;
+#pragma unroll
+            for (int dt = 0; dt < DT; dt++) o_acc[mt][dt] = zero4;
+        }
+        for (int sp = step_lo; sp < step_hi; sp++) {
+            const __half* kb = lds_k + (sp * 4) * TILE + lane * 8;
+            float4v sv[MT][4];
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const half8 kf = *reinterpret_cast<const half8*>(kb + q * TILE + s * 512);     // (blocks past the end: stale LDS, masked below)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+                        sv[mt][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[mt][s], s == 0 ? zero4 : sv[mt][q], 0, 0, 0);
+                }
+            }
+            half8 pf[MT][2];
+            const int key0 = sp * 4 * KV_BLOCK;
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                const bool clear = key0 + 4 * KV_BLOCK - 1 <= vis_hi[mt] && key0 >= vis_lo[mt];      // wave-uniform
+                if (!clear) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int kp = key0 + q * KV_BLOCK + 4 * a + r;
+                            const bool ok = row_ok[mt] && kp <= row_pos[mt] && kp >= win_lo[mt];
+                            sv[mt][q][r] = ok ? sv[mt][q][r] : -INFINITY;
+                        }
+                }
+                float mx = fmaxf(fmaxf(sv[mt][0][0], sv[mt][0][1]), fmaxf(sv[mt][0][2], sv[mt][0][3]));
+#pragma unroll
+                for (int q = 1; q < 4; q++) mx = fmaxf(mx, fmaxf(fmaxf(sv[mt][q][0], sv[mt][q][1]), fmaxf(sv[mt][q][2], sv[mt][q][3])));
+                mx = rows_reduce_max(mx * sl2);
+                const float m_new = fmaxf(m_run[mt], mx);
+                const float m_safe = m_new == -INFINITY ? 0.f : m_new;
+                if (__ballot(m_new != m_run[mt]) != 0) {                        // wave-uniform: some row's maximum moved
+                    const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_safe);      // lane column b ↔ row b
+                    float al[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) al[r] = __shfl(alpha, 4 * a + r, 64);   // O layout: row 4a + r
+#pragma unroll
+                    for (int dt = 0; dt < DT; dt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o_acc[mt][dt][r] *= al[r];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) l_acc[mt][r] *= al[r];
+                    m_run[mt] = m_new;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 2; i++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            pf[mt][j][4 * i + r] = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sv[mt][2 * j + i][r], sl2, -m_safe));
+            }
+            // O[row][d] += P[row][key]·V[key][d]: A = P fragment, B = V fragment (operands swapped against the Oᵀ forms)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const __half* vb = lds_v + (sp * 2 + j) * 2 * TILE + lane * 8;
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) l_acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[mt][j], ones, l_acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int ld = 0; ld < KS; ld++)
+#pragma unroll
+                    for (int sub = 0; sub < 2; sub++) {
+                        const half8 vfrag = *reinterpret_cast<const half8*>(vb + (sub * KS + ld) * 512);
+                        const int dt = 2 * ld + sub;
+#pragma unroll
+                        for (int mt = 0; mt < MT; mt++)
+                            o_acc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[mt][j], vfrag, o_acc[mt][dt], 0, 0, 0);
+                    }
+            }
+        }
+        // rows straight from the accumulators: lane (a, b) holds O[row 4a + r][dt·16 + b]
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rho_o = (2 * tp + mt) * 16 + 4 * a + r;
+                if (rho_o < rows_total) {
+                    const float l_row = l_acc[mt][r];
+                    const float inv = l_row > 0.f ? 1.0f / l_row : 0.f;
+                    __half* o = p.out + ((long)(tok0 + rho_o / G) * p.nq + kvh * G + rho_o % G) * HD + b;
+#pragma unroll
+                    for (int dt = 0; dt < DT; dt++) o[dt * 16] = __float2half(o_acc[mt][dt][r] * inv);
+                }
+            }
+    }
+}
+
 // merge grid.z partials: one thread per (row, dim)
 template <int HD>
 __global__ void paged_attn_reduce_kernel(AttnArgs p) {
@@ -939,6 +1126,21 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     // … and only when its workgroups (128 rows × one kv head each) cover the chip: a lone 256-token prompt has 64 of them and
     // is faster KV-split over 512 workgroups (TTFT 6.7 vs 7.1 ms)
     const long flash_min_wgs = kn.attn_flash_min_rows_set ? 1 : 256;
+    // short prompts whose whole context fits one LDS image (kv ≤ 256 at head_dim 128): resident-K/V form, two workgroups per
+    // (sequence, kv head).  max_kv_len bounds every sequence; needs ≥ 4 row tiles per sequence on average to pay off.
+    if (!fq && cu_seqlens_q && head_dim == 128 && !kn.attn_no_resident && max_kv_len <= 256 && max_q_len >= 32 &&
+        (long)total_q_tokens * G >= (long)num_seqs * 64 && (long)num_seqs * 2 * num_kv_heads >= kn.attn_resident_min_wgs) {
+        const size_t lds_res = (size_t)2 * (256 / KV_BLOCK) * 16 * 128 * 2;       // K + V images: 128 KiB
+        static bool attr_res = false;
+        if (!attr_res) {
+            FH_CHECK_HIP(hipFuncSetAttribute((const void*)paged_prefill_attn_resident_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res));
+            attr_res = true;
+        }
+        hipLaunchKernelGGL((paged_prefill_attn_resident_kernel<128>), dim3(num_seqs * 2, num_kv_heads, 1), dim3(512), lds_res, s, a);
+        FH_CHECK_LAUNCH();
+        form_hit(FORM_ATTN_RESIDENT);
+        return 0;
+    }
     if (!fq && cu_seqlens_q && !flash_off && (long)max_q_len * G >= flash_min_rows &&
         (long)total_q_tokens * 2 >= (long)num_seqs * max_q_len &&
         ((long)total_q_tokens * G / (head_dim == 256 ? 64 : 128)) * num_kv_heads >= flash_min_wgs) {

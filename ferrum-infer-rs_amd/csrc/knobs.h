@@ -22,6 +22,8 @@ struct Knobs {
     long attn_rs_min_wgs = 512;
     bool attn_no_rs = false;
     bool attn_narrow = false;
+    bool attn_no_resident = false;    // never take the resident-K/V short-prompt prefill form
+    long attn_resident_min_wgs = 128; // … and only from this many workgroups (tests lower it)
     bool attn_flash32 = false;        // the flash form with 32-key steps (paged_prefill_attn_kernel) for head_dim 128 too
     // INT4 GEMMs (w4_gemm.hip)
     int moe_kw_pairs = 8;
@@ -79,6 +81,7 @@ enum Form : int {
     FORM_TP_ALLREDUCE_ONESHOT,
     FORM_F16_DENSE_LINEAR,      // unquantised projection (DenseLinear)
     FORM_W4_FUSED_TAIL,         // ≤ 4-row q|k|v GEMM with the previous layer's combine + add + norm as its prologue
+    FORM_ATTN_RESIDENT,         // short-prompt prefill: the sequence's K/V resident in LDS
     FORM_W4_BIG,                // prefill: 128- / 256-row tiles, scale folded into the fp16 B operand
     FORM_W4_LDSK,               // 17–64 rows: LDS-shared activations, K split over the waves of a workgroup
     FORM_COUNT

@@ -454,8 +454,9 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
     forms.reset()
     toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
     # the forms the 8192-token prefill is meant to take: 96- / 256-row GEMM tiles with the scale folded into the fp16 B operand,
-    # LDS-shared K/V attention, and for the MoE model the router GEMM + 96-pair grouped tiles through the same tall-tile kernel
-    forms.require("w4_big", "attn_flash", *(("route_gemm", "moe_tile_big") if moe else ()))
+    # resident-K/V attention (256-token prompts: the whole context in one LDS image), and for the MoE model the router GEMM +
+    # 96-pair grouped tiles through the same tall-tile kernel
+    forms.require("w4_big", "attn_resident", *(("route_gemm", "moe_tile_big") if moe else ()))
     par = modelgen.Parity(f"bench-workload-{name}", cos_min=0.999, rel_max=5e-2)
     gap = (lambda: om.last_route_gap_rel()) if moe else (lambda: float("inf"))
     cur = np.array(toks, np.uint32)                               # unfollowed rows continue on the device's own ids

@@ -561,7 +561,7 @@ def test_paged_varlen_attention_many_prefill_tiles_row_split(env, window, knobs,
     """24 prompts × 200 tokens (GQA group 2 ⇒ 25 row tiles each): enough workgroups for the row-split prefill form on its own
     heuristic; every sequence against the CPU restatement."""
     pkg, B, ctx, O, torch = env
-    knobs.set(ATTN_NO_FLASH=1)                                     # the flash form has its own test below
+    knobs.set(ATTN_NO_FLASH=1, ATTN_NO_RESIDENT=1)                 # the flash and resident-K/V forms have their own tests below
     rng = np.random.default_rng(77 + window)
     nq, nkv, hd, S, T = 8, 4, 128, 24, 200
     q_lens, pos_offs = [T] * S, [0] * (S - 2) + [48, 5]            # two of them continue an existing context
@@ -630,6 +630,47 @@ def test_paged_prefill_attention_lds_shared_kv(env, window, nq, nkv, hd, knobs, 
     for s in range(S):
         ref = _ref_attention(O, q[cu[s]:cu[s + 1]], K[s], V[s], pos_offs[s], nq, nkv, hd, window)
         assert nmse(ref, got[cu[s]:cu[s + 1]]) < 1e-5, s
+
+
+@pytest.mark.parametrize("window,nq,nkv", [(0, 8, 2), (24, 8, 2), (0, 14, 2), (40, 32, 4), (0, 32, 16), (1, 8, 8)])
+def test_paged_prefill_attention_resident_kv(env, window, nq, nkv, knobs, forms):
+    """Short prompts whose whole context fits one LDS image (kv ≤ 256, head_dim 128): the resident-K/V form — fresh prompts, chunks
+    that continue a context, odd block counts and block counts that are not a multiple of the four-block step, a sequence with
+    fewer row tiles than waves, the full 256-key case, GQA groups 1 … 8 (7: rows of a token straddle tiles)."""
+    pkg, B, ctx, O, torch = env
+    knobs.set(ATTN_RESIDENT_MIN_WGS=1)
+    hd = 128
+    rng = np.random.default_rng(11 + window + nq)
+    q_lens, pos_offs = [200, 33, 64, 256, 49, 100], [0, 90, 20, 0, 200, 70]
+    S = len(q_lens)
+    kv_lens = [p + t for p, t in zip(pos_offs, q_lens)]
+    assert max(kv_lens) <= 256
+    max_blocks = (max(kv_lens) + 15) // 16
+    num_blocks = sum((n + 15) // 16 for n in kv_lens) + 1
+    perm = rng.permutation(num_blocks)
+    tables = np.zeros((S, max_blocks), np.int32)
+    used, K, V = 0, [], []
+    for s_, n in enumerate(kv_lens):
+        nb = (n + 15) // 16
+        tables[s_, :nb] = perm[used:used + nb]
+        used += nb
+        K.append(f16r(rng.standard_normal((n, nkv, hd))))
+        V.append(f16r(rng.standard_normal((n, nkv, hd))))
+    ck, cv = _fill_pool(env, K, V, tables, kv_lens, nkv, hd, num_blocks)
+    m_total = sum(q_lens)
+    cu = np.concatenate([[0], np.cumsum(q_lens)]).astype(np.int32)
+    q = f16r(rng.standard_normal((m_total, nq, hd)))
+    out = torch.full((m_total + 1, nq, hd), 9.0, dtype=torch.float16, device="cuda")      # guard row
+    B.paged_varlen_attention(ctx, dev16(torch, q), ck, cv, out, torch.from_numpy(cu).cuda(),
+                             torch.from_numpy(np.array(pos_offs, np.int32)).cuda(), torch.from_numpy(tables).cuda(), S,
+                             m_total, max(kv_lens), nq, nkv, hd, window, 16, max_blocks, max(q_lens))
+    ctx.sync()
+    forms.require("attn_resident", absent=("attn_flash", "attn_row_split", "attn_kv_narrow"))
+    got = host(out)
+    assert np.all(got[m_total] == 9.0)
+    for s_ in range(S):
+        ref = _ref_attention(O, q[cu[s_]:cu[s_ + 1]], K[s_], V[s_], pos_offs[s_], nq, nkv, hd, window)
+        assert nmse(ref, got[cu[s_]:cu[s_ + 1]]) < 1e-5, s_
 
 
 def test_paged_prefill_attention_lds_shared_kv_many_sequences(env, knobs, forms):
