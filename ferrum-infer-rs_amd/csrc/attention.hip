@@ -888,25 +888,36 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);             // ≤ MAXB (the launcher checks)
     // stage K and V of every block: tile t of the pool → LDS (V: 8-byte halves of a pair's two blocks side by side)
     {
+        // (every load of the wave requested before the first LDS write: one memory round trip, not one per tile)
         const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
-        for (int t = wave; t < 2 * nblocks; t += NW) {
-            const int blk = t >> 1, isv = t & 1;
-            const long phys = bt[blk];
-            const __half* src = (isv ? p.v_pool : p.k_pool) + (phys * p.nkv + kvh) * (long)TILE + lane * 8;
-            half8 st[KS];
+        constexpr int NT = 2 * MAXB / NW;                       // tile copies per wave (K and V of MAXB blocks over NW waves)
+        long phys[NT];
 #pragma unroll
-            for (int s = 0; s < KS; s++) st[s] = *reinterpret_cast<const half8*>(src + s * 512);
-            if (!isv) {
-                __half* dst = lds_k + blk * TILE + lane * 8;
+        for (int i = 0; i < NT; i++) phys[i] = bt[min((wave + NW * i) >> 1, nblocks - 1)];
+        half8 st[NT][KS];
 #pragma unroll
-                for (int s = 0; s < KS; s++) *reinterpret_cast<half8*>(dst + s * 512) = st[s];
-            } else {
-                __half* dst = lds_v + (blk >> 1) * 2 * TILE + lane * 8 + (blk & 1) * 4;
+        for (int i = 0; i < NT; i++) {
+            const int t = wave + NW * i, isv = t & 1;
+            const __half* src = (isv ? p.v_pool : p.k_pool) + (phys[i] * p.nkv + kvh) * (long)TILE + lane * 8;
 #pragma unroll
-                for (int s = 0; s < KS; s++) {
-                    const uint4 w4 = __builtin_bit_cast(uint4, st[s]);
-                    *reinterpret_cast<uint2*>(dst + s * 512) = make_uint2(w4.x, w4.y);
-                    *reinterpret_cast<uint2*>(dst + (KS + s) * 512) = make_uint2(w4.z, w4.w);
+            for (int s = 0; s < KS; s++) st[i][s] = *reinterpret_cast<const half8*>(src + s * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int t = wave + NW * i, blk = t >> 1, isv = t & 1;
+            if (blk < nblocks) {
+                if (!isv) {
+                    __half* dst = lds_k + blk * TILE + lane * 8;
+#pragma unroll
+                    for (int s = 0; s < KS; s++) *reinterpret_cast<half8*>(dst + s * 512) = st[i][s];
+                } else {
+                    __half* dst = lds_v + (blk >> 1) * 2 * TILE + lane * 8 + (blk & 1) * 4;
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        const uint4 w4 = __builtin_bit_cast(uint4, st[i][s]);
+                        *reinterpret_cast<uint2*>(dst + s * 512) = make_uint2(w4.x, w4.y);
+                        *reinterpret_cast<uint2*>(dst + (KS + s) * 512) = make_uint2(w4.z, w4.w);
+                    }
                 }
             }
         }
