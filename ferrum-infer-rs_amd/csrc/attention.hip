@@ -880,6 +880,13 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
     const int a = lane >> 4, b = lane & 15;
     const int seq = blockIdx.x >> 1, jpar = blockIdx.x & 1, kvh = blockIdx.y;
     const int G = p.nq / p.nkv;
+    // row → (token, head of the group): a shift when the GQA group is a power of two (an emulated integer division costs ≈ 20
+    // VALU, and the pass set-up and the row stores do ten of them per pass)
+    const int gsh = (G & (G - 1)) == 0 ? __builtin_ctz(G) : -1;
+    auto divmod_g = [&](int rho, int& t, int& g) {
+        if (gsh >= 0) { t = rho >> gsh; g = rho & (G - 1); }
+        else { t = rho / G; g = rho - t * G; }
+    };
     const int tok0 = (int)p.cu_seqlens_q[seq];
     const int q_len = (int)p.cu_seqlens_q[seq + 1] - tok0;
     const int rows_total = q_len * G, tiles_s = (rows_total + 15) >> 4;
@@ -943,12 +950,16 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
         for (int mt = 0; mt < MT; mt++) {
             const int tile = 2 * tp + mt;
             const bool full = tile * 16 + 15 < rows_total;
-            const int tmin = pos0 + (tile * 16) / G, tmax = pos0 + min(tile * 16 + 15, rows_total - 1) / G;
+            int tq0, tq1, gq_;
+            divmod_g(tile * 16, tq0, gq_);
+            divmod_g(min(tile * 16 + 15, rows_total - 1), tq1, gq_);
+            const int tmin = pos0 + tq0, tmax = pos0 + tq1;
             vis_hi[mt] = full ? tmin : -1;
             vis_lo[mt] = p.sliding_window > 0 ? max(0, tmax + 1 - p.sliding_window) : 0;
             const int rho = tile * 16 + b;
             row_ok[mt] = rho < rows_total;
-            const int t_local = row_ok[mt] ? rho / G : 0, g = row_ok[mt] ? rho % G : 0;
+            int t_local, g;
+            divmod_g(row_ok[mt] ? rho : 0, t_local, g);
             row_pos[mt] = pos0 + t_local;
             win_lo[mt] = p.sliding_window > 0 ? max(0, row_pos[mt] + 1 - p.sliding_window) : 0;
             const long q_off = ((long)(tok0 + t_local) * p.nq + kvh * G + g) * HD;
@@ -957,7 +968,9 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
             if (tile * 16 < rows_total) t_last = max(t_last, tmax);
         }
         const int kv_hi = t_last + 1;                                           // keys [0, kv_hi) matter to this pass
-        const int kv_lo = p.sliding_window > 0 ? max(0, pos0 + (2 * tp * 16) / G + 1 - p.sliding_window) : 0;
+        int tw0, gw_;
+        divmod_g(2 * tp * 16, tw0, gw_);
+        const int kv_lo = p.sliding_window > 0 ? max(0, pos0 + tw0 + 1 - p.sliding_window) : 0;
         const int step_lo = (kv_lo / KV_BLOCK) / 4, step_hi = (cdiv_dev(kv_hi, KV_BLOCK) + 3) / 4;
         float m_run[MT];
         float4v o_acc[MT][DT], l_acc[MT];                                       // O[row 4a + r][d = dt·16 + b], Σ P in the same layout
@@ -969,7 +982,11 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
             for (int dt = 0; dt < DT; dt++) o_acc[mt][dt] = zero4;
         }
         for (int sp = step_lo; sp < step_hi; sp++) {
-            const __half* kb = lds_k + (sp * 4) * TILE + lane * 8;
+            // (the element offset of the step is made opaque so that the 16 K reads use 16-bit immediates off ONE per-step base;
+            // left alone, hipcc keeps a loop-wide base and spends a VALU add per ds_read on offsets beyond 64 KiB)
+            int koff = (sp * 4) * TILE + lane * 8;
+            asm volatile("" : "+v"(koff));
+            const __half* kb = lds_k + koff;
             float4v sv[MT][4];
 #pragma unroll
             for (int s = 0; s < KS; s++) {
@@ -1026,7 +1043,9 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
             // O[row][d] += P[row][key]·V[key][d]: A = P fragment, B = V fragment (operands swapped against the Oᵀ forms)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const __half* vb = lds_v + (sp * 2 + j) * 2 * TILE + lane * 8;
+                int voff = (sp * 2 + j) * 2 * TILE + lane * 8;
+                asm volatile("" : "+v"(voff));
+                const __half* vb = lds_v + voff;
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++) l_acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf[mt][j], ones, l_acc[mt], 0, 0, 0);
 #pragma unroll
@@ -1050,7 +1069,9 @@ __global__ __launch_bounds__(512, 1) void paged_prefill_attn_resident_kernel(Att
                 if (rho_o < rows_total) {
                     const float l_row = l_acc[mt][r];
                     const float inv = l_row > 0.f ? 1.0f / l_row : 0.f;
-                    __half* o = p.out + ((long)(tok0 + rho_o / G) * p.nq + kvh * G + rho_o % G) * HD + b;
+                    int to, go;
+                    divmod_g(rho_o, to, go);
+                    __half* o = p.out + ((long)(tok0 + to) * p.nq + kvh * G + go) * HD + b;
 #pragma unroll
                     for (int dt = 0; dt < DT; dt++) o[dt * 16] = __float2half(o_acc[mt][dt][r] * inv);
                 }
