@@ -1951,6 +1951,8 @@ bool w4_gemm_dense_can_fuse_combine_norm(const W4Device& w, int m) {
 int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float* workspace,
                   size_t workspace_bytes, hipStream_t stream, const FusedCombineNorm* fa) {
     if (m <= 0) return 0;
+    // (act-order weights: the packed rows are in sorted-g_idx order and every caller hands over activations whose columns were
+    // gathered with the same permutation — dense_linear, ferrum_hip_gptq_linear_forward_f16 — so every kernel form applies)
     FH_REQUIRE(!fa || (w4_gemm_dense_can_fuse_combine_norm(w, m) && fa->residual_in != fa->residual_out && fa->top_k >= 1),
                "w4_gemm_dense: the fused combine + norm prologue needs <= 4 rows of a plain INT4 projection and ping-pong residual buffers");
     if (w.f16t) {                                     // DenseLinear: B::gemm on fp16 weights (linear.rs:109-129)
@@ -1979,7 +1981,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     // M = 8192: 64-row tiles 905, 96-row 1204, 128-row 1171, 256-row 1277 TFLOP/s (tools/exp_prefill_gemm.py, a throttled
     // back-to-back loop; one prefill of Llama-3.1-8B: 133 → 101 ms).  Shallow K: the 96-row form, two workgroups per CU, whose
     // prologues and epilogues overlap (2048→5120 at M = 8192: 852 / 924 TFLOP/s for 128 / 256 rows, 962 for 96).
-    if (kn.w4_big >= 0 && m >= 96 && w.perm == nullptr && w.G % 2 == 0) {
+    if (kn.w4_big >= 0 && m >= 96 && w.G % 2 == 0) {
         const int cols = cdiv(w.n64, 4);
         const long wgs6 = (long)cols * cdiv(m, 96), wgs8 = (long)cols * cdiv(m, 128), wgs16 = (long)cols * cdiv(m, 256);
         auto fill = [](long wgs) { return (double)wgs / (double)(cdiv(wgs, 256) * 256); };
@@ -2017,7 +2019,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
 #endif
     const int tile_min_env = kn.w4_tile_min_m;
     const int tile_min_m = tile_min_env > 0 ? tile_min_env : ((long)w.k * w.n >= (12L << 20) ? 33 : 64);
-    if (m >= tile_min_m && w.perm == nullptr) {
+    if (m >= tile_min_m) {
         // too few tiles to cover the chip (narrow N or few rows): split K over grid.z into fp32 slabs + one reduce launch,
         // keeping ≥ 8 quant groups per split
         const int tile_wgs = kn.w4_tile_wgs;
@@ -2039,7 +2041,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
     }
     const int lds_mode = kn.w4_ldsa;
     const bool lds_shape = (w.G >= 64 && w.n64 >= 32) || w.n64 >= 256;
-    if (mt >= 2 && w.perm == nullptr && (lds_mode == 2 || (lds_mode == 1 && lds_shape && mt == 2))) {
+    if (mt >= 2 && (lds_mode == 2 || (lds_mode == 1 && lds_shape && mt == 2))) {
         int nw = 4;
         if (kn.w4_ldsa_nw) nw = kn.w4_ldsa_nw == 8 && mt == 2 ? 8 : 4;
         const int cols = cdiv(w.n64, nw);

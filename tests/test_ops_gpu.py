@@ -133,6 +133,18 @@ def test_gptq_asymmetric_and_act_order(env, k, n, m):
     assert nmse(ref, got) < NMSE_FP16_TOL
 
 
+@pytest.mark.parametrize("k,n,m,form", [(8192, 2048, 32, "w4_ldsa"), (2048, 640, 200, "w4_tilep"), (1024, 4096, 2100, "w4_big"),
+                                        (4096, 6144, 40, "w4_tilep")])
+def test_gptq_act_order_takes_every_dense_kernel_form(env, k, n, m, form, forms):
+    """desc_act weights (BASELINE configs[3]: Gemma-3 GPTQ): the packed rows are in sorted-g_idx order and the activations' columns
+    are gathered with the same permutation before the GEMM, so the 17–32-row, 64-row-tile and tall-tile kernels serve them like
+    any other weights (round 1 sent every act-order projection of ≥ 17 rows through the per-wave-activation skinny kernel)."""
+    forms.reset()
+    ref, got = _gptq_case(env, k, n, m, 0xAC70 + m, False, g_idx=True)
+    forms.require(form)
+    assert nmse(ref, got) < NMSE_FP16_TOL
+
+
 @pytest.mark.parametrize("k,n,ms,sym", [
     # row-count boundaries of the three dense kernels (≤16 wgsplit, 17–32 LDS-A / wgsplit, ≥64 pipelined tile + split-K, 33–63 wgsplit)
     # on shapes that select each path: deep-K narrow-N (LDS-A with slabs), wide-N, tiny, N not a multiple of 64, asymmetric
