@@ -543,6 +543,26 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
             if (int rc = synth_w4(&L.down, c.intermediate, c.hidden, 1, false, ls ^ 0x55, s)) return rc;
         }
     }
+    // development (FERRUM_HIP_SYNTH_DESC_ACT=1): give every dense projection an activation-order permutation, as a desc_act GPTQ
+    // checkpoint has (BASELINE configs[3]) — the weights are random anyway; what this reproduces is the cost: a column gather per
+    // projection and no fused slab chains
+    if (const char* e = getenv("FERRUM_HIP_SYNTH_DESC_ACT"); e && atoi(e)) {
+        for (int li = 0; li < c.num_layers; li++) {
+            LayerWeights& L = m->layers[li];
+            for (W4Device* w : {&L.qkv, &L.o, &L.gate_up, &L.down}) {
+                if (!w->qw || w->perm) continue;
+                std::vector<int32_t> perm(w->k);
+                for (int i = 0; i < w->k; i++) perm[i] = i;
+                uint64_t st = seed ^ (0x9e3779b97f4a7c15ull * (uint64_t)(li * 8 + (w - &L.qkv) + 1));
+                for (int i = w->k - 1; i > 0; i--) {          // Fisher–Yates with the reference's LCG
+                    st = st * 6364136223846793005ull + 1442695040888963407ull;
+                    std::swap(perm[i], perm[(int)((st >> 33) % (uint64_t)(i + 1))]);
+                }
+                FH_CHECK_HIP(hipMalloc((void**)&w->perm, perm.size() * 4));
+                FH_CHECK_HIP(hipMemcpy(w->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+            }
+        }
+    }
     FH_CHECK_HIP(hipStreamSynchronize(s));
     return 0;
 }
