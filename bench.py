@@ -529,6 +529,12 @@ def main():
             ns["int4_gemm_prefill"] = {"kernel": f"w4_gemm_big_kernel (96/128/256-row tiles, scale folded into the fp16 B operand) qkv {kk}->{nn}, M={chunk}",
                                        "avg_us": round(us, 2),
                                        "tflops": round(tf, 1), "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(tf / MFMA_PEAK_TFLOPS, 4)}
+            if not cfg.get("num_experts"):            # dense model: the widest projection too (Llama-3.1-8B: 4096 -> 28672)
+                us2, _ = model.time_kernel("gate_up", chunk, kv_end, reps=2)
+                k2, n2 = cfg["hidden"], 2 * cfg["intermediate"]
+                tf2 = 2.0 * chunk * k2 * n2 / us2 / 1e6
+                ns["int4_gemm_prefill_gate_up"] = {"kernel": f"w4_gemm_big_kernel gate_up {k2}->{n2}, M={chunk}", "avg_us": round(us2, 2),
+                                                   "tflops": round(tf2, 1), "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(tf2 / MFMA_PEAK_TFLOPS, 4)}
             mp = os.path.join(ROOT, "profiles", "pmc_mfma_busy.json")
             if os.path.exists(mp):
                 ns["int4_gemm_prefill"]["mfma_busy_pmc"] = json.load(open(mp))
