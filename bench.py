@@ -41,7 +41,8 @@ LLAMA31_8B = dict(num_layers=32, hidden=4096, num_heads=32, num_kv_heads=8, head
 GEMMA3_27B = dict(num_layers=62, hidden=5376, num_heads=32, num_kv_heads=16, head_dim=128, intermediate=21504, vocab=262208,
                   has_qk_norm=1, activation=1, num_experts=0, top_k=0, expert_inter=0, norm_topk_prob=0, rms_eps=1e-6,
                   rope_theta=1e6, rope_scaling_kind=1, rope_p0=8.0, sliding_window=1024, sliding_window_pattern=6,
-                  sandwich_norms=1, embed_scale=73.5, rope_local_theta=10000.0)
+                  sandwich_norms=1, embed_scale=73.5, rope_local_theta=10000.0,
+                  desc_act=1)    # the GPTQ pack BASELINE names is act-order: every dense projection gets a row permutation
 LLAMA3_70B = dict(num_layers=80, hidden=8192, num_heads=64, num_kv_heads=8, head_dim=128, intermediate=28672, vocab=128256,
                   has_qk_norm=0, activation=0, num_experts=0, top_k=0, expert_inter=0, norm_topk_prob=0, rms_eps=1e-5,
                   rope_theta=5e5)
@@ -78,10 +79,20 @@ def build_model(pkg, cfg, c, max_seq_len, prefill_tokens, seed, layers=None):
     d = dict(cfg)
     if layers:
         d["num_layers"] = layers
+    # act-order (desc_act) pack: random row permutations on the synthetic projections (read by init_synthetic; single GPU only —
+    # a real desc_act pack cannot be row-sharded without requantising, so the tensor-parallel runs keep natural-order packs)
+    desc_act = bool(d.pop("desc_act", 0)) and d.get("tp_world", 1) <= 1
     blocks = (c + 2) * ((max_seq_len + 15) // 16)
     m = pkg.HipModel(group_size=128, kv_num_blocks=blocks, max_seqs=max(c, 1), max_tokens=max(prefill_tokens, c),
                      max_seq_len=max_seq_len, **d)
-    m.init_synthetic(seed)
+    prev = os.environ.get("FERRUM_HIP_SYNTH_DESC_ACT")
+    if desc_act:
+        os.environ["FERRUM_HIP_SYNTH_DESC_ACT"] = "1"
+    try:
+        m.init_synthetic(seed)
+    finally:
+        if desc_act and prev is None:
+            del os.environ["FERRUM_HIP_SYNTH_DESC_ACT"]
     m.finalize()
     return m
 
@@ -630,7 +641,8 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": f"{mname} GPTQ-INT4 (BASELINE configs[{BASELINE_CFG_INDEX[args.model]}]), TP=1 per GPU, replicas across GPUs",
                            "concurrency": c, "prompt_len": PL, "kv_len_range": [PL + W, PL + W + K], "kv_block": 16,
-                           "layers": num_layers_run, "parallelism": f"replica x{world}"}}
+                           "layers": num_layers_run, "parallelism": f"replica x{world}",
+                           **({"desc_act": True} if cfg.get("desc_act") else {})}}
         line.update(extra)
         return line
 

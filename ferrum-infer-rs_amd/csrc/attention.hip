@@ -53,6 +53,9 @@ struct AttnArgs {
     __half* v_pool_w;
     float eps;
     int qk_mode;
+    // decode forms: the consumer is an act-order o_proj — channel c of a row is stored at out_scatter[c] (inverse of the
+    // projection's row permutation), so no gather launch sits between attention and the GEMM
+    const int32_t* out_scatter;
 };
 
 // FUSED_QKV (decode, q_len = 1): the workgroup of (sequence, kv head) first does what
@@ -376,6 +379,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_kernel(AttnArgs p) {
     }
     if (!ok_o) return;
     const float inv = L > 0.f ? 1.0f / L : 0.f;
+    if (p.out_scatter) {
+        __half* orow = p.out + (long)(tok0 + t_o) * p.nq * HD;
+        const int32_t* sc = p.out_scatter + (kvh * G + g_o) * HD + dl * DPT;
+#pragma unroll
+        for (int i = 0; i < DPT; i++) orow[sc[i]] = __float2half(ov[i] * inv);
+        return;
+    }
     __half* o = p.out + ((long)(tok0 + t_o) * p.nq + kvh * G + g_o) * HD + dl * DPT;
 #pragma unroll
     for (int i = 0; i < DPT; i++) o[i] = __float2half(ov[i] * inv);
@@ -1105,6 +1115,13 @@ __global__ void paged_attn_reduce_kernel(AttnArgs p) {
     }
     const float inv = L > 0.f ? 1.0f / L : 0.f;
     const int t_o = rho / G, g_o = rho % G;
+    if (p.out_scatter) {
+        __half* orow = p.out + (long)(tok0 + t_o) * p.nq * HD;
+        const int32_t* sc = p.out_scatter + (kvh * G + g_o) * HD + dl * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) orow[sc[i]] = __float2half(acc[i] * inv);
+        return;
+    }
     __half* o = p.out + ((long)(tok0 + t_o) * p.nq + kvh * G + g_o) * HD + dl * 8;
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = __float2half(acc[i] * inv);
@@ -1136,8 +1153,10 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
                                const int32_t* block_tables, int num_seqs, int total_q_tokens, int max_q_len,
                                int max_kv_len, int num_heads, int num_kv_heads, int head_dim,
                                int sliding_window, int block_size, int max_blocks_per_seq, float* workspace,
-                               size_t workspace_bytes, hipStream_t s, const FusedQkv* fq = nullptr) {
+                               size_t workspace_bytes, hipStream_t s, const FusedQkv* fq = nullptr,
+                               const int32_t* out_scatter = nullptr) {
     if (num_seqs <= 0 || total_q_tokens <= 0) return 0;
+    FH_REQUIRE(!out_scatter || (!cu_seqlens_q && max_q_len == 1), "paged attention: scattered output is a decode-form feature");
     FH_REQUIRE(block_size == KV_BLOCK, "paged attention: block_size=%d unsupported (native layout uses 16)", block_size);
     FH_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged attention: nq=%d not a multiple of nkv=%d",
                num_heads, num_kv_heads);
@@ -1151,6 +1170,7 @@ static int paged_attention_launch(const __half* q, const __half* k_pool, const _
     a.tiles_per_seq = cdiv((long)max_q_len * G, 16);
     a.max_blocks = max_blocks_per_seq; a.sliding_window = sliding_window;
     a.scale = 1.0f / sqrtf((float)head_dim);
+    a.out_scatter = out_scatter;
     // prefill-like batches (most sequences bring many rows): LDS-shared K/V form.  The token count bounds the work units.
     const Knobs& kn = knobs();                                   // read once at library load (knobs.h), never per launch
     const bool flash_off = kn.attn_no_flash;
@@ -1269,10 +1289,10 @@ int paged_batched_decode_attention_f16(const __half* q, const __half* k_pool, co
                                        const int32_t* block_tables, const uint32_t* valid_kv_lens, int num_seqs,
                                        int max_kv_len, int num_heads, int num_kv_heads, int head_dim, int block_size,
                                        int max_blocks_per_seq, float* workspace, size_t workspace_bytes,
-                                       hipStream_t s) {
+                                       hipStream_t s, const int32_t* out_scatter) {
     return paged_attention_launch(q, k_pool, v_pool, out, nullptr, nullptr, valid_kv_lens, block_tables, num_seqs,
                                   num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, 0, block_size,
-                                  max_blocks_per_seq, workspace, workspace_bytes, s);
+                                  max_blocks_per_seq, workspace, workspace_bytes, s, nullptr, out_scatter);
 }
 
 // Decode step of one layer in ONE launch: split_qkv_norm_rope_into_paged_cache_varlen (q_len = 1 per sequence,
@@ -1282,14 +1302,15 @@ int paged_decode_attention_fused_qkv_f16(const __half* qkv, const __half* q_norm
                                          __half* v_pool, __half* out, const int32_t* block_tables,
                                          const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len, int num_heads,
                                          int num_kv_heads, int head_dim, int sliding_window, int block_size,
-                                         int max_blocks_per_seq, float* workspace, size_t workspace_bytes, hipStream_t s) {
+                                         int max_blocks_per_seq, float* workspace, size_t workspace_bytes, hipStream_t s,
+                                         const int32_t* out_scatter) {
     FH_REQUIRE(num_kv_heads > 0 && num_heads % num_kv_heads == 0 && num_heads / num_kv_heads <= 14,
                "fused decode attention: GQA group %d/%d must be <= 14", num_heads, num_kv_heads);
     FH_REQUIRE(qk_mode >= 0 && qk_mode <= 3, "fused decode attention: qk_mode=%d out of range", qk_mode);
     FusedQkv fq{qkv, q_norm_w, k_norm_w, cos_t, sin_t, k_pool, v_pool, eps, qk_mode};
     return paged_attention_launch(nullptr, k_pool, v_pool, out, nullptr, nullptr, valid_kv_lens, block_tables, num_seqs,
                                   num_seqs, 1, max_kv_len, num_heads, num_kv_heads, head_dim, sliding_window, block_size,
-                                  max_blocks_per_seq, workspace, workspace_bytes, s, &fq);
+                                  max_blocks_per_seq, workspace, workspace_bytes, s, &fq, out_scatter);
 }
 
 }  // namespace fh

@@ -69,6 +69,16 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// Act-order consumers (desc_act GPTQ: the packed weight rows are sorted by quant group, w4_repack_host) read their input as
+// x'[j] = x[perm[j]] (kernels/gather_columns.cu:15).  A producer that owns a whole row stages it in LDS and writes the gathered
+// row itself — 16-byte stores, the permutation from L2 — instead of leaving a gather launch in front of the GEMM.
+__device__ __forceinline__ half8 lds_gather8(const _Float16* row, const int32_t* __restrict__ perm, int j0) {
+    const int4 p0 = *reinterpret_cast<const int4*>(perm + j0), p1 = *reinterpret_cast<const int4*>(perm + j0 + 4);
+    half8 o;
+    o[0] = row[p0.x]; o[1] = row[p0.y]; o[2] = row[p0.z]; o[3] = row[p0.w];
+    o[4] = row[p1.x]; o[5] = row[p1.y]; o[6] = row[p1.z]; o[7] = row[p1.w];
+    return o;
+}
 __device__ __forceinline__ float wave_reduce_sum(float v) {
     v += dpp_move<0xB1>(v);        // quad_perm [1,0,3,2]
     v += dpp_move<0x4E>(v);        // quad_perm [2,3,0,1]

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
     long slab_stride, int ld_slab, const __half* __restrict__ w, float eps,
     __half* __restrict__ norm_out, const __half* __restrict__ router_w, int num_experts, int top_k,
     int norm_topk_prob, int32_t* __restrict__ ids, float* __restrict__ weights, float* __restrict__ logits_out,
-    int H) {
+    int H, const int32_t* __restrict__ out_perm) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     __half* xs = reinterpret_cast<__half*>(smem_raw);                      // normalised row [H]
     const int tiles = (num_experts + 15) >> 4;
@@ -88,10 +88,13 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
         half8 o;
 #pragma unroll
         for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[j] * inv * (float)wv[j]);
-        *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+        if (!out_perm) *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
         *reinterpret_cast<half8*>(xs + i * 8) = o;
     }
     __syncthreads();
+    // act-order consumer: the row leaves in the packed-row order of its weights (the router below reads the natural row)
+    if (out_perm && i < nvec)
+        *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = lds_gather8(reinterpret_cast<const _Float16*>(xs), out_perm, i * 8);
     if (num_experts <= 0) return;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -177,20 +180,22 @@ __global__ __launch_bounds__(1024) void add_rmsnorm_route_kernel(
 int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const float* x_slabs, int S, long slab_stride,
                                        int ld_slab, const __half* w, float eps, __half* norm_out, const __half* router_w,
                                        int num_experts, int top_k, int norm_topk_prob, int32_t* expert_ids,
-                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s);
+                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s,
+                                       const int32_t* out_perm);
 
 int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half* w, float eps, __half* norm_out,
                                  const __half* router_w, int num_experts, int top_k, int norm_topk_prob,
                                  int32_t* expert_ids, float* expert_weights, float* logits_out, int tokens, int H,
                                  hipStream_t s) {
     return fused_add_rms_norm_route_slabs_f16(residual, x, nullptr, 0, 0, 0, w, eps, norm_out, router_w, num_experts, top_k,
-                                              norm_topk_prob, expert_ids, expert_weights, logits_out, tokens, H, s);
+                                              norm_topk_prob, expert_ids, expert_weights, logits_out, tokens, H, s, nullptr);
 }
 
 int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const float* x_slabs, int S, long slab_stride,
                                        int ld_slab, const __half* w, float eps, __half* norm_out, const __half* router_w,
                                        int num_experts, int top_k, int norm_topk_prob, int32_t* expert_ids,
-                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s) {
+                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s,
+                                       const int32_t* out_perm) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(H % 32 == 0 && H <= 8192, "fused_add_rms_norm_route: hidden=%d must be a multiple of 32, <= 8192", H);
     FH_REQUIRE(num_experts <= 512 && top_k <= 64 && (num_experts == 0 || (top_k > 0 && top_k <= num_experts)),
@@ -201,11 +206,11 @@ int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const 
     if (x_slabs)
         hipLaunchKernelGGL(add_rmsnorm_route_kernel<true>, dim3(tokens), dim3(1024), lds, s, residual, x, x_slabs, S, slab_stride,
                            ld_slab, w, eps, norm_out, router_w, num_experts, top_k, norm_topk_prob, expert_ids, expert_weights,
-                           logits_out, H);
+                           logits_out, H, out_perm);
     else
         hipLaunchKernelGGL(add_rmsnorm_route_kernel<false>, dim3(tokens), dim3(1024), lds, s, residual, x, x_slabs, S, slab_stride,
                            ld_slab, w, eps, norm_out, router_w, num_experts, top_k, norm_topk_prob, expert_ids, expert_weights,
-                           logits_out, H);
+                           logits_out, H, out_perm);
     FH_CHECK_LAUNCH();
     return 0;
 }

@@ -25,7 +25,9 @@ struct W4Device {
     uint32_t* qw = nullptr;
     __half* sc = nullptr;
     __half* zp = nullptr;        // null when symmetric
-    int32_t* perm = nullptr;     // device act-order permutation or null
+    int32_t* perm = nullptr;     // device act-order permutation or null: the GEMM's input is x'[j] = x[perm[j]]
+    int32_t* inv_perm = nullptr; // its inverse (x'[inv_perm[c]] = x[c]) for producers that scatter (decode attention → o_proj)
+    bool perm_folded = false;    // the producer ALWAYS writes the permuted row (down: gate_up's columns were packed in perm order)
     __half* bias = nullptr;      // optional [n]
     bool fused_gate_up = false;  // columns permuted for the fused silu·mul epilogue
     __half* f16t = nullptr;      // UNQUANTISED projection (DenseLinear, linear.rs:109-129): fp16 weights [n, k] in f16t tiles;
@@ -83,19 +85,20 @@ int f16t_gemm_f32out(const __half* x, const __half* wt, float* out, int m, int n
 // ── norms / elementwise (norm.hip) ───────────────────────────────────────────
 int rms_norm_f16(const __half* x, const __half* w, float eps, __half* out, int tokens, int dim, hipStream_t s);
 int embed_rms_norm_f16(const __half* table, const uint32_t* token_ids, float embed_scale, __half* residual, float* residual_f32,
-                       const __half* w, float eps, __half* norm_out, int tokens, int dim, unsigned* zero_words, int n_zero, hipStream_t s);
+                       const __half* w, float eps, __half* norm_out, int tokens, int dim, unsigned* zero_words, int n_zero, hipStream_t s,
+                       const int32_t* out_perm = nullptr);   // out_perm: norm_out[row][j] = y[out_perm[j]] (act-order consumer)
 int gather_rms_norm_f16(const __half* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int rows, int dim, hipStream_t s);
 int fused_add_rms_norm_f16(__half* residual, const __half* x, const __half* w, float eps, __half* out,
-                           int tokens, int dim, hipStream_t s);
+                           int tokens, int dim, hipStream_t s, const int32_t* out_perm = nullptr);
 int embedding_lookup_f16(const __half* table, const uint32_t* ids, __half* out, int n_ids, int dim, hipStream_t s);
 int fused_silu_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s);
 int fused_gelu_tanh_mul_split_f16(const __half* gate_up, __half* out, int tokens, int im, hipStream_t s);
 int add_inplace_f16(__half* residual, const __half* x, long len, hipStream_t s);
 int sandwich_add_rms_norm_f32(const __half* branch, const __half* w_branch, float* residual, const __half* w_next, float eps,
-                              __half* norm_out, int tokens, int dim, hipStream_t s);
+                              __half* norm_out, int tokens, int dim, hipStream_t s, const int32_t* out_perm = nullptr);
 int sandwich_add_rms_norm_f32_slabs(const float* slabs, int S, long slab_stride, int ld_slab, const __half* w_branch,
                                     float* residual, const __half* w_next, float eps, __half* norm_out, int tokens, int dim,
-                                    hipStream_t s);
+                                    hipStream_t s, const int32_t* out_perm = nullptr);
 int fused_gated_act_slabs_f16(const float* slabs, int S, long slab_stride, int ld, __half* out, int tokens, int im, int gelu,
                               hipStream_t s);
 int rms_norm_f32_to_f16(const float* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int n_rows, int dim,
@@ -141,12 +144,13 @@ int paged_decode_attention_fused_qkv_f16(const __half* qkv, const __half* q_norm
                                          __half* v_pool, __half* out, const int32_t* block_tables,
                                          const uint32_t* valid_kv_lens, int num_seqs, int max_kv_len, int num_heads,
                                          int num_kv_heads, int head_dim, int sliding_window, int block_size,
-                                         int max_blocks_per_seq, float* workspace, size_t workspace_bytes, hipStream_t s);
+                                         int max_blocks_per_seq, float* workspace, size_t workspace_bytes, hipStream_t s,
+                                         const int32_t* out_scatter = nullptr);   // act-order o_proj: out[row][out_scatter[c]] = y[c]
 int paged_batched_decode_attention_f16(const __half* q, const __half* k_pool, const __half* v_pool, __half* out,
                                        const int32_t* block_tables, const uint32_t* valid_kv_lens, int num_seqs,
                                        int max_kv_len, int num_heads, int num_kv_heads, int head_dim, int block_size,
                                        int max_blocks_per_seq, float* workspace, size_t workspace_bytes,
-                                       hipStream_t s);
+                                       hipStream_t s, const int32_t* out_scatter = nullptr);
 size_t paged_attention_workspace_bytes(int total_q_tokens, int num_heads, int head_dim, int max_kv_len);
 
 // ── MoE routing (moe.hip) ────────────────────────────────────────────────────
@@ -178,7 +182,8 @@ int fused_add_rms_norm_route_f16(__half* residual, const __half* x, const __half
 int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const float* x_slabs, int S, long slab_stride,
                                        int ld_slab, const __half* w, float eps, __half* norm_out, const __half* router_w,
                                        int num_experts, int top_k, int norm_topk_prob, int32_t* expert_ids,
-                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s);
+                                       float* expert_weights, float* logits_out, int tokens, int H, hipStream_t s,
+                                       const int32_t* out_perm = nullptr);
 int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, const __half* residual,
                                  __half* residual_out, const __half* next_w, float eps, __half* norm_out, int tokens,
                                  int top_k, int H, hipStream_t s);

@@ -84,6 +84,8 @@ enum Form : int {
     FORM_ATTN_RESIDENT,         // short-prompt prefill: the sequence's K/V resident in LDS
     FORM_W4_BIG,                // prefill: 128- / 256-row tiles, scale folded into the fp16 B operand
     FORM_W4_LDSK,               // 17–64 rows: LDS-shared activations, K split over the waves of a workgroup
+    FORM_GATHER_COLUMNS,        // act-order input gather as a launch of its own (no producer wrote the permuted row)
+    FORM_PERM_PRODUCER,         // act-order: the producing kernel (norm, gated activation via gate_up's column order, decode attention) wrote the permuted row
     FORM_COUNT
 };
 

@@ -11,6 +11,7 @@
 // over the row with the row held in registers between the reduction and the scale.
 #include "common.h"
 #include "kernels.h"
+#include "knobs.h"
 
 namespace fh {
 
@@ -24,12 +25,20 @@ __device__ __forceinline__ float block_reduce_sum_256(float v, float* smem) {
     return t;
 }
 
+// every thread has written its vectors of the row to `stage`; 256 threads, vector i of thread t = t + c·256
+__device__ __forceinline__ void store_row_gathered_256(__half* out_row, const _Float16* stage, const int32_t* __restrict__ perm, int nvec) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvec; i += 256) *reinterpret_cast<half8*>(out_row + i * 8) = lds_gather8(stage, perm, i * 8);
+}
+
 // One 256-thread workgroup per row; each thread keeps up to CHUNKS 16-byte chunks in registers.
 template <bool FUSED_ADD, int CHUNKS>
 __global__ __launch_bounds__(256) void rms_norm_kernel(const __half* __restrict__ x, __half* __restrict__ residual,
                                                        const __half* __restrict__ w, float eps,
-                                                       __half* __restrict__ out, int dim) {
+                                                       __half* __restrict__ out, int dim,
+                                                       const int32_t* __restrict__ out_perm) {
     __shared__ float smem[4];
+    extern __shared__ _Float16 stage[];            // dim halves when out_perm
     const long row = blockIdx.x;
     const int nvec = dim >> 3;
     half8 v[CHUNKS];
@@ -64,32 +73,35 @@ __global__ __launch_bounds__(256) void rms_norm_kernel(const __half* __restrict_
             half8 o;
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
-            *reinterpret_cast<half8*>(out + row * dim + i * 8) = o;
+            if (out_perm) *reinterpret_cast<half8*>(stage + i * 8) = o;
+            else *reinterpret_cast<half8*>(out + row * dim + i * 8) = o;
         }
     }
+    if (out_perm) store_row_gathered_256(out + row * dim, stage, out_perm, nvec);
 }
 
 template <bool FUSED>
 static int launch_rms(const __half* x, __half* residual, const __half* w, float eps, __half* out, int tokens,
-                      int dim, hipStream_t s) {
+                      int dim, const int32_t* out_perm, hipStream_t s) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(dim % 8 == 0 && dim <= 8 * 256 * 8, "rms_norm: dim=%d must be a multiple of 8 and <= 16384", dim);
     int chunks = cdiv(dim / 8, 256);
     dim3 grid(tokens), block(256);
-    if (chunks <= 1) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 1>), grid, block, 0, s, x, residual, w, eps, out, dim);
-    else if (chunks <= 2) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 2>), grid, block, 0, s, x, residual, w, eps, out, dim);
-    else if (chunks <= 4) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 4>), grid, block, 0, s, x, residual, w, eps, out, dim);
-    else hipLaunchKernelGGL((rms_norm_kernel<FUSED, 8>), grid, block, 0, s, x, residual, w, eps, out, dim);
+    const size_t lds = out_perm ? (size_t)dim * 2 : 0;
+    if (chunks <= 1) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 1>), grid, block, lds, s, x, residual, w, eps, out, dim, out_perm);
+    else if (chunks <= 2) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 2>), grid, block, lds, s, x, residual, w, eps, out, dim, out_perm);
+    else if (chunks <= 4) hipLaunchKernelGGL((rms_norm_kernel<FUSED, 4>), grid, block, lds, s, x, residual, w, eps, out, dim, out_perm);
+    else hipLaunchKernelGGL((rms_norm_kernel<FUSED, 8>), grid, block, lds, s, x, residual, w, eps, out, dim, out_perm);
     FH_CHECK_LAUNCH();
     return 0;
 }
 
 int rms_norm_f16(const __half* x, const __half* w, float eps, __half* out, int tokens, int dim, hipStream_t s) {
-    return launch_rms<false>(x, nullptr, w, eps, out, tokens, dim, s);
+    return launch_rms<false>(x, nullptr, w, eps, out, tokens, dim, nullptr, s);
 }
 int fused_add_rms_norm_f16(__half* residual, const __half* x, const __half* w, float eps, __half* out, int tokens,
-                           int dim, hipStream_t s) {
-    return launch_rms<true>(x, residual, w, eps, out, tokens, dim, s);
+                           int dim, hipStream_t s, const int32_t* out_perm) {
+    return launch_rms<true>(x, residual, w, eps, out, tokens, dim, out_perm, s);
 }
 
 // Head / tail of a forward in ONE launch each (a dependent launch costs ≈ 4 µs even when trivial; a decode step had nine of
@@ -101,8 +113,10 @@ template <typename IdxT, int CHUNKS>
 __global__ __launch_bounds__(256) void gather_rms_norm_kernel(const __half* __restrict__ table, const IdxT* __restrict__ ids, float scale,
                                                               __half* __restrict__ copy_f16, float* __restrict__ copy_f32,
                                                               const __half* __restrict__ w, float eps, __half* __restrict__ out, int dim,
-                                                              unsigned* __restrict__ zero_words, int n_zero) {
+                                                              unsigned* __restrict__ zero_words, int n_zero,
+                                                              const int32_t* __restrict__ out_perm) {
     __shared__ float smem[4];
+    extern __shared__ _Float16 stage[];            // dim halves when out_perm
     const long row = blockIdx.x;
     const long src = (long)ids[row];
     if (blockIdx.x == 0 && zero_words)
@@ -143,19 +157,22 @@ __global__ __launch_bounds__(256) void gather_rms_norm_kernel(const __half* __re
             half8 o;
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
-            *reinterpret_cast<half8*>(out + row * dim + i * 8) = o;
+            if (out_perm) *reinterpret_cast<half8*>(stage + i * 8) = o;
+            else *reinterpret_cast<half8*>(out + row * dim + i * 8) = o;
         }
     }
+    if (out_perm) store_row_gathered_256(out + row * dim, stage, out_perm, nvec);
 }
 
 template <typename IdxT>
 static int launch_gather_rms(const __half* table, const IdxT* ids, float scale, __half* copy_f16, float* copy_f32, const __half* w, float eps,
-                             __half* out, int rows, int dim, unsigned* zero_words, int n_zero, hipStream_t s) {
+                             __half* out, int rows, int dim, unsigned* zero_words, int n_zero, const int32_t* out_perm, hipStream_t s) {
     if (rows <= 0) return 0;
     FH_REQUIRE(dim % 8 == 0 && dim <= 8 * 256 * 8, "gather_rms_norm: dim=%d must be a multiple of 8 and <= 16384", dim);
     const int chunks = cdiv(dim / 8, 256);
     dim3 grid(rows), block(256);
-#define FH_GRN(C) hipLaunchKernelGGL((gather_rms_norm_kernel<IdxT, C>), grid, block, 0, s, table, ids, scale, copy_f16, copy_f32, w, eps, out, dim, zero_words, n_zero)
+    const size_t lds = out_perm ? (size_t)dim * 2 : 0;
+#define FH_GRN(C) hipLaunchKernelGGL((gather_rms_norm_kernel<IdxT, C>), grid, block, lds, s, table, ids, scale, copy_f16, copy_f32, w, eps, out, dim, zero_words, n_zero, out_perm)
     if (chunks <= 1) FH_GRN(1); else if (chunks <= 2) FH_GRN(2); else if (chunks <= 4) FH_GRN(4); else FH_GRN(8);
 #undef FH_GRN
     FH_CHECK_LAUNCH();
@@ -164,12 +181,13 @@ static int launch_gather_rms(const __half* table, const IdxT* ids, float scale, 
 // embedding_lookup (+ scale_inplace) + rms_norm of layer 0, the residual stream written on the way (fp16, and fp32 for
 // sandwich-norm models)
 int embed_rms_norm_f16(const __half* table, const uint32_t* token_ids, float embed_scale, __half* residual, float* residual_f32,
-                       const __half* w, float eps, __half* norm_out, int tokens, int dim, unsigned* zero_words, int n_zero, hipStream_t s) {
-    return launch_gather_rms<uint32_t>(table, token_ids, embed_scale, residual, residual_f32, w, eps, norm_out, tokens, dim, zero_words, n_zero, s);
+                       const __half* w, float eps, __half* norm_out, int tokens, int dim, unsigned* zero_words, int n_zero, hipStream_t s,
+                       const int32_t* out_perm) {
+    return launch_gather_rms<uint32_t>(table, token_ids, embed_scale, residual, residual_f32, w, eps, norm_out, tokens, dim, zero_words, n_zero, out_perm, s);
 }
 // gather_rows + rms_norm on the sampled rows (final norm)
 int gather_rms_norm_f16(const __half* x, const int32_t* row_idx, const __half* w, float eps, __half* out, int rows, int dim, hipStream_t s) {
-    return launch_gather_rms<int32_t>(x, row_idx, 0.0f, nullptr, nullptr, w, eps, out, rows, dim, nullptr, 0, s);
+    return launch_gather_rms<int32_t>(x, row_idx, 0.0f, nullptr, nullptr, w, eps, out, rows, dim, nullptr, 0, nullptr, s);
 }
 
 // ── row gathers ──────────────────────────────────────────────────────────────
@@ -200,8 +218,10 @@ __global__ __launch_bounds__(256) void sandwich_add_norm_f32_kernel(const __half
                                                                      int ld_slab, const __half* __restrict__ w_branch,
                                                                      float* __restrict__ residual,
                                                                      const __half* __restrict__ w_next, float eps,
-                                                                     __half* __restrict__ norm_out, int H) {
+                                                                     __half* __restrict__ norm_out, int H,
+                                                                     const int32_t* __restrict__ out_perm) {
     __shared__ float red[4];
+    extern __shared__ _Float16 stage[];            // H halves when out_perm
     const long row = blockIdx.x;
     const int nvec = H >> 3;
     constexpr int CH = 4;
@@ -260,27 +280,29 @@ __global__ __launch_bounds__(256) void sandwich_add_norm_f32_kernel(const __half
             half8 o;
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (_Float16)(r[c][j] * inv2 * (float)wv[j]);
-            *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+            if (out_perm) *reinterpret_cast<half8*>(stage + i * 8) = o;
+            else *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
         }
     }
+    if (out_perm) store_row_gathered_256(norm_out + row * H, stage, out_perm, nvec);
 }
 
 int sandwich_add_rms_norm_f32(const __half* branch, const __half* w_branch, float* residual, const __half* w_next, float eps,
-                              __half* norm_out, int tokens, int dim, hipStream_t s) {
+                              __half* norm_out, int tokens, int dim, hipStream_t s, const int32_t* out_perm) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(dim % 8 == 0 && dim <= 8192, "sandwich_add_rms_norm_f32: dim=%d must be a multiple of 8, <= 8192", dim);
-    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel<false>, dim3(tokens), dim3(256), 0, s, branch, nullptr, 0, 0L, 0, w_branch,
-                       residual, w_next, eps, norm_out, dim);
+    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel<false>, dim3(tokens), dim3(256), out_perm ? (size_t)dim * 2 : 0, s, branch, nullptr, 0, 0L, 0,
+                       w_branch, residual, w_next, eps, norm_out, dim, out_perm);
     FH_CHECK_LAUNCH();
     return 0;
 }
 int sandwich_add_rms_norm_f32_slabs(const float* slabs, int S, long slab_stride, int ld_slab, const __half* w_branch,
                                     float* residual, const __half* w_next, float eps, __half* norm_out, int tokens, int dim,
-                                    hipStream_t s) {
+                                    hipStream_t s, const int32_t* out_perm) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(dim % 8 == 0 && dim <= 8192 && S >= 1, "sandwich_add_rms_norm_f32_slabs: dim=%d S=%d", dim, S);
-    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel<true>, dim3(tokens), dim3(256), 0, s, nullptr, slabs, S, slab_stride, ld_slab,
-                       w_branch, residual, w_next, eps, norm_out, dim);
+    hipLaunchKernelGGL(sandwich_add_norm_f32_kernel<true>, dim3(tokens), dim3(256), out_perm ? (size_t)dim * 2 : 0, s, nullptr, slabs, S, slab_stride,
+                       ld_slab, w_branch, residual, w_next, eps, norm_out, dim, out_perm);
     FH_CHECK_LAUNCH();
     return 0;
 }
@@ -464,8 +486,25 @@ __global__ void gather_columns_kernel(const __half* __restrict__ in, const int32
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < cols) out[r * cols + c] = in[r * cols + perm[c]];
 }
+// Rows that fit LDS (≤ 32768 columns): the row is read once with 16-byte loads, gathered from LDS and written with 16-byte
+// stores (2-byte global gathers took 150 µs for 8192 × 4096; this form runs at the copy rate).
+__global__ __launch_bounds__(256) void gather_columns_lds_kernel(const __half* __restrict__ in, const int32_t* __restrict__ perm,
+                                                                 __half* __restrict__ out, int cols) {
+    extern __shared__ _Float16 stage[];
+    const long r = blockIdx.x;
+    const int nvec = cols >> 3;
+    for (int i = threadIdx.x; i < nvec; i += 256)
+        *reinterpret_cast<half8*>(stage + i * 8) = *reinterpret_cast<const half8*>(in + r * cols + i * 8);
+    store_row_gathered_256(out + r * cols, stage, perm, nvec);
+}
 int gather_columns_f16(const __half* in, const int32_t* perm, __half* out, int rows, int cols, hipStream_t s) {
     if (rows <= 0) return 0;
+    form_hit(FORM_GATHER_COLUMNS);
+    if (cols % 8 == 0 && cols <= 32768) {
+        hipLaunchKernelGGL(gather_columns_lds_kernel, dim3(rows), dim3(256), (size_t)cols * 2, s, in, perm, out, cols);
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(gather_columns_kernel, dim3(cdiv(cols, 256), rows), dim3(256), 0, s, in, perm, out, cols);
     FH_CHECK_LAUNCH();
     return 0;

@@ -22,6 +22,12 @@ struct LayerWeights {
     __half* post_ffn_ln = nullptr;
     __half* qkv_bias = nullptr;       // staged until finalize (then owned by qkv.bias)
     W4Device qkv, o, gate_up, down;
+    // act-order (desc_act) MLP: down's row permutation is folded into the column order of gate_up at repack, so the gated
+    // activation leaves already permuted.  Whichever of the two arrives first waits here for the other.
+    struct PendingGptq { std::vector<int32_t> qweight, qzeros, g_idx; std::vector<float> scales; int k = 0, n = 0; bool has_g_idx = false; };
+    std::unique_ptr<PendingGptq> pending_gate_up;
+    std::vector<int32_t> down_perm_host;   // empty: down has no permutation (or has not arrived)
+    bool down_set = false;
     W4Device exp_gate_up, exp_down;   // stacked experts
     std::vector<uint8_t> exp_loaded;   // per expert: bit0 gate_up, bit1 down
     __half* k_pool = nullptr;

@@ -47,11 +47,13 @@ void free_w4(W4Device& w) {
     if (w.sc) (void)hipFree(w.sc);
     if (w.zp) (void)hipFree(w.zp);
     if (w.perm) (void)hipFree(w.perm);
+    if (w.inv_perm) (void)hipFree(w.inv_perm);
     if (w.bias) (void)hipFree(w.bias);
     if (w.f16t) (void)hipFree(w.f16t);
     w = W4Device();
 }
 
+int upload_perm(const std::vector<int32_t>& perm, W4Device* w);
 int upload_w4(const W4HostPacked& hp, W4Device* w) {
     free_w4(*w);
     w->k = hp.k; w->n = hp.n; w->n64 = hp.n64; w->G = hp.G; w->num_experts = 1;
@@ -63,10 +65,17 @@ int upload_w4(const W4HostPacked& hp, W4Device* w) {
         FH_CHECK_HIP(hipMalloc((void**)&w->zp, hp.zp.size() * 2));
         FH_CHECK_HIP(hipMemcpy(w->zp, hp.zp.data(), hp.zp.size() * 2, hipMemcpyHostToDevice));
     }
-    if (!hp.perm.empty()) {
-        FH_CHECK_HIP(hipMalloc((void**)&w->perm, hp.perm.size() * 4));
-        FH_CHECK_HIP(hipMemcpy(w->perm, hp.perm.data(), hp.perm.size() * 4, hipMemcpyHostToDevice));
-    }
+    return hp.perm.empty() ? 0 : upload_perm(hp.perm, w);
+}
+
+// input-column permutation of an act-order projection and its inverse (producers that scatter use the inverse)
+int upload_perm(const std::vector<int32_t>& perm, W4Device* w) {
+    std::vector<int32_t> inv(perm.size());
+    for (size_t j = 0; j < perm.size(); j++) inv[perm[j]] = (int32_t)j;
+    FH_CHECK_HIP(hipMalloc((void**)&w->perm, perm.size() * 4));
+    FH_CHECK_HIP(hipMemcpy(w->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+    FH_CHECK_HIP(hipMalloc((void**)&w->inv_perm, inv.size() * 4));
+    FH_CHECK_HIP(hipMemcpy(w->inv_perm, inv.data(), inv.size() * 4, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -405,6 +414,25 @@ static int ensure_expert_stack(W4Device* w, int k, int n, int E, bool fused) {
     return 0;
 }
 
+// Dense gate_up: when down is act-order (perm P: down reads act'[j] = act[P[j]]), pack column j of the gate half from the
+// checkpoint's gate column P[j] and column I + j from up column I + P[j]: the gated activation of the packed output IS act'.
+static int pack_gate_up(FerrumHipModel* m, LayerWeights& L, const int32_t* qweight, const float* scales, const int32_t* qzeros,
+                        const int32_t* g_idx, int k, int n) {
+    W4HostPacked hp;
+    std::vector<int32_t> cols;
+    const std::vector<int32_t>& P = L.down_perm_host;
+    const int I = n / 2;
+    const bool fold = !P.empty() && (int)P.size() == I && L.down.qw != nullptr;
+    if (fold) {
+        cols.resize(n);
+        for (int j = 0; j < I; j++) { cols[j] = P[j]; cols[I + j] = I + P[j]; }
+    }
+    if (int r = w4_repack_host(qweight, scales, qzeros, g_idx, fold ? cols.data() : nullptr, m->cfg.group_size, k, n, &hp)) return r;
+    if (int r = upload_w4(hp, &L.gate_up)) return r;
+    L.down.perm_folded = fold;
+    return 0;
+}
+
 int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int expert, const int32_t* qweight,
                               const float* scales, const int32_t* qzeros, const int32_t* g_idx, int k, int n) {
     FH_REQUIRE(m && qweight && scales && qzeros && layer >= 0 && layer < m->cfg.num_layers, "model_set_gptq: bad argument");
@@ -422,8 +450,32 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int exper
         case 3: rc = check_shape("down", k, n, c.intermediate, H); dst = &L.down; break;
         }
         if (rc) return rc;
+        if (which == 2 && !L.down_set) {
+            // down has not arrived: if it turns out to be act-order, its row permutation becomes the column order of gate_up
+            // (the gated activation then leaves already permuted — no gather in front of down) — wait for it
+            auto p = std::make_unique<LayerWeights::PendingGptq>();
+            const int groups = k / c.group_size;
+            p->qweight.assign(qweight, qweight + (size_t)(k / 8) * n);
+            p->scales.assign(scales, scales + (size_t)groups * n);
+            p->qzeros.assign(qzeros, qzeros + (size_t)groups * (n / 8));
+            p->has_g_idx = g_idx != nullptr;
+            if (g_idx) p->g_idx.assign(g_idx, g_idx + k);
+            p->k = k; p->n = n;
+            L.pending_gate_up = std::move(p);
+            return 0;
+        }
+        if (which == 2) return pack_gate_up(m, L, qweight, scales, qzeros, g_idx, k, n);
         if (int r = w4_repack_host(qweight, scales, qzeros, g_idx, nullptr, c.group_size, k, n, &hp)) return r;
-        return upload_w4(hp, dst);
+        if (int r = upload_w4(hp, dst)) return r;
+        if (which == 3) {
+            L.down_set = true;
+            L.down_perm_host = hp.perm;
+            if (L.pending_gate_up) {
+                std::unique_ptr<LayerWeights::PendingGptq> p = std::move(L.pending_gate_up);
+                return pack_gate_up(m, L, p->qweight.data(), p->scales.data(), p->qzeros.data(), p->has_g_idx ? p->g_idx.data() : nullptr, p->k, p->n);
+            }
+        }
+        return 0;
     }
     FH_REQUIRE(which == 4 || which == 5, "model_set_gptq: which=%d", which);
     FH_REQUIRE(c.num_experts > 0 && expert >= 0 && expert < c.num_experts, "model_set_gptq: expert=%d of %d", expert, c.num_experts);
@@ -544,8 +596,8 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
         }
     }
     // development (FERRUM_HIP_SYNTH_DESC_ACT=1): give every dense projection an activation-order permutation, as a desc_act GPTQ
-    // checkpoint has (BASELINE configs[3]) — the weights are random anyway; what this reproduces is the cost: a column gather per
-    // projection and no fused slab chains
+    // checkpoint has (BASELINE configs[3]) — the weights are random anyway; what this reproduces is the cost of serving the
+    // permuted inputs (producers write them permuted; prefill o_proj keeps one gather launch)
     if (const char* e = getenv("FERRUM_HIP_SYNTH_DESC_ACT"); e && atoi(e)) {
         for (int li = 0; li < c.num_layers; li++) {
             LayerWeights& L = m->layers[li];
@@ -558,9 +610,10 @@ int ferrum_hip_model_init_synthetic(FerrumHipModel* m, uint64_t seed) {
                     st = st * 6364136223846793005ull + 1442695040888963407ull;
                     std::swap(perm[i], perm[(int)((st >> 33) % (uint64_t)(i + 1))]);
                 }
-                FH_CHECK_HIP(hipMalloc((void**)&w->perm, perm.size() * 4));
-                FH_CHECK_HIP(hipMemcpy(w->perm, perm.data(), perm.size() * 4, hipMemcpyHostToDevice));
+                if (int rc = upload_perm(perm, w)) return rc;
             }
+            // (random weights: a gate_up whose columns were packed in down's row order is just another random matrix)
+            L.down.perm_folded = L.down.perm && L.gate_up.qw;
         }
     }
     FH_CHECK_HIP(hipStreamSynchronize(s));
@@ -572,6 +625,12 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     if (m->finalized) return 0;
     const FerrumHipModelConfig& c = m->cfg;
     FH_REQUIRE(m->embed && m->final_norm, "model_finalize: embed / final_norm missing");
+    for (LayerWeights& L : m->layers)
+        if (L.pending_gate_up) {      // down never arrived as GPTQ (unquantised, or missing: reported below): nothing to fold
+            std::unique_ptr<LayerWeights::PendingGptq> p = std::move(L.pending_gate_up);
+            if (int rc = pack_gate_up(m, L, p->qweight.data(), p->scales.data(), p->qzeros.data(), p->has_g_idx ? p->g_idx.data() : nullptr, p->k, p->n))
+                return rc;
+        }
     for (int li = 0; li < c.num_layers; li++) {
         const LayerWeights& L = m->layers[li];
         auto have = [](const W4Device& w) { return w.qw != nullptr || w.f16t != nullptr; };
@@ -625,7 +684,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         size_t kmax = 0;     // act-order input gather scratch
         for (const LayerWeights& L : m->layers)
             for (const W4Device* w : {&L.qkv, &L.o, &L.gate_up, &L.down})
-                if (w->perm) kmax = std::max(kmax, (size_t)w->k);
+                if (w->perm && !w->perm_folded) kmax = std::max(kmax, (size_t)w->k);
         if (kmax) rc |= dev_alloc(&m->gather_scratch, T * kmax);
     }
     rc |= dev_alloc(&m->norm_out, T * H);
@@ -977,8 +1036,9 @@ static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted
 }
 #undef FH_TRY
 
-int dense_linear(FerrumHipModel* m, const W4Device& w, const __half* x, __half* out, int T, hipStream_t s) {
-    if (w.perm) {
+int dense_linear(FerrumHipModel* m, const W4Device& w, const __half* x, __half* out, int T, hipStream_t s, bool x_permuted = false) {
+    if (w.perm && (x_permuted || w.perm_folded)) form_hit(FORM_PERM_PRODUCER);
+    else if (w.perm) {
         FH_REQUIRE(m->gather_scratch, "dense_linear: act-order weights but no gather scratch");
         if (int rc = gather_columns_f16(x, w.perm, m->gather_scratch, T, w.k, s)) return rc;
         x = m->gather_scratch;
@@ -1020,8 +1080,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     // head, one launch: embedding_lookup (+ the Gemma embedding scale, llama_family.rs:3656) → residual stream (fp16; for
     // sandwich-norm models also the fp32 shadow, llama_family.rs:3664-3674) → layer 0's input norm.  Later layers get their
     // input norm fused into the previous layer's tail.
+    // act-order (desc_act) projections read x'[j] = x[perm[j]]: the kernel that PRODUCES the row writes it permuted wherever one
+    // workgroup owns the row (every norm of the dense layer) or the rows are few (decode attention scatters); the gated
+    // activation is permuted by gate_up's column order (pack_gate_up).  Only the prefill o_proj keeps a gather launch.
     RUN(embed_rms_norm_f16(m->embed, tokens, c.embed_scale, m->residual, sandwich ? m->residual_f32 : nullptr, m->layers[0].input_ln,
-                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 : 0, s));
+                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 : 0, s, m->layers[0].qkv.perm));
+    bool qkv_in_perm = m->layers[0].qkv.perm != nullptr;      // norm_out holds the row in L.qkv's packed order
     // decode at ≤ 4 rows (MoE models): the tail of layer l — combine + residual add + next input norm — runs as the prologue of
     // layer l+1's q|k|v GEMM instead of as a launch of its own (every dependent launch costs ≈ 4 µs there)
     bool pending_tail = false;
@@ -1030,12 +1094,16 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
         const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
+        const int32_t* next_qkv_perm = li + 1 < c.num_layers ? m->layers[li + 1].qkv.perm : nullptr;
+        const int32_t* gu_perm = L.gate_up.perm;
         if (pending_tail) {
             RUN(w4_gemm_dense(L.qkv, nullptr, m->qkv_out, T, m->workspace, m->workspace_bytes, s, &tail));
             pending_tail = false;
         } else {
-            RUN(dense_linear(m, L.qkv, m->norm_out, m->qkv_out, T, s));
+            RUN(dense_linear(m, L.qkv, m->norm_out, m->qkv_out, T, s, qkv_in_perm));
         }
+        qkv_in_perm = false;
+        bool attn_perm = false;          // attn_out holds the row in L.o's packed order
         // per-layer attention schedule (llama_layer_attention_schedule, llama_family.rs:1028-1045)
         const int pattern = c.sliding_window_pattern;
         const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
@@ -1048,7 +1116,8 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             RUN(paged_decode_attention_fused_qkv_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy, L.k_norm ? L.k_norm : dummy,
                                                      cos_l, sin_l, c.rms_eps, qk_mode, L.k_pool, L.v_pool, m->attn_out,
                                                      bt, kvl, sh.num_seqs, sh.max_kv_len, nq, nkv, hd, layer_window, KV_BLOCK,
-                                                     m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s));
+                                                     m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s, L.o.inv_perm));
+            attn_perm = L.o.perm != nullptr;
         } else {
             RUN(split_qkv_norm_rope_into_paged_cache_varlen_f16(m->qkv_out, L.q_norm ? L.q_norm : dummy,
                                                                 L.k_norm ? L.k_norm : dummy, cos_l, sin_l, m->q_out,
@@ -1057,7 +1126,8 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             if (layer_decode) {
                 RUN(paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, bt, kvl, sh.num_seqs,
                                                        sh.max_kv_len, nq, nkv, hd, KV_BLOCK, m->max_blocks_per_seq,
-                                                       m->workspace, m->workspace_bytes, s));
+                                                       m->workspace, m->workspace_bytes, s, L.o.inv_perm));
+                attn_perm = L.o.perm != nullptr;
             } else if (sh.single_prefix > 0 && sh.single_prefix < sh.num_seqs && (long)sh.rest_min_q * (nq / nkv) >= 16L * m->attn_flash_min_rows) {
                 // decode rows first, LONG prompts after them (≥ 1024 tokens at a GQA group of 8; for a 256-token prompt the
                 // second launch costs more than the form saves: 9.7 → 10.2 ms per iteration): two launches, so that the
@@ -1102,14 +1172,14 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 if (int rc_ = tp_all_reduce(m, m->mlp_out, (size_t)T * H)) return rc_;
                 return moe_combine_add_rms_norm_f16(m->mlp_out, m->ones, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, 1, H, s);
             };
-            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && Q >= 1 && tiles / Q <= 8 && !L.o.perm;
+            const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && Q >= 1 && tiles / Q <= 8 && (!L.o.perm || attn_perm);
             const bool o_quant = L.o.qw != nullptr;           // the slab forms are INT4 kernels; an unquantised o_proj takes the direct GEMM
             if (decode_fast) {
                 // o_proj as fp32 split-K slabs, reduced inside the next kernel (no reduce launch)
                 const float* slabs = nullptr;
                 int S = m->o_slabs, rows_pad = 0, n_pad = 0;
                 if (tp || !o_quant) {
-                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
                     if (tp) RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                     S = 0;
                 } else if (S > 0 && T > 16 && T <= 32 && !L.o.bias) {
@@ -1122,7 +1192,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     slabs = m->workspace;
                     S = std::min(S, L.o.G);
                 } else {
-                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
                 }
                 form_hit(Q > 1 ? FORM_ROUTE_SPLIT : FORM_ROUTE_FUSED);
                 if (Q > 1) {
@@ -1162,7 +1232,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 RUN(moe_batch_gemms(m, L, P, sorted_max, max_blocks, s));
                 RUN(moe_tail(m->residual, m->residual));
             } else {
-                RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+                RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
                 if (tp) RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                 form_hit(T >= m->route_gemm_min_tokens ? FORM_ROUTE_GEMM : FORM_ROUTE_FUSED);
                 if (T >= m->route_gemm_min_tokens) {
@@ -1188,29 +1258,34 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             // projections produce fp16 partials (GEMM + reduce), all-reduce, then add + norm; the column-parallel gate_up keeps
             // its slabs → gated-activation form.  Everything stays stream-ordered device work, so the step is still one graph.
             const bool tp = c.tp_world > 1;
-            const bool slab_chain = m->dense_slabs && T > 16 && T <= 32 && !L.o.perm && !L.gate_up.perm && !L.down.perm &&
+            // (act-order projections: every input of the chain arrives permuted from its producer — decode attention, the norms
+            // below, gate_up's column order)
+            const bool slab_chain = m->dense_slabs && T > 16 && T <= 32 && (!L.o.perm || attn_perm) && (!L.down.perm || L.down.perm_folded) &&
                                     L.o.qw && L.gate_up.qw && L.down.qw;   // INT4 slab kernels; unquantised projections take the op chain
             int S = 0, rows_pad = 0, n_pad = 0;
             if (slab_chain) {
                 form_hit(FORM_DENSE_SLAB_CHAIN);
                 if (tp) {
-                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+                    RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
                     RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                     if (sandwich) {
-                        RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                        RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
                     } else {
-                        RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                        RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
                     }
                 } else {
+                if (L.o.perm) form_hit(FORM_PERM_PRODUCER);
                 RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                 if (sandwich) {
                     RUN(sandwich_add_rms_norm_f32_slabs(m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_attn_ln, m->residual_f32,
-                                                        L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                                                        L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
                 } else {
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ln,
-                                                           c.rms_eps, m->norm_out, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, T, H, s));
+                                                           c.rms_eps, m->norm_out, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, T, H, s, gu_perm));
                 }
                 }
+                if (gu_perm) form_hit(FORM_PERM_PRODUCER);
+                if (L.down.perm) form_hit(FORM_PERM_PRODUCER);
                 S = 0;
                 RUN(w4_gemm_dense_slabs_lds(L.gate_up, m->norm_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                 RUN(fused_gated_act_slabs_f16(m->workspace, S, (long)rows_pad * n_pad, n_pad, m->act_out, T, I, c.activation == 1, s));
@@ -1219,9 +1294,9 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     RUN(dense_linear(m, L.down, m->act_out, m->mlp_out, T, s));
                     RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
                     if (sandwich) {
-                        RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s));
+                        RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
                     } else if (next_ln) {
-                        RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s));
+                        RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
                     } else {
                         RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
                     }
@@ -1229,24 +1304,25 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 RUN(w4_gemm_dense_slabs_lds(L.down, m->act_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                 if (sandwich) {
                     RUN(sandwich_add_rms_norm_f32_slabs(m->workspace, S, (long)rows_pad * n_pad, n_pad, L.post_ffn_ln, m->residual_f32,
-                                                        next_ln, c.rms_eps, m->norm_out, T, H, s));
+                                                        next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
                 } else {
                     // last layer: the norm output is unused (the final norm runs on the sampled rows)
                     RUN(fused_add_rms_norm_route_slabs_f16(m->residual, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad,
                                                            next_ln ? next_ln : L.input_ln, c.rms_eps, m->norm_out, nullptr, 0, 0, 0,
-                                                           nullptr, nullptr, nullptr, T, H, s));
+                                                           nullptr, nullptr, nullptr, T, H, s, next_qkv_perm));
                 }
                 }
+                qkv_in_perm = next_qkv_perm != nullptr;
             } else {
-            RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s));
+            RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
             RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
             if (sandwich) {
                 // Gemma 3 (llama_family.rs:3357-3421): residual += norm(o, post_attention_layernorm); pre-MLP norm
-                RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
             } else {
-                RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
+                RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
             }
-            RUN(dense_linear(m, L.gate_up, m->norm_out, m->gate_up_out, T, s));
+            RUN(dense_linear(m, L.gate_up, m->norm_out, m->gate_up_out, T, s, true));
             if (c.activation == 1) {
                 RUN(fused_gelu_tanh_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
             } else {
@@ -1256,12 +1332,13 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
             if (sandwich) {
                 // residual += norm(mlp_out, post_feedforward_layernorm); next layer's input norm rides along
-                RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s));
+                RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
             } else if (next_ln) {
-                RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s));
+                RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
             } else {
                 RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
             }
+            qkv_in_perm = next_ln && next_qkv_perm != nullptr;
             }
         }
         if (m->taps_enabled && m->taps) {

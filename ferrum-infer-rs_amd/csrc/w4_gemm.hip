@@ -2178,7 +2178,8 @@ int w4_gemm_moe_merge_route(const W4Device& w, const __half* x, __half* out, con
 int w4_gemm_dense_slabs(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int S,
                         int* rows_pad_out, int* n_pad_out, hipStream_t stream) {
     if (m <= 0) return 0;
-    FH_REQUIRE(w.perm == nullptr && w.bias == nullptr, "w4_gemm_dense_slabs: act-order / bias weights use the direct path");
+    // (act-order weights: the caller hands over rows its producer already wrote in the packed-row order, like w4_gemm_dense)
+    FH_REQUIRE(w.bias == nullptr, "w4_gemm_dense_slabs: bias weights use the direct path");
     W4Args a{};
     a.qw = w.qw; a.sc = w.sc; a.zp = w.zp;
     a.x = x; a.M = m; a.K = w.k; a.N = w.n; a.G = w.G; a.n64 = w.n64; a.ldo = w.n;
@@ -2241,7 +2242,7 @@ int w4_gemm_dense_lds_splits(const W4Device& w, int m) {
 int w4_gemm_dense_slabs_lds(const W4Device& w, const __half* x, float* slabs, size_t slab_bytes, int m, int* S_inout,
                             int* rows_pad_out, int* n_pad_out, hipStream_t stream) {
     if (m <= 0) return 0;
-    FH_REQUIRE(w.perm == nullptr && w.bias == nullptr, "w4_gemm_dense_slabs_lds: act-order / bias weights use the direct path");
+    FH_REQUIRE(w.bias == nullptr, "w4_gemm_dense_slabs_lds: bias weights use the direct path");
     FH_REQUIRE(m > 16 && m <= 32, "w4_gemm_dense_slabs_lds: m=%d (17..32 rows)", m);
     int S = *S_inout > 0 ? *S_inout : w4_gemm_dense_lds_splits(w, m);
     S = std::max(1, std::min(S, w.G));

@@ -28,7 +28,7 @@ class TinyModel:
     def __init__(self, moe, layers=2, hidden=256, nq=4, nkv=2, hd=128, inter=256, vocab=512, experts=8, top_k=2,
                  expert_inter=128, qk_norm=True, seed=0, max_seq_len=256, activation=0, sliding_window=0,
                  rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False, sandwich=False,
-                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False,
+                 sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False, mlp_down_first=False,
                  qkv_bias=False, dense_proj=False):
         self.cfg = dict(num_layers=layers, hidden=hidden, num_heads=nq, num_kv_heads=nkv, head_dim=hd,
                         intermediate=0 if moe else inter, vocab=vocab, max_seq_len=max_seq_len, has_qk_norm=int(qk_norm),
@@ -82,6 +82,8 @@ class TinyModel:
             if asym_act_order:   # desc_act checkpoints (Gemma-3 GPTQ packs): a shuffled row → group map per projection
                 for name, (k_, _n, _qw, _sc, _qz) in L["gptq"].items():
                     L["g_idx"][name] = rng.permutation(np.arange(k_) // 128).astype(np.int32)
+            if mlp_down_first and not moe:      # the order a loader hands the MLP pair over must not matter (gate_up ↔ down fold)
+                L["gptq"] = {k_: L["gptq"][k_] for k_ in ("qkv", "o", "down", "gate_up")}
             self.layers.append(L)
 
     def load_into(self, model, is_oracle):
@@ -345,7 +347,7 @@ class Parity:
         return rep
 
 
-def run_parity_case(pkg, moe, layers=2, prompt_len=19, decode_steps=4, seed=0, case=None, rel_tol=2e-2, **model_kw):
+def run_parity_case(pkg, moe, layers=2, prompt_len=19, decode_steps=4, seed=0, case=None, rel_tol=2e-2, before_decode=None, **model_kw):
     """Single-sequence prefill + teacher-forced greedy decode, HIP runner vs oracle.
     Acceptance follows the reference's model-level criterion (qwen3_cuda_parity_test.rs:194-240): same argmax AND
     cosine > 0.999 at every step.  Ids are compared exactly; mismatches are counted in res["parity"] (see Parity)."""
@@ -368,6 +370,8 @@ def run_parity_case(pkg, moe, layers=2, prompt_len=19, decode_steps=4, seed=0, c
     g_tok, g_logits = hm.unified_forward([(1, prompt, 0, True)], greedy=True, want_logits=True)
     tok = check("prefill", o_last, g_logits[0], g_tok[0])
     pos = prompt_len
+    if before_decode:
+        before_decode()
     for st in range(decode_steps):
         o_last = om.forward(0, np.array([tok], np.uint32), pos)
         g_tok, g_logits = hm.unified_forward([(1, np.array([tok], np.uint32), pos, True)], greedy=True, want_logits=True)

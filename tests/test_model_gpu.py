@@ -64,13 +64,24 @@ def test_llama_style_no_qk_norm_rope_scaling_and_tied_head(pkg):
 
 
 @pytest.mark.parametrize("prompt_len", [9, 23, 70])
-def test_asymmetric_act_order_checkpoint_style(pkg, prompt_len):
+@pytest.mark.parametrize("style", ["llama", "gemma-down-first"])
+def test_asymmetric_act_order_checkpoint_style(pkg, prompt_len, style, forms):
     """desc_act + asymmetric zero points on every dense projection (the Gemma-3 GPTQ pack style of BASELINE configs[3]):
-    per-row group map, per-group zero points — through the ≤16-row, 17–32-row and ≥64-row GEMM paths."""
+    per-row group map, per-group zero points — through the ≤16-row, 17–32-row and ≥64-row GEMM paths.  The permuted inputs
+    come from the producers: every norm writes its row in the consumer's packed order, down's permutation is gate_up's column
+    order (whichever of the two the loader hands over first), decode attention scatters; only the prefill o_proj gathers."""
     from tests import modelgen
+    kw = dict(sandwich=True, activation=1, embed_scale=4.0, mlp_down_first=True) if style != "llama" else {}
+    prefill_hits = {}
+    def before_decode():
+        prefill_hits.update(forms.hits())
+        forms.reset()
+    forms.reset()
     res = modelgen.run_parity_case(pkg, moe=False, layers=2, prompt_len=prompt_len, decode_steps=2, seed=91 + prompt_len,
-                                   asym_act_order=True, hidden=256, inter=512)
+                                   asym_act_order=True, hidden=256, inter=512, before_decode=before_decode, **kw)
     _assert_parity(res)
+    assert prefill_hits.get("gather_columns", 0) == 2 and prefill_hits.get("perm_producer", 0) == 6, prefill_hits   # o_proj of both layers
+    forms.require("perm_producer", absent=("gather_columns",))                                                       # decode: none
 
 
 @pytest.mark.parametrize("kw", [
@@ -367,19 +378,26 @@ FULL_DIMS = {
     # that one id is allowed to differ, and is reported with its margin in parity_counts.jsonl)
     "dense-gqa7-c24": dict(moe=False, hidden=256, nq=14, nkv=2, hd=128, inter=384, layers=2, c=24, plen=4, steps=3, ties=1),
     "dense-hd64-c32": dict(moe=False, hidden=256, nq=8, nkv=8, hd=64, inter=256, layers=2, c=32, plen=3, steps=2),
+    # desc_act packs through the 17–32-row slab chain: every input of the chain arrives permuted from its producer
+    "dense-act-order-c24": dict(moe=False, hidden=256, nq=4, nkv=2, hd=128, inter=512, layers=2, c=24, plen=4, steps=3,
+                                asym_act_order=True, ties=1),
+    "gemma-act-order-c20": dict(moe=False, hidden=256, nq=4, nkv=2, hd=128, inter=512, layers=2, c=20, plen=3, steps=3,
+                                asym_act_order=True, activation=1, sandwich=True, embed_scale=4.0, mlp_down_first=True, ties=1),
     # Gemma-3 27B (configs[3]) layer at TP=1 dims: sandwich norms / fp32 residual, GeGLU, hidden 5376 = 42 quant groups;
     # two layers so that one is local (window 1024, θ 10k) and one global (linear-scaled θ 1M)
     "gemma3-27b": dict(moe=False, hidden=5376, nq=32, nkv=16, hd=128, inter=21504, activation=1, sandwich=True,
                        sliding_window=1024, sliding_window_pattern=2, rope_local_theta=10000.0, rope_theta=1e6,
-                       rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=73.5, layers=2, c=18, plen=2, steps=1),
+                       rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=73.5, layers=2, c=18, plen=2, steps=1,
+                       asym_act_order=True),      # the GPTQ pack BASELINE names is desc_act with explicit zero points
 }
 
 
 @pytest.mark.parametrize("name", sorted(FULL_DIMS))
-def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
+def test_full_dims_layer_batched_prefill_and_decode(pkg, name, forms):
     from tests import modelgen
     from oracle import oracle as O
     kw = dict(FULL_DIMS[name])
+    act_order = kw.get("asym_act_order", False)
     c, moe = kw.pop("c"), kw.pop("moe")
     layers, plen, steps, ties = kw.pop("layers", 1), kw.pop("plen", 3), kw.pop("steps", 2), kw.pop("ties", 0)
     tm = modelgen.TinyModel(moe, layers=layers, vocab=2048, seed=41, max_seq_len=64, **kw)
@@ -401,12 +419,15 @@ def test_full_dims_layer_batched_prefill_and_decode(pkg, name):
     for i, p in enumerate(prompts):
         ref = om.forward(i, p, 0)
         cur[i] = par.check(f"prefill/{i}", ref, lg[i], toks[i], gap())
+    forms.reset()
     for s in range(steps):                                       # teacher-forced on the oracle's tokens
         toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
         for i in range(c):
             ref = om.forward(i, np.array([cur[i]], np.uint32), plen + s)
             cur[i] = par.check(f"step{s}/{i}", ref, lg[i], toks[i], gap())
     O.set_threads(1)
+    if act_order:    # decode of a desc_act pack: the slab chain, and no gather launch anywhere
+        forms.require("perm_producer", "dense_slab_chain", "w4_slabs_lds", absent=("gather_columns",))
     # c·(steps+1) sampled rows: exact ids, at most 2 excused rows in all (their margin and error are in the record), and
     # at most 2 rows on which a router near-tie picked another expert
     par.finish(max_mismatches=ties if small else 2, max_route_ties=2 if moe else 0)
@@ -762,8 +783,8 @@ def test_tp2_gemma27b_shards_graph_decode_with_oneshot_allreduce(pkg, forms, kno
     import ctypes as C
     from tests import modelgen
     kw = dict(FULL_DIMS["gemma3-27b"])
-    for k_ in ("c", "moe", "layers", "plen", "steps"):
-        kw.pop(k_)
+    for k_ in ("c", "moe", "layers", "plen", "steps", "asym_act_order"):    # (tp.py shards natural-order packs: a desc_act pack's
+        kw.pop(k_)                                                         # row-parallel shards cut through its quant groups)
     tm = modelgen.TinyModel(False, layers=2, vocab=2048, seed=47, max_seq_len=64, **kw)
     world, c, plen, steps = 2, 18, 4, 6
     mk = dict(kv_num_blocks=c + 4, max_seqs=c, max_tokens=c * plen)
