@@ -44,6 +44,7 @@ void reload_knobs() {
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
     k.w4_ldsa_nw = env_int("FERRUM_HIP_W4_LDSA_NW", 0);
     k.w4_ldsa_s = env_int("FERRUM_HIP_W4_LDSA_S", 0);
+    k.w4_ldsw = env_int("FERRUM_HIP_W4_LDSW", 0);
     k.w4_ldsk = env_int("FERRUM_HIP_W4_LDSK", 0);
     k.w4_big = env_int("FERRUM_HIP_W4_BIG", 0);
     k.w4_nt = env_int("FERRUM_HIP_W4_NT", 0);

@@ -32,6 +32,7 @@ struct Knobs {
     int w4_ldsa = 1;
     int w4_ldsa_nw = 0;
     int w4_ldsa_s = 0;
+    int w4_ldsw = 0;             // EXPERIMENTS builds: 17–32-row dense GEMM through w4_gemm_ldsw_kernel (3 or 6 = ring slots)
     int w4_big = 0;                   // 0 auto, −1 never, 8 / 16 forces w4_gemm_big_kernel's 128- / 256-row tiles
     int w4_ldsk = 0;                  // EXPERIMENTS=1 builds only: nw·100 + kw·10 + d forces a w4_gemm_ldsk_kernel form (+1000: ares)
     int w4_nt = 0;

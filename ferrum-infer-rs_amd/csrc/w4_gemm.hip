@@ -323,7 +323,21 @@ struct W4Args {
     const __half* fa_ln;       // [K] norm weights
     float fa_eps;
     int fa_top_k;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    unsigned long long* tl;    // development: per-wave wall-clock stamps of the LDS-shared-activation kernel (tools/exp_timeline.py)
+#endif
 };
+#ifdef FERRUM_HIP_EXPERIMENTS
+static unsigned long long* g_timeline = nullptr;
+extern "C" __attribute__((visibility("default"))) void ferrum_hip_debug_set_timeline(void* p) { g_timeline = (unsigned long long*)p; }
+#define FH_TL(i)                                                                                                        \
+    do {                                                                                                                \
+        if (p.tl && lane == 0)                                                                                          \
+            p.tl[((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 4 + (i)] = wall_clock64(); \
+    } while (0)
+#else
+#define FH_TL(i) do {} while (0)
+#endif
 
 // Align-block-size computed INSIDE the grouped GEMM (P ≤ 1024 pairs): every workgroup derives its
 // 16-row block (expert + ascending pair ids) from the raw router output with an LDS histogram, a wave
@@ -993,6 +1007,7 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
     const int st = st_ok ? st_raw : p.n64 - 1;
     const int rb = blockIdx.y, z = blockIdx.z;
     const int g0 = (int)((long)p.G * z / p.S), g1 = (int)((long)p.G * (z + 1) / p.S);
+    FH_TL(0);
 
     // cooperative A loads: fragment idx ↔ (mt, k-step s, lane l): row mt·16 + (l & 15), k = 32 s + 8 (l >> 4)
     const __half* asrc[ALD];
@@ -1059,6 +1074,7 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
         FH_PIN();
         store_a(0, 0);                                  // A(g0) → LDS buffer 0
         __syncthreads();
+        FH_TL(1);
         int gb = g0;
         for (; gb + D <= g1; gb += D) {
 #pragma unroll
@@ -1084,6 +1100,7 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
         }
     }
 #undef FH_PIN
+    FH_TL(2);
     if (!st_ok) return;
     if (p.partial) {
         float* slab = p.partial + (long)z * p.rows_pad * p.n_pad;
@@ -1095,6 +1112,9 @@ __global__ __launch_bounds__(NW * 64) void w4_gemm_ldsa_kernel(W4Args p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) slab[(long)row * p.n_pad + st * 64 + nt * 16 + b] = acc[mt][nt][r];
             }
+#ifdef FERRUM_HIP_EXPERIMENTS
+        if (p.tl) { __builtin_amdgcn_s_waitcnt(0); FH_TL(3); }
+#endif
         return;
     }
 #pragma unroll
@@ -1878,9 +1898,22 @@ static int launch_tile(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stre
     return 0;
 }
 
+#ifdef FERRUM_HIP_EXPERIMENTS
+static int launch_ldsw(const W4Args& a_in, bool has_zp, dim3 grid, hipStream_t stream);
+#endif
 template <int MT, int NW>
-static int launch_ldsa(const W4Args& a, bool has_zp, dim3 grid, hipStream_t stream) {
+static int launch_ldsa(const W4Args& a_in, bool has_zp, dim3 grid, hipStream_t stream) {
     const size_t lds = (size_t)2 * MT * 256 * 16;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    W4Args a = a_in;
+    a.tl = g_timeline;
+#else
+    const W4Args& a = a_in;
+#endif
+#ifdef FERRUM_HIP_EXPERIMENTS
+    if constexpr (MT == 2 && NW == 4)
+        if (knobs().w4_ldsw && grid.y == 1) return launch_ldsw(a_in, has_zp, grid, stream);
+#endif
     if (has_zp) hipLaunchKernelGGL((w4_gemm_ldsa_kernel<MT, NW, true>), grid, dim3(NW * 64), lds, stream, a);
     else hipLaunchKernelGGL((w4_gemm_ldsa_kernel<MT, NW, false>), grid, dim3(NW * 64), lds, stream, a);
     FH_CHECK_LAUNCH();
