@@ -333,7 +333,7 @@ extern "C" __attribute__((visibility("default"))) void ferrum_hip_debug_set_time
 #define FH_TL(i)                                                                                                        \
     do {                                                                                                                \
         if (p.tl && lane == 0)                                                                                          \
-            p.tl[((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * NW + wave) * 4 + (i)] = wall_clock64(); \
+            p.tl[((((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (i)] = wall_clock64(); \
     } while (0)
 #else
 #define FH_TL(i) do {} while (0)
