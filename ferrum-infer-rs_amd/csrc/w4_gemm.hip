@@ -329,7 +329,9 @@ struct W4Args {
 };
 #ifdef FERRUM_HIP_EXPERIMENTS
 static unsigned long long* g_timeline = nullptr;
+static int g_timeline_mode = 0;      // expert-major grouped GEMM: 0 every launch, 1 down, 2 gate_up
 extern "C" __attribute__((visibility("default"))) void ferrum_hip_debug_set_timeline(void* p) { g_timeline = (unsigned long long*)p; }
+extern "C" __attribute__((visibility("default"))) void ferrum_hip_debug_set_timeline_mode(int m) { g_timeline_mode = m; }
 #define FH_TL(i)                                                                                                        \
     do {                                                                                                                \
         if (p.tl && lane == 0)                                                                                          \
@@ -692,6 +694,9 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
 // meanwhile (ballot compaction of pair_expert_ids == e, ascending pair id — the order moe_align_block_size produces), and
 // leaves if there are none.  More than 16 pairs of one expert (rare at P ≤ 8·E) take further passes over the weights (L2).
 // Same per-row arithmetic as the block-major kernel (w4_consume_group, one 16-row tile): bit-identical outputs.
+// (138 VGPRs + 16 AGPRs: three waves per SIMD, 3072 resident at once — all of gate_up's, three quarters of down's 4096, whose
+// last quarter starts when the first waves leave, tools/exp_timeline_moe.py.  Forcing four per SIMD spills into the loop
+// (32 → 52 µs); four-wave workgroups change nothing: the bound is registers, not workgroup slots.)
 template <bool HAS_ZP, int MODE>
 __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
     static_assert(MODE == 1 || MODE == 2, "grouped-GEMM modes only");
@@ -712,6 +717,7 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
         scv[buf] = sc_lane[(long)g * 16];
         if (HAS_ZP) zpv[buf] = zp_lane[(long)g * 16];
     };
+    FH_TL(0);
     // the routing and the first weight group are requested together
     int ids[16];
     const int P = p.M, chunks = (P + 63) >> 6;
@@ -729,6 +735,7 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
             n_e += __popcll(bal);
         }
     }
+    FH_TL(1);
     if (n_e == 0) return;
     __syncthreads();
     for (int j = 0; j * 16 < n_e; j++) {
@@ -775,6 +782,7 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
             consume(0);
         }
 #undef FH_PIN
+        FH_TL(2);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             if (orow[r] >= P) continue;
@@ -794,6 +802,9 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
                 }
             }
         }
+#ifdef FERRUM_HIP_EXPERIMENTS
+        if (p.tl) { __builtin_amdgcn_s_waitcnt(0); FH_TL(3); }
+#endif
     }
 }
 
@@ -2167,6 +2178,9 @@ int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, co
     a.top_k = top_k;
     const dim3 grid(w.n64, num_experts, 1);
     const bool zp = w.zp != nullptr;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    a.tl = (g_timeline_mode == 0 || g_timeline_mode == (fused_silu ? 2 : 1)) ? g_timeline : nullptr;
+#endif
     form_hit(FORM_MOE_EXPERT_MAJOR);
     if (fused_silu) {
         if (zp) hipLaunchKernelGGL((w4_gemm_moe_em_kernel<true, 2>), grid, dim3(64), 0, stream, a);
