@@ -48,3 +48,13 @@ print("wave exit            (us after the first wave): " + q(us[work, 3]))
 hist, edges = np.histogram(us[work, 3], bins=12)
 print("exit histogram: " + "  ".join(f"{edges[i]:.0f}-{edges[i+1]:.0f}us:{hist[i]}" for i in range(len(hist))))
 print(f"kernel span by the stamps: {us[work, 3].max():.2f} us")
+# where do the slow waves sit?  workgroup id = e * n64 + st (x fastest); consecutive ids go to consecutive XCDs
+ids = np.nonzero(tl.cpu().numpy().reshape(-1, 4)[:, 0] != 0)[0]
+n64 = 24 if which == "gate_up" else 32
+xcd, st_, ex = ids % 8, ids % n64, ids // n64
+dur = us[:, 3] - us[:, 0]
+print("median stream time by XCD (id % 8):   " + "  ".join(f"{x}:{np.median(dur[work & (xcd == x)]):.1f}" for x in range(8)))
+print("median stream time by supertile st:   " + "  ".join(f"{x}:{np.median(dur[work & (st_ == x)]):.1f}" for x in range(0, n64, 3)))
+print("median stream time by expert octile:  " + "  ".join(f"{x}:{np.median(dur[work & (ex // 16 == x)]):.1f}" for x in range(8)))
+slot = ids % 1024
+print("median stream time by id % 4 (SIMD?): " + "  ".join(f"{x}:{np.median(dur[work & ((ids // 8) % 4 == x)]):.1f}" for x in range(4)))
