@@ -1183,11 +1183,13 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     if (tp) RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                     S = 0;
                 } else if (S > 0 && T > 16 && T <= 32 && !L.o.bias) {
+                    if (L.o.perm) form_hit(FORM_PERM_PRODUCER);          // (attn_perm: the decode attention wrote the permuted rows)
                     // 17–32 rows: activations staged once per workgroup in LDS (a wave fetching its own fragments pulls 2× the
                     // weight bytes from L2); decode c=32 4.60 → 4.57 ms per step
                     RUN(w4_gemm_dense_slabs_lds(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
                     slabs = m->workspace;
                 } else if (S > 0) {
+                    if (L.o.perm) form_hit(FORM_PERM_PRODUCER);
                     RUN(w4_gemm_dense_slabs(L.o, m->attn_out, m->workspace, m->workspace_bytes, T, S, &rows_pad, &n_pad, s));
                     slabs = m->workspace;
                     S = std::min(S, L.o.G);
