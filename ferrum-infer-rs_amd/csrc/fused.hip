@@ -493,8 +493,9 @@ template <int CHUNKS>
 __global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
     const __half* __restrict__ down, const float* __restrict__ weights, const __half* __restrict__ residual,
     __half* __restrict__ residual_out, const __half* __restrict__ next_w, float eps, __half* __restrict__ norm_out,
-    int top_k, int H) {
+    int top_k, int H, const int32_t* __restrict__ out_perm) {
     __shared__ float red[4];
+    extern __shared__ _Float16 stage[];            // H halves when out_perm (act-order q|k|v of the next layer: the row leaves permuted)
     const long row = blockIdx.x;
     const int nvec = H >> 3;
     half8 v[CHUNKS];
@@ -547,19 +548,25 @@ __global__ __launch_bounds__(256) void moe_combine_add_rmsnorm_kernel(
             half8 o;
 #pragma unroll
             for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[j]);
-            *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
+            if (out_perm) *reinterpret_cast<half8*>(stage + i * 8) = o;
+            else *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = o;
         }
+    }
+    if (out_perm) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nvec; i += 256) *reinterpret_cast<half8*>(norm_out + row * H + i * 8) = lds_gather8(stage, out_perm, i * 8);
     }
 }
 
 int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, const __half* residual,
                                  __half* residual_out, const __half* next_w, float eps, __half* norm_out, int tokens,
-                                 int top_k, int H, hipStream_t s) {
+                                 int top_k, int H, hipStream_t s, const int32_t* out_perm) {
     if (tokens <= 0) return 0;
     FH_REQUIRE(H % 8 == 0 && H <= 8 * 256 * 4, "moe_combine_add_rms_norm: hidden=%d must be a multiple of 8, <= 8192", H);
     const int chunks = cdiv(H / 8, 256);
-#define FH_A(C) hipLaunchKernelGGL((moe_combine_add_rmsnorm_kernel<C>), dim3(tokens), dim3(256), 0, s, down, weights, \
-                                   residual, residual_out, next_w, eps, norm_out, top_k, H)
+    const size_t lds = (out_perm && next_w) ? (size_t)H * 2 : 0;
+#define FH_A(C) hipLaunchKernelGGL((moe_combine_add_rmsnorm_kernel<C>), dim3(tokens), dim3(256), lds, s, down, weights, \
+                                   residual, residual_out, next_w, eps, norm_out, top_k, H, next_w ? out_perm : nullptr)
     if (chunks <= 1) FH_A(1); else if (chunks <= 2) FH_A(2); else FH_A(4);
 #undef FH_A
     FH_CHECK_LAUNCH();

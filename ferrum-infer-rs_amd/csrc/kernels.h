@@ -186,7 +186,7 @@ int fused_add_rms_norm_route_slabs_f16(__half* residual, const __half* x, const 
                                        const int32_t* out_perm = nullptr);
 int moe_combine_add_rms_norm_f16(const __half* down, const float* weights, const __half* residual,
                                  __half* residual_out, const __half* next_w, float eps, __half* norm_out, int tokens,
-                                 int top_k, int H, hipStream_t s);
+                                 int top_k, int H, hipStream_t s, const int32_t* out_perm = nullptr);
 // B split over Q expert parts per token (+ optional fp32 split-K slabs of the o projection); the Q sorted
 // candidate lists are merged by the gate_up grouped GEMM (w4_gemm_moe_merge_route).
 int fused_add_rms_norm_route_split_f16(const __half* residual_in, __half* residual_out, const __half* x,

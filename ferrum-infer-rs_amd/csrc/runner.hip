@@ -1166,11 +1166,13 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             // the rank's own experts is a partial [T, H] that meets the other ranks' in the all-reduce a dense MLP uses, and the
             // reduced row then enters the residual like a single expert row of weight 1 (the same kernel, top_k = 1)
             auto moe_tail = [&](const __half* res_in, __half* res_out) -> int {
+                // (an act-order q|k|v of the next layer gets its rows permuted by this kernel)
+                qkv_in_perm = next_ln && next_qkv_perm != nullptr;
                 if (!ep)
-                    return moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, K, H, s);
+                    return moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, K, H, s, next_qkv_perm);
                 if (int rc_ = moe_combine_local_f16(m->moe_down, m->expert_w, m->expert_ids_local, m->mlp_out, T, K, H, s)) return rc_;
                 if (int rc_ = tp_all_reduce(m, m->mlp_out, (size_t)T * H)) return rc_;
-                return moe_combine_add_rms_norm_f16(m->mlp_out, m->ones, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, 1, H, s);
+                return moe_combine_add_rms_norm_f16(m->mlp_out, m->ones, res_in, res_out, next_ln, c.rms_eps, m->norm_out, T, 1, H, s, next_qkv_perm);
             };
             const bool decode_fast = T <= 64 && P <= 1024 && K <= 8 && Q >= 1 && tiles / Q <= 8 && (!L.o.perm || attn_perm);
             const bool o_quant = L.o.qw != nullptr;           // the slab forms are INT4 kernels; an unquantised o_proj takes the direct GEMM

@@ -87,8 +87,8 @@ def test_asymmetric_act_order_checkpoint_style(pkg, prompt_len, style, forms):
 @pytest.mark.parametrize("prompt_len", [9, 70])
 def test_act_order_attention_projections_in_a_moe_model(pkg, prompt_len, forms):
     """A MoE checkpoint whose ATTENTION projections are desc_act packs (the expert stacks are natural order: act-order experts are
-    refused at load): the decode attention scatters for o_proj and the split-route / slab fast path stays on; q|k|v, fed by the MoE
-    tail kernels, keeps its gather launch."""
+    refused at load): the decode attention scatters for o_proj and the split-route / slab fast path stays on; q|k|v gets its rows
+    permuted by the embedding norm (layer 0) and by the MoE tail kernel (combine + add + norm) of the layer before."""
     from tests import modelgen
     seen = {}
     def before_decode():
@@ -98,10 +98,9 @@ def test_act_order_attention_projections_in_a_moe_model(pkg, prompt_len, forms):
     res = modelgen.run_parity_case(pkg, moe=True, layers=2, prompt_len=prompt_len, decode_steps=3, seed=301 + prompt_len,
                                    asym_act_order=True, before_decode=before_decode)
     _assert_parity(res)
-    h = forms.require("perm_producer", "gather_columns", "w4_slabs")          # decode: o_proj permuted by attention; q|k|v gathered
-    assert h["gather_columns"] == 3 * (2 - 1) and h["perm_producer"] == 3 * 3, h   # 3 steps: layer 1's q|k|v gathers (layer 0's comes
-                                                                                   # permuted from the embedding norm); + o_proj of both layers
-    assert seen.get("gather_columns", 0) == 2 * 2 - 1, seen                  # prefill: q|k|v (but layer 0's) and o_proj of both layers
+    h = forms.require("perm_producer", "w4_slabs", absent=("gather_columns",))    # decode: no gather launch at all
+    assert h["perm_producer"] == 3 * 4, h                                        # 3 steps × (q|k|v + o_proj) × 2 layers
+    assert seen.get("gather_columns", 0) == 2 and seen.get("perm_producer", 0) == 2, seen   # prefill: only o_proj gathers
 
 
 @pytest.mark.parametrize("kw", [
