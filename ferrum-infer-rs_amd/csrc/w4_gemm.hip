@@ -696,7 +696,9 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
 // Same per-row arithmetic as the block-major kernel (w4_consume_group, one 16-row tile): bit-identical outputs.
 // (138 VGPRs + 16 AGPRs: three waves per SIMD, 3072 resident at once — all of gate_up's, three quarters of down's 4096, whose
 // last quarter starts when the first waves leave, tools/exp_timeline_moe.py.  Forcing four per SIMD spills into the loop
-// (32 → 52 µs); four-wave workgroups change nothing: the bound is registers, not workgroup slots.)
+// (32 → 52 µs), a non-interleaved consume at four per SIMD still spills (down 17.8 → 21.3 µs), four-wave workgroups change nothing
+// (the bound is registers, not workgroup slots), and two supertiles per wave for down — 2048 waves, one round — land on the same
+// 17.8 µs: the second round is not what holds down at 4.9 TB/s.)
 template <bool HAS_ZP, int MODE>
 __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
     static_assert(MODE == 1 || MODE == 2, "grouped-GEMM modes only");
