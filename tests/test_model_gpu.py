@@ -327,6 +327,40 @@ def test_decode_steps_graph_equals_eager_and_oracle(pkg, knobs, forms):
         assert agree or True
 
 
+@pytest.mark.parametrize("style", ["dense-gemma", "moe"])
+def test_decode_steps_graph_on_act_order_packs(pkg, knobs, forms, style):
+    """desc_act packs inside the captured decode step: the permuted-row producers (norms with the consumer's permutation, the
+    scattering decode attention, gate_up's folded column order, the MoE tail) are plain kernel arguments, so graph replay ≡ eager
+    launches ≡ step-by-step unified_forward, with no gather launch captured."""
+    from tests import modelgen
+    kw = dict(sandwich=True, activation=1, embed_scale=4.0, mlp_down_first=True) if style == "dense-gemma" else {}
+    tm = modelgen.TinyModel(style == "moe", layers=2, seed=77, asym_act_order=True, **kw)
+    rng = np.random.default_rng(78)
+    V = tm.cfg["vocab"]
+    prompts = [rng.integers(0, V, size=n).astype(np.uint32) for n in (19, 5, 33)]
+    steps = 14
+    outs = []
+    for mode in ("graph", "eager", "unified"):
+        hm = tm.hip_model(pkg, kv_num_blocks=64, max_seqs=8, max_tokens=128)
+        knobs.set(NO_GRAPH=1 if mode == "eager" else None)
+        first, _ = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+        forms.reset()
+        if mode == "unified":
+            cur = first.copy()
+            hist = []
+            for s in range(steps):
+                cur, _ = hm.unified_forward([(i, [int(cur[i])], len(prompts[i]) + s, True) for i in range(3)], greedy=True)
+                hist.append(cur.copy())
+            outs.append(np.stack(hist))
+        else:
+            outs.append(hm.decode_steps([0, 1, 2], first, steps))
+            if mode == "graph":
+                forms.require("graph_capture", "graph_replay", "perm_producer", absent=("gather_columns",))
+            else:
+                forms.require("perm_producer", absent=("graph_capture", "graph_replay", "gather_columns"))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
 def test_decode_steps_graph_survives_history_regrowth(pkg, knobs, forms):
     """A short decode_steps call followed by a longer one on the same batch replays the graph captured by the first (same
     batch size, same kv bucket) while the sampled-id history buffer is regrown in between (regression: the replayed step
