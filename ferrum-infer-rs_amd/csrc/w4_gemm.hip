@@ -2061,7 +2061,7 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
         return 0;
     }
 #else
-    FH_REQUIRE(kn.w4_ldsk == 0, "FERRUM_HIP_W4_LDSK: the experimental decode GEMM forms are not compiled in (make EXPERIMENTS=1)");
+    FH_REQUIRE(kn.w4_ldsk == 0 && kn.w4_ldsw == 0, "FERRUM_HIP_W4_LDSK / _LDSW: the experimental decode GEMM forms are not compiled in (make EXPERIMENTS=1)");
 #endif
     const int tile_min_env = kn.w4_tile_min_m;
     const int tile_min_m = tile_min_env > 0 ? tile_min_env : ((long)w.k * w.n >= (12L << 20) ? 33 : 64);
