@@ -38,7 +38,7 @@ void reload_knobs() {
     k.attn_flash32 = env_flag("FERRUM_HIP_ATTN_FLASH32");
     k.attn_no_resident = env_flag("FERRUM_HIP_ATTN_NO_RESIDENT");
     k.attn_resident_min_wgs = env_int("FERRUM_HIP_ATTN_RESIDENT_MIN_WGS", 128);
-    k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 8);
+    k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 16);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);

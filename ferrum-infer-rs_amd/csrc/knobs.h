@@ -26,7 +26,7 @@ struct Knobs {
     long attn_resident_min_wgs = 128; // … and only from this many workgroups (tests lower it)
     bool attn_flash32 = false;        // the flash form with 32-key steps (paged_prefill_attn_kernel) for head_dim 128 too
     // INT4 GEMMs (w4_gemm.hip)
-    int moe_kw_pairs = 8;
+    int moe_kw_pairs = 16;
     int w4_tile_min_m = 0;
     int w4_tile_wgs = 256;
     int w4_ldsa = 1;
