@@ -282,6 +282,26 @@ def test_decode_batch_larger_than_64_sequences(pkg, moe):
     assert checked >= 2
 
 
+def test_moe_k_split_form_is_confined_to_its_pair_list(pkg, knobs):
+    """FERRUM_HIP_MOE_KW_PAIRS selects the four-wave K-split form of the block-major MoE decode GEMM, which keeps its pair list in 64
+    LDS slots per wave: a setting beyond that must not reach the form (it once did, computing garbage faster).  12 sequences ×
+    top-8 = 96 pairs with the knob at 1024 must reproduce the default build's tokens and logits bit for bit."""
+    from tests import modelgen
+    tm = modelgen.TinyModel(True, layers=2, seed=83, experts=32, top_k=8)
+    rng = np.random.default_rng(84)
+    V = tm.cfg["vocab"]
+    prompts = [rng.integers(0, V, size=int(n)).astype(np.uint32) for n in rng.integers(3, 9, size=12)]
+    outs = []
+    for kw in (None, 1024):
+        knobs.set(MOE_KW_PAIRS=kw)
+        hm = tm.hip_model(pkg, kv_num_blocks=64, max_seqs=16, max_tokens=128)
+        first, lg0 = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        nxt, lg1 = hm.unified_forward([(i, [int(first[i])], len(prompts[i]), True) for i in range(12)], greedy=True, want_logits=True)
+        outs.append((first.copy(), nxt.copy(), lg1.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+    assert np.all(np.isfinite(outs[1][2]))
+
+
 def test_decode_steps_graph_equals_eager_and_oracle(pkg, knobs, forms):
     """The hipGraph-replayed decode loop must produce the same ids as step-by-step unified_forward."""
     from tests import modelgen
