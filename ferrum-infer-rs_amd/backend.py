@@ -14,7 +14,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libferrum_hip.so")
+LIB_PATH = os.environ.get("FERRUM_HIP_LIB") or os.path.join(_HERE, "lib", "libferrum_hip.so")   # (override: development builds, e.g. make EXPERIMENTS=1 into lib_exp/)
 _lib = None
 
 vp, i32p, u32p, f32p, u8p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_uint8)
@@ -150,6 +150,19 @@ class ExpertStack(GptqLinear):
                                                                   _ptr(output), prob_m, num_experts, top_k,
                                                                   int(fused_silu_mul), ctx.stream),
                "moe_gemm_phase_expert_major")
+
+    def gemm_phase_expert_major_pair(self, ctx, down_stack, inp, expert_ids_per_pair, act_out, output, prob_m, num_experts, top_k):
+        """gate_up (+ silu·mul) and down as ONE launch; self is the fused gate_up stack."""
+        _check(ctx.lib.ferrum_hip_moe_gemm_phase_expert_major_pair_f16(self.handle, down_stack.handle, _ptr(inp),
+                                                                       _ptr(expert_ids_per_pair), _ptr(act_out), _ptr(output),
+                                                                       prob_m, num_experts, top_k, ctx.stream),
+               "moe_gemm_phase_expert_major_pair")
+
+    def pair_timeouts(self, ctx):
+        import ctypes
+        t = ctypes.c_uint(0)
+        _check(ctx.lib.ferrum_hip_moe_pair_status(self.handle, ctypes.byref(t)), "moe_pair_status")
+        return t.value
 
     def gemm_phase_merge_route(self, ctx, inp, cand, stats, output, tokens, num_parts, top_k, norm_topk_prob, num_experts,
                                max_blocks, expert_ids_out, expert_weights_out, sorted_out, block_ids_out, total_out,

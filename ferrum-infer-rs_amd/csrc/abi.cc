@@ -39,6 +39,7 @@ void reload_knobs() {
     k.attn_no_resident = env_flag("FERRUM_HIP_ATTN_NO_RESIDENT");
     k.attn_resident_min_wgs = env_int("FERRUM_HIP_ATTN_RESIDENT_MIN_WGS", 128);
     k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 16);
+    k.moe_em2 = env_int("FERRUM_HIP_MOE_EM2", 1);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
@@ -68,7 +69,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk", "gather_columns",
-    "perm_producer"};
+    "perm_producer", "moe_expert_major_pair"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 
@@ -89,6 +90,9 @@ struct FerrumHipGptq {
     struct DispatchSlot { int32_t* host = nullptr; int32_t* dev = nullptr; size_t cap = 0; hipEvent_t done = nullptr; };
     DispatchSlot slots[4];
     int next_slot = 0;
+    // expert_major_pair: [2][E] arrival counters + the give-up word of the merged gate_up → down launch
+    unsigned* pair_arrive = nullptr;
+    int pair_experts = 0;
 };
 
 struct FerrumHipGraph {
@@ -348,6 +352,7 @@ int ferrum_hip_gptq_free(FerrumHipGptq* g) {
     if (g->dev.bias) (void)hipFree(g->dev.bias);
     if (g->gather_scratch) (void)hipFree(g->gather_scratch);
     for (void* p : g->retired_scratch) (void)hipFree(p);
+    if (g->pair_arrive) (void)hipFree(g->pair_arrive);
     for (auto& sl : g->slots) {
         if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
         if (sl.host) (void)hipHostFree(sl.host);
@@ -436,6 +441,46 @@ int ferrum_hip_moe_gemm_phase_expert_major_f16(const FerrumHipGptq* stack, const
     if (prob_m > 1024) { fh::set_error("moe_gemm_phase_expert_major: prob_m=%d > 1024 (use moe_align_block_size + moe_gemm_phase)", prob_m); return FERRUM_HIP_UNSUPPORTED; }
     return w4_gemm_moe_expert_major(stack->dev, CH(input), H(output), expert_ids_per_pair, num_experts, prob_m, top_k,
                                     fused_silu_mul, ST(stream));
+}
+
+int ferrum_hip_moe_gemm_phase_expert_major_pair_f16(FerrumHipGptq* gate_up_stack, const FerrumHipGptq* down_stack, const void* input,
+                                                    const int32_t* expert_ids_per_pair, void* act_out, void* output, int prob_m,
+                                                    int num_experts, int top_k, void* stream) {
+    FH_REQUIRE(gate_up_stack && down_stack && input && expert_ids_per_pair && act_out && output, "moe_gemm_phase_expert_major_pair: null argument");
+    FH_REQUIRE(top_k >= 1 && num_experts >= 1, "moe_gemm_phase_expert_major_pair: top_k=%d num_experts=%d", top_k, num_experts);
+    FH_REQUIRE(gate_up_stack->dev.fused_gate_up && !down_stack->dev.fused_gate_up,
+               "moe_gemm_phase_expert_major_pair: gate_up stack must be loaded with fuse_gate_up, the down stack without");
+    if (prob_m > 1024) { fh::set_error("moe_gemm_phase_expert_major_pair: prob_m=%d > 1024", prob_m); return FERRUM_HIP_UNSUPPORTED; }
+    FerrumHipGptq* g = gate_up_stack;
+    if (g->pair_experts < num_experts) {
+        // (a captured graph may still hold the old counters: retired with the handle, like outgrown gather buffers)
+        if (g->pair_arrive) g->retired_scratch.push_back(g->pair_arrive);
+        g->pair_arrive = nullptr;
+        const size_t words = (size_t)2 * num_experts * MOE_PAIR_COUNTER_STRIDE + 4;
+        FH_CHECK_HIP(hipMalloc((void**)&g->pair_arrive, words * sizeof(unsigned)));
+        FH_CHECK_HIP(hipMemset(g->pair_arrive, 0, words * sizeof(unsigned)));
+        g->pair_experts = num_experts;
+    }
+    // op level: the counters are zeroed by a memset node in front of every launch (a captured call replays with the same
+    // pointers, so the runner's alternating halves do not apply); the give-up word is checked by ferrum_hip_moe_pair_status
+    unsigned* arrive = g->pair_arrive;
+    const size_t half = (size_t)g->pair_experts * MOE_PAIR_COUNTER_STRIDE;
+    FH_CHECK_HIP(hipMemsetAsync(arrive, 0, half * sizeof(unsigned), ST(stream)));
+    int took = 0;
+    if (int rc = w4_gemm_moe_expert_major_pair(g->dev, down_stack->dev, CH(input), H(act_out), H(output), expert_ids_per_pair, num_experts,
+                                               prob_m, top_k, arrive, arrive + half, arrive + 2 * half, &took, ST(stream)))
+        return rc;
+    if (!took) { fh::set_error("moe_gemm_phase_expert_major_pair: shapes not taken by the merged form"); return FERRUM_HIP_UNSUPPORTED; }
+    return 0;
+}
+
+/* number of in-launch waits of the stack's merged launches that gave up so far (0 = every hand-off completed) */
+int ferrum_hip_moe_pair_status(const FerrumHipGptq* gate_up_stack, unsigned* timeouts) {
+    FH_REQUIRE(gate_up_stack && timeouts, "moe_pair_status: null argument");
+    *timeouts = 0;
+    if (!gate_up_stack->pair_arrive) return 0;
+    FH_CHECK_HIP(hipMemcpy(timeouts, gate_up_stack->pair_arrive + 2 * (size_t)gate_up_stack->pair_experts * MOE_PAIR_COUNTER_STRIDE, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return 0;
 }
 
 int ferrum_hip_sandwich_add_rms_norm_f32(const void* branch_f16, const void* w_branch, float* residual_f32, const void* w_next,

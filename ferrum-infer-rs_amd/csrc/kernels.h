@@ -60,6 +60,12 @@ int w4_gemm_moe(const W4Device& w, const __half* x, __half* out, const int32_t* 
                 int max_blocks, int top_k, int fused_silu, hipStream_t stream);
 int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids, int num_experts,
                              int num_valid_pairs, int top_k, int fused_silu, hipStream_t stream);
+// words between the per-expert arrival counters of the merged launch (one 256-byte line each): `arrive` / `arrive_next` hold
+// num_experts · MOE_PAIR_COUNTER_STRIDE words
+constexpr int MOE_PAIR_COUNTER_STRIDE = 64;
+int w4_gemm_moe_expert_major_pair(const W4Device& gu, const W4Device& dn, const __half* x, __half* h, __half* out,
+                                  const int32_t* pair_expert_ids, int num_experts, int num_valid_pairs, int top_k,
+                                  unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream);
 int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
                              int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
                              int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream);

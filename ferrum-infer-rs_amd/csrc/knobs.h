@@ -27,6 +27,7 @@ struct Knobs {
     bool attn_flash32 = false;        // the flash form with 32-key steps (paged_prefill_attn_kernel) for head_dim 128 too
     // INT4 GEMMs (w4_gemm.hip)
     int moe_kw_pairs = 16;
+    int moe_em2 = 1;                  // decode: gate_up → down as one expert-major launch (0 = two launches)
     int w4_tile_min_m = 0;
     int w4_tile_wgs = 256;
     int w4_ldsa = 1;
@@ -87,6 +88,7 @@ enum Form : int {
     FORM_W4_LDSK,               // 17–64 rows: LDS-shared activations, K split over the waves of a workgroup
     FORM_GATHER_COLUMNS,        // act-order input gather as a launch of its own (no producer wrote the permuted row)
     FORM_PERM_PRODUCER,         // act-order: the producing kernel (norm, gated activation via gate_up's column order, decode attention) wrote the permuted row
+    FORM_MOE_EXPERT_MAJOR_PAIR, // gate_up → down in one expert-major launch (in-launch hand-off per expert)
     FORM_COUNT
 };
 

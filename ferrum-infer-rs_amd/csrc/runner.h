@@ -78,6 +78,11 @@ struct FerrumHipModel {
     fh::RouteCand* route_cand = nullptr;  // [T ≤ 64][Q][8]
     float* route_stats = nullptr;         // [T][Q][2]
     unsigned* route_arrive = nullptr;     // [T] arrival counters of the split route kernel (zero between launches)
+    unsigned* em2_arrive = nullptr;       // [2][E] per-expert arrival counters of the merged gate_up → down launch (double buffer: each launch zeroes the other half) + [1] give-up count
+    int em2_parity = 0;                   // which half the next merged launch counts in (enqueue order = stream order)
+    bool em2_failed = false;              // a bounded in-launch wait gave up once: the two-launch form from then on
+    unsigned* inlaunch_timeouts = nullptr; // pinned host word (device-visible): bumped by any in-launch wait that gave up; read after every host sync
+    unsigned inlaunch_timeouts_seen = 0;
     int route_parts = 4;                  // expert parts per token in the decode route kernel (1 = single-workgroup kernel)
     bool fuse_rope_attn = true;           // decode: QK-norm + RoPE + KV write inside the attention launch
     int fuse_tail_max_rows = 1;           // MoE decode at ≤ this many rows (≤ 4): a layer's combine + add + norm runs as the prologue of the next

@@ -258,6 +258,21 @@ static void drop_graph(FerrumHipModel* m) {
     if (m->graph) { (void)hipGraphDestroy(m->graph); m->graph = nullptr; }
 }
 
+// Merged launches hand data over between workgroups and bound every wait; a wait that gave up has produced garbage.  Called
+// after every host synchronisation of a forward: the call fails, the captured graph is dropped and the merged forms stay off.
+static int check_inlaunch_waits(FerrumHipModel* m) {
+    if (!m->inlaunch_timeouts) return 0;
+    const unsigned now = *reinterpret_cast<volatile unsigned*>(m->inlaunch_timeouts);
+    if (now == m->inlaunch_timeouts_seen) return 0;
+    const unsigned n = now - m->inlaunch_timeouts_seen;
+    m->inlaunch_timeouts_seen = now;
+    m->em2_failed = true;
+    drop_graph(m);
+    fh::set_error("%u in-launch wait(s) of a merged kernel gave up (gate_up → down hand-off): the results of this call are invalid; "
+                  "the two-launch form is used from now on", n);
+    return 3;
+}
+
 static int q_dim(const FerrumHipModelConfig& c) { return c.num_heads * c.head_dim; }
 static int kv_dim(const FerrumHipModelConfig& c) { return c.num_kv_heads * c.head_dim; }
 static int qkv_dim(const FerrumHipModelConfig& c) { return q_dim(c) + 2 * kv_dim(c); }
@@ -368,6 +383,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->expert_ids_local, (void*)m->ones, m->vp_pairs, m->vp_gathered})
         if (p) (void)hipFree(p);
     if (m->idx_host) (void)hipHostFree(m->idx_host);
+    if (m->inlaunch_timeouts) (void)hipHostFree(m->inlaunch_timeouts);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return 0;
@@ -719,7 +735,14 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         rc |= dev_alloc(&m->residual2, (size_t)64 * H);
         rc |= dev_alloc(&m->route_cand, (size_t)512 * 8);     // [T ≤ 64][Q ≤ 8][8]
         rc |= dev_alloc(&m->route_stats, (size_t)512 * 2);
-        rc |= dev_alloc(&m->route_arrive, (size_t)64);         // zeroed here; the route kernel re-arms it
+        // [64] arrival counters of the split route kernel (zeroed here; the kernel re-arms them) + [2][E] per-expert counters of the
+        // merged gate_up → down launch + its give-up count; the head kernel of every forward zeroes the route counters and half 0
+        rc |= dev_alloc(&m->route_arrive, (size_t)64 + 2 * (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE + 4);
+        if (!rc) m->em2_arrive = m->route_arrive + 64;
+        if (!rc) {
+            FH_CHECK_HIP(hipHostMalloc((void**)&m->inlaunch_timeouts, 64, hipHostMallocDefault));
+            *m->inlaunch_timeouts = 0u;
+        }
         rc |= dev_alloc(&m->moe_act, P * c.expert_inter);
         rc |= dev_alloc(&m->moe_down, P * H);
     } else {
@@ -971,6 +994,15 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
     const int32_t* ids = moe_ids(m);
     // (the expert-major threshold compares pairs per expert: P pairs over num_experts, whatever share of them is local)
     if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts) {
+        if (knobs().moe_em2 && m->em2_arrive && !m->em2_failed) {
+            // one launch: down tiles wait for their expert's gate_up tiles inside it (w4_gemm_moe_em2_kernel)
+            unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * E * MOE_PAIR_COUNTER_STRIDE;
+            unsigned* nxt = m->em2_arrive + (size_t)(m->em2_parity ^ 1) * E * MOE_PAIR_COUNTER_STRIDE;
+            int took = 0;
+            if (int rc = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, m->norm_out, m->moe_act, m->moe_down, ids, E, P, K, cur, nxt,
+                                                       m->inlaunch_timeouts, &took, s)) return rc;
+            if (took) { m->em2_parity ^= 1; return 0; }
+        }
         if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, ids, E, P, K, 1, s)) return rc;
         return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, ids, E, P, 1, 0, s);
     }
@@ -1084,7 +1116,8 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     // workgroup owns the row (every norm of the dense layer) or the rows are few (decode attention scatters); the gated
     // activation is permuted by gate_up's column order (pack_gate_up).  Only the prefill o_proj keeps a gather launch.
     RUN(embed_rms_norm_f16(m->embed, tokens, c.embed_scale, m->residual, sandwich ? m->residual_f32 : nullptr, m->layers[0].input_ln,
-                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 : 0, s, m->layers[0].qkv.perm));
+                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 + m->ep_E * MOE_PAIR_COUNTER_STRIDE : 0, s, m->layers[0].qkv.perm));
+    m->em2_parity = 0;          // the head kernel zeroed half 0 of the merged MoE launch's counters; every such launch zeroes the other half
     bool qkv_in_perm = m->layers[0].qkv.perm != nullptr;      // norm_out holds the row in L.qkv's packed order
     // decode at ≤ 4 rows (MoE models): the tail of layer l — combine + residual add + next input norm — runs as the prologue of
     // layer l+1's q|k|v GEMM instead of as a launch of its own (every dependent launch costs ≈ 4 µs there)
@@ -1518,7 +1551,7 @@ int ferrum_hip_model_unified_forward_ex(FerrumHipModel* m, const FerrumHipBatchI
     }
     FH_CHECK_HIP(hipStreamSynchronize(m->stream));
     for (int i = 0; i < num_items; i++) m->seqs[items[i].seq_id].len += items[i].num_q_tokens;
-    return 0;
+    return check_inlaunch_waits(m);
 }
 
 int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, const uint32_t* first_tokens, int n,
@@ -1640,7 +1673,7 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
         FH_CHECK_HIP(hipMemcpyAsync(out_tokens, m->history, (size_t)steps * n * 4, hipMemcpyDeviceToHost, m->stream));
     FH_CHECK_HIP(hipStreamSynchronize(m->stream));
     for (int i = 0; i < n; i++) m->seqs[seq_ids[i]].len += steps;
-    return 0;
+    return check_inlaunch_waits(m);
 }
 
 // Bench instrumentation: average device time of ONE launch of a hot kernel, measured with HIP events

@@ -236,8 +236,8 @@ __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned lo
             for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float v = HAS_ZP ? t1[mt][r] - z_f * s_sum[mt][r] : t1[mt][r];
-                    acc[mt][nt][r] += s_f * v;
+                    float v = HAS_ZP ? __builtin_fmaf(-z_f, s_sum[mt][r], t1[mt][r]) : t1[mt][r];
+                    acc[mt][nt][r] = __builtin_fmaf(s_f, v, acc[mt][nt][r]);      // (explicit: left to contraction, one inlining context fused it and another did not)
                 }
         }
         return;
@@ -274,8 +274,8 @@ __device__ __forceinline__ void w4_consume_group(const WQ (&wq)[NT], unsigned lo
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float v = HAS_ZP ? tmp[mt][nt][r] - z_f * s_sum[mt][r] : tmp[mt][nt][r];
-                acc[mt][nt][r] += s_f * v;
+                float v = HAS_ZP ? __builtin_fmaf(-z_f, s_sum[mt][r], tmp[mt][nt][r]) : tmp[mt][nt][r];
+                acc[mt][nt][r] = __builtin_fmaf(s_f, v, acc[mt][nt][r]);
             }
     }
 }
@@ -808,6 +808,250 @@ __global__ __launch_bounds__(64) void w4_gemm_moe_em_kernel(W4Args p) {
         if (p.tl) { __builtin_amdgcn_s_waitcnt(0); FH_TL(3); }
 #endif
     }
+}
+
+// ── gate_up → down of a decode batch in ONE expert-major launch ────────────────────────────────────────────────────
+// The two grouped GEMMs of a layer as one grid: blocks [0, n64_gu·E) are gate_up tiles (column supertile fastest, expert
+// next — the em kernel's own order), blocks behind them down tiles.  All gate_up waves are resident at once (three per
+// SIMD), so a down wave only ever gets a slot a gate_up wave has left; it asks for its expert's first two weight groups at
+// once, finds the expert's pairs, and then waits until the expert's gate_up tiles have all arrived (one counter per
+// expert, n64_gu arrivals) before it reads the gated activations.  What that buys over two launches: no kernel boundary,
+// gate_up's tail (the last few hundred 64-KiB streams cannot fill the memory pipe) runs beside down's weight requests, and
+// down's first-data latency is gone.  Hand-off (MI355X_MICROARCH.md § visibility, valid forms, first row): the gated
+// activations are stored write-through (8-byte sc1 stores — the transposed accumulator, w4_consume_group_t), every storing
+// wave drains its stores and then adds to its expert's counter; the consumer polls that counter with relaxed sc1 loads
+// (one lane, s_sleep between polls) and reads the activations with sc1 buffer loads only.  No wave waits before it has
+// produced everything it will ever produce, every wait is bounded (a give-up bumps `timeout`, which the host reads at its
+// next synchronisation), and nothing depends on where a block runs.  The counters of the NEXT launch (the other half of a
+// double buffer) are zeroed here, so no memset node sits in front of the launch.
+struct W4Em2Args {
+    const uint32_t* gu_qw; const __half* gu_sc; const __half* gu_zp; long gu_stride_qw, gu_stride_sc; int gu_G, gu_n64;
+    const uint32_t* dn_qw; const __half* dn_sc; const __half* dn_zp; long dn_stride_qw, dn_stride_sc; int dn_G, dn_n64;
+    const __half* x;                 // [T, K] normalised rows (input row of pair p = p / top_k)
+    __half* h;                       // [P, I] gated activations: written and read inside the launch
+    __half* out;                     // [P, H] expert outputs
+    const int32_t* pair_expert_ids;  // [P]
+    int P, top_k, E, K, I, H;
+    unsigned* arrive;                // [E · EM2_STRIDE] one counter per expert, each on a 256-byte line of its own; zero on entry
+    unsigned* arrive_next;           // the same for the launch after this one: zeroed here
+    unsigned* timeout;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    unsigned long long* tl;          // development: per-wave wall-clock stamps (tools/exp_timeline_moe.py)
+#endif
+};
+// Thousands of waves poll 128 counters: packed into 512 bytes they would all sit behind one or two memory channels (polls
+// and arrivals queue up behind each other there — the first build of this kernel took 108 µs instead of 50); one counter per
+// 256-byte line spreads them over the channels.
+constexpr int EM2_STRIDE = MOE_PAIR_COUNTER_STRIDE;
+#ifdef FERRUM_HIP_EXPERIMENTS
+#define FH_TL2(i) do { if (p.tl && lane == 0) p.tl[(long)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define FH_TL2(i) do {} while (0)
+#endif
+
+template <bool HAS_ZP, bool IS_GU>
+__device__ __forceinline__ void w4_em2_role(const W4Em2Args& p, int tile, int* s_rows, _Float16* s_out) {
+    const int lane = threadIdx.x;
+    const int a = lane >> 4, b = lane & 15;
+    const int n64 = IS_GU ? p.gu_n64 : p.dn_n64, G = IS_GU ? p.gu_G : p.dn_G;
+    const int st = tile % n64, e = tile / n64;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t* qw0 = IS_GU ? p.gu_qw : p.dn_qw;
+    const __half* sc0 = IS_GU ? p.gu_sc : p.dn_sc;
+    const __half* zp0 = IS_GU ? p.gu_zp : p.dn_zp;
+    const long sqw = IS_GU ? p.gu_stride_qw : p.dn_stride_qw, ssc = IS_GU ? p.gu_stride_sc : p.dn_stride_sc;
+    const u32x4* qw_lane = reinterpret_cast<const u32x4*>(qw0 + (long)e * sqw) + ((long)st * G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(sc0 + (long)e * ssc) + ((long)st * G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(zp0 + (long)e * ssc) + ((long)st * G) * 16 + b : nullptr;
+    u32x4 wq[2][4];
+    uint2 scv[2], zpv[2];
+    half8 af[2][1][4];
+    auto issue_w = [&](int buf, int g) {
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) wq[buf][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+        scv[buf] = sc_lane[(long)g * 16];
+        if (HAS_ZP) zpv[buf] = zp_lane[(long)g * 16];
+    };
+    if (IS_GU && st == 0 && lane == 0) p.arrive_next[e * EM2_STRIDE] = 0u;
+    FH_TL2(0);
+    int ids[16];
+    const int P = p.P, chunks = (P + 63) >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; i++) ids[i] = (i < chunks && i * 64 + lane < P) ? p.pair_expert_ids[i * 64 + lane] : -1;
+    issue_w(0, 0);
+    if (!IS_GU) issue_w(1, 1);         // (down: G ≥ 2, checked by the launcher) both ring slots are on their way before the wait
+    __builtin_amdgcn_sched_barrier(0);
+    int n_e = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (i < chunks) {
+            const bool mine = ids[i] == e;
+            const unsigned long long bal = __ballot(mine);
+            if (mine) s_rows[n_e + __popcll(bal & ((1ull << lane) - 1ull))] = i * 64 + lane;
+            n_e += __popcll(bal);
+        }
+    }
+    FH_TL2(1);
+    if (n_e == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // (one wave per workgroup: its own LDS writes, in order)
+    __builtin_amdgcn_wave_barrier();
+    float4v acc[1][4];
+    auto consume = [&](int buf) {
+        const unsigned long long sb = ((unsigned long long)scv[buf].y << 32) | scv[buf].x;
+        const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[buf].y << 32) | zpv[buf].x) : 0ull;
+        w4_consume_group<1, 4, HAS_ZP>(wq[buf], sb, zb, 0, af[buf], acc);
+    };
+#define FH_PIN() __builtin_amdgcn_sched_barrier(0)
+    if constexpr (IS_GU) {
+        for (int j = 0; j * 16 < n_e; j++) {
+            const int id = j * 16 + b < n_e ? s_rows[j * 16 + b] : P;
+            const __half* xrow = p.x + (long)(id < P ? id / p.top_k : 0) * p.K + 8 * a;
+            auto issue_a = [&](int buf, int g) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) af[buf][0][s] = *reinterpret_cast<const half8*>(xrow + g * 128 + 32 * s);
+            };
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[0][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (j > 0) issue_w(0, 0);                    // further passes re-stream the expert (L2)
+            issue_a(0, 0);
+            FH_PIN();
+            int g = 0;
+            for (; g + 2 <= G - 1; g += 2) {
+                issue_w(1, g + 1); issue_a(1, g + 1);
+                FH_PIN();
+                consume(0);
+                FH_PIN();
+                issue_w(0, g + 2); issue_a(0, g + 2);
+                FH_PIN();
+                consume(1);
+                FH_PIN();
+            }
+            if (g + 1 < G) {
+                issue_w(1, g + 1); issue_a(1, g + 1);
+                FH_PIN();
+                consume(0);
+                consume(1);
+            } else {
+                consume(0);
+            }
+            // silu(gate)·up → the 16 × 32 output block in LDS → one 16-byte write-through store per lane (row lane/4, 8 columns)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int jj = 0; jj < 2; jj++) {
+                    const float gt = acc[0][jj][r], up = acc[0][2 + jj][r];
+                    s_out[(4 * a + r) * 32 + jj * 16 + b] = (_Float16)((gt / (1.0f + __expf(-gt))) * up);
+                }
+            __builtin_amdgcn_wave_barrier();
+            {
+                const int row = lane >> 2, c8 = (lane & 3) * 8;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&s_out[row * 32 + c8]);
+                const int rid = j * 16 + row < n_e ? s_rows[j * 16 + row] : P;
+                const int col = st * 32 + c8;
+                if (rid < P && col + 7 < p.I) {
+                    const __amdgpu_buffer_rsrc_t hw = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, 0x7fffffff, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, hw, (rid * p.I + col) * 2, 0, 16);      // aux 16 = sc1
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // every store of this wave has left before the expert's counter moves
+        FH_TL2(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.arrive + e * EM2_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FH_TL2(3);
+    } else {
+        // down: wait for the expert's gate_up tiles (bounded: ≈ 20 ms of the 100 MHz wall clock)
+        {
+            const unsigned need = (unsigned)p.gu_n64;
+            const unsigned long long t0 = wall_clock64();
+            unsigned spins = 0;
+            for (;;) {
+                unsigned c = lane == 0 ? __hip_atomic_load(p.arrive + e * EM2_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= need) break;
+                // the expert's tiles arrive over ≈ 15 µs: long naps (≈ 3 µs) while most are missing, short ones for the last few
+                if (c + 4 < need) __builtin_amdgcn_s_sleep(127);
+                else __builtin_amdgcn_s_sleep(24);
+                if ((++spins & 63u) == 0u && wall_clock64() - t0 > 2000000ull) {
+                    if (lane == 0) __hip_atomic_fetch_add(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // no instruction: keeps the loads below behind the poll
+        }
+        FH_TL2(2);
+        const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, P * p.I * 2, 0x00020000);
+        for (int j = 0; j * 16 < n_e; j++) {
+            const int id = j * 16 + b < n_e ? s_rows[j * 16 + b] : P;
+            // (a lane without a row reads past the buffer's end: zeros, and no memory request — every byte read here comes from
+            // the memory side, 16 lanes of row 0 per wave would be most of the launch's activation traffic)
+            const int hoff = id < P ? (id * p.I + 8 * a) * 2 : 0x7ffffff0 - 4096;      // bytes; P·I·2 < 2 GiB
+            auto issue_a = [&](int buf, int g) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, hoff + (g * 128 + 32 * s) * 2, 0, 16);   // aux 16 = sc1
+                    af[buf][0][s] = __builtin_bit_cast(half8, v);
+                }
+            };
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) acc[0][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+            if (j > 0) { issue_w(0, 0); issue_w(1, 1); }
+            issue_a(0, 0); issue_a(1, 1);
+            FH_PIN();
+            int g = 0;
+            for (; g + 3 < G; g += 2) {
+                consume(0);
+                FH_PIN();
+                issue_w(0, g + 2); issue_a(0, g + 2);
+                FH_PIN();
+                consume(1);
+                FH_PIN();
+                issue_w(1, g + 3); issue_a(1, g + 3);
+                FH_PIN();
+            }
+            consume(0);
+            if (g + 2 < G) {
+                FH_PIN();
+                issue_w(0, g + 2); issue_a(0, g + 2);
+                FH_PIN();
+                consume(1);
+                consume(0);
+            } else {
+                consume(1);
+            }
+            // the 16 × 64 output block through LDS → two 16-byte stores per lane (rows lane/8 and 8 + lane/8)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) s_out[(4 * a + r) * 64 + nt * 16 + b] = (_Float16)acc[0][nt][r];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                const int row = hh * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(&s_out[row * 64 + c8]);
+                const int rid = j * 16 + row < n_e ? s_rows[j * 16 + row] : P;
+                const int col = st * 64 + c8;
+                if (rid < P && col + 7 < p.H) *reinterpret_cast<u32x4*>(p.out + (long)rid * p.H + col) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#ifdef FERRUM_HIP_EXPERIMENTS
+        if (p.tl) { __builtin_amdgcn_s_waitcnt(0); FH_TL2(3); }
+#endif
+    }
+#undef FH_PIN
+}
+
+// (three waves per SIMD are what keeps all gate_up tiles resident: without the attribute the two inlined roles take 154 + 36
+// registers — two waves per SIMD; with it 168, and one 8-byte spill in the prologue, outside every loop)
+template <bool HAS_ZP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void w4_gemm_moe_em2_kernel(W4Em2Args p) {
+    __shared__ int s_rows[1024];
+    __shared__ __attribute__((aligned(16))) _Float16 s_out[16 * 64];     // the tile's output rows, for 16-byte stores
+    const int n_gu = p.gu_n64 * p.E;
+    if ((int)blockIdx.x < n_gu) w4_em2_role<HAS_ZP, true>(p, blockIdx.x, s_rows, s_out);
+    else w4_em2_role<HAS_ZP, false>(p, blockIdx.x - n_gu, s_rows, s_out);
 }
 
 // Sum S fp32 slabs in fixed order → fp16 [M, N] (optionally gathering padded MoE rows).
@@ -2194,6 +2438,39 @@ int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, co
         else hipLaunchKernelGGL((w4_gemm_moe_em_kernel<false, 1>), grid, dim3(64), 0, stream, a);
     }
     FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// gate_up (+ silu·mul) and down of a decode batch as ONE launch (w4_gemm_moe_em2_kernel).  `arrive` must be zero on entry;
+// the launch zeroes `arrive_next` (the caller alternates two counter arrays).  *took = 0 when the shapes do not fit the
+// merged form (the caller then runs the two expert-major launches).
+int w4_gemm_moe_expert_major_pair(const W4Device& gu, const W4Device& dn, const __half* x, __half* h, __half* out,
+                                  const int32_t* pair_expert_ids, int num_experts, int num_valid_pairs, int top_k,
+                                  unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream) {
+    *took = 0;
+    if (num_valid_pairs <= 0) return 0;
+    const bool zp = gu.zp != nullptr;
+    if (zp != (dn.zp != nullptr) || dn.G < 2 || !gu.fused_gate_up || gu.n / 2 != dn.k || (gu.n / 2) % 8 != 0 || dn.n % 8 != 0 ||
+        num_valid_pairs > 1024 || num_experts > 65535 || (long)num_valid_pairs * (gu.n / 2) * 2 >= (1L << 31) || !arrive || !arrive_next ||
+        !timeout)
+        return 0;
+    W4Em2Args a{};
+    a.gu_qw = gu.qw; a.gu_sc = gu.sc; a.gu_zp = gu.zp; a.gu_G = gu.G; a.gu_n64 = gu.n64;
+    a.gu_stride_qw = (long)gu.n64 * gu.G * 4 * 64 * 4; a.gu_stride_sc = (long)gu.n64 * gu.G * 16 * 4;
+    a.dn_qw = dn.qw; a.dn_sc = dn.sc; a.dn_zp = dn.zp; a.dn_G = dn.G; a.dn_n64 = dn.n64;
+    a.dn_stride_qw = (long)dn.n64 * dn.G * 4 * 64 * 4; a.dn_stride_sc = (long)dn.n64 * dn.G * 16 * 4;
+    a.x = x; a.h = h; a.out = out; a.pair_expert_ids = pair_expert_ids;
+    a.P = num_valid_pairs; a.top_k = top_k; a.E = num_experts; a.K = gu.k; a.I = gu.n / 2; a.H = dn.n;
+    a.arrive = arrive; a.arrive_next = arrive_next; a.timeout = timeout;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    a.tl = g_timeline;
+#endif
+    const dim3 grid((unsigned)((gu.n64 + dn.n64) * num_experts), 1, 1);
+    form_hit(FORM_MOE_EXPERT_MAJOR_PAIR);
+    if (zp) hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<true>), grid, dim3(64), 0, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<false>), grid, dim3(64), 0, stream, a);
+    FH_CHECK_LAUNCH();
+    *took = 1;
     return 0;
 }
 

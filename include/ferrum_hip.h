@@ -151,6 +151,20 @@ int ferrum_hip_moe_gemm_phase_expert_major_f16(const FerrumHipGptq* stack, const
                                                const int32_t* expert_ids_per_pair, void* output, int prob_m,
                                                int num_experts, int top_k, int fused_silu_mul, void* stream);
 
+/* gate_up (+ silu·mul) AND down of a decode batch in ONE expert-major launch (MarlinExpertStack::gemm_phase_vllm twice,
+ * marlin_expert_stack.rs:86; layer order qwen3_moe_forward_unified_layer.rs:300-420): the down tiles of an expert wait inside
+ * the launch for that expert's gate_up tiles, with their first weights already requested.  gate_up_stack must have been loaded
+ * with fuse_gate_up; act_out [prob_m, N_gate_up/2] receives the gated activations (the hand-off buffer), output [prob_m, N_down]
+ * the expert outputs — the same bits the two ferrum_hip_moe_gemm_phase_expert_major_f16 calls produce.  Shapes the merged form
+ * does not take (mixed symmetric / asymmetric stacks, K_down < 256, widths not multiples of 8) → FERRUM_HIP_UNSUPPORTED. */
+int ferrum_hip_moe_gemm_phase_expert_major_pair_f16(FerrumHipGptq* gate_up_stack, const FerrumHipGptq* down_stack, const void* input,
+                                                    const int32_t* expert_ids_per_pair, void* act_out, void* output, int prob_m,
+                                                    int num_experts, int top_k, void* stream);
+
+/* Number of in-launch waits of the stack's merged launches that gave up so far (0 = every hand-off completed; a non-zero
+ * count means the outputs of the affected call are invalid — the waits are bounded so that a missing producer never hangs). */
+int ferrum_hip_moe_pair_status(const FerrumHipGptq* gate_up_stack, unsigned* timeouts);
+
 /* Sandwich-norm residual update on an fp32 residual stream (Gemma 3): `rms_norm_activation_add_to_f32` +
  * `rms_norm_f32_to_activation` of the reference's device path (llama_family.rs:3381-3421) in one launch:
  * residual_f32 += rms_norm(branch, w_branch);  norm_out = f16(rms_norm(residual_f32, w_next))  (w_next NULL → skipped). */

@@ -567,7 +567,7 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
             cur[i] = par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i], gap())
         fed.append(cur.copy())
     # decode at c = 32, kv ≈ 260: fused rope + attention with 8 waves, and the 17–32-row chains
-    forms.require("attn_fused_qkv_wide", *(("route_split", "moe_expert_major") if moe else ("dense_slab_chain", "w4_slabs_lds")))
+    forms.require("attn_fused_qkv_wide", *(("route_split", "moe_expert_major_pair") if moe else ("dense_slab_chain", "w4_slabs_lds")))
     O.set_threads(1)
     rep = par.finish(max_mismatches=1, max_route_ties=1 if moe else 0)   # 27 followed rows: exact ids, at most one excused row
     for oc, i in enumerate(followed[:2]):
@@ -1060,7 +1060,7 @@ def test_expert_parallel_qwen3_30b_dims(pkg, forms):
 
     forms.reset()
     res = _run_ranks(ranks, drive)
-    forms.require("tp_allreduce_loopback", "moe_expert_major", "route_split")
+    forms.require("tp_allreduce_loopback", "moe_expert_major_pair", "route_split")
     flips = _tp_vs_single(tm, full, {"ranks": res, "ref": ref}, c, steps, "qwen3-ep4")
     assert flips <= 2, flips                                     # 128 sampled rows
     del ranks

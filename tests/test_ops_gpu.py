@@ -859,7 +859,7 @@ def test_moe_align_block_size_bit_exact(env, tokens, ne, k):
 
 @pytest.mark.parametrize("tokens,E,K,H,I", [(1, 8, 2, 256, 128), (9, 8, 2, 256, 128), (32, 16, 4, 512, 256), (64, 8, 2, 256, 128),
                                             (32, 128, 8, 2048, 768), (96, 128, 8, 2048, 768)])   # Qwen3-30B-A3B expert dims
-def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
+def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I, forms):
     # whole expert MLP path vs moe_forward_cpu (dispatch.rs:2208-2288), plain and fused-silu stacks
     pkg, B, ctx, O, torch = env
     rng = np.random.default_rng(tokens * E + H)
@@ -935,6 +935,18 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I):
         down_stack.gemm_phase_expert_major(ctx, act, ids_d, down3, P, E, 1)
         ctx.sync()
         assert torch.equal(down, down3)
+        if fused and P <= 1024 and I >= 256:
+            # gate_up → down as ONE launch (down tiles wait in the launch for their expert's gate_up tiles): the same bits, on
+            # poisoned output buffers, three times over (the counters are re-armed per call)
+            forms.reset()
+            for rep in range(3):
+                act4 = torch.full((P, I), float("nan"), dtype=torch.float16, device="cuda")
+                down4 = torch.full((P, H), float("nan"), dtype=torch.float16, device="cuda")
+                stack.gemm_phase_expert_major_pair(ctx, down_stack, xd, ids_d, act4, down4, P, E, K)
+                ctx.sync()
+                assert stack.pair_timeouts(ctx) == 0
+                assert torch.equal(act, act4) and torch.equal(down, down4), rep
+            forms.require("moe_expert_major_pair")
         if fused:
             # align computed inside the GEMM from the raw expert ids: bit-identical outputs
             act2 = torch.zeros(P, I, dtype=torch.float16, device="cuda")
