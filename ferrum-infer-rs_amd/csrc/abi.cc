@@ -40,6 +40,7 @@ void reload_knobs() {
     k.attn_resident_min_wgs = env_int("FERRUM_HIP_ATTN_RESIDENT_MIN_WGS", 128);
     k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 16);
     k.moe_em2 = env_int("FERRUM_HIP_MOE_EM2", 1);
+    k.decode_chain = env_int("FERRUM_HIP_DECODE_CHAIN", 1);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
@@ -69,7 +70,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk", "gather_columns",
-    "perm_producer", "moe_expert_major_pair"};
+    "perm_producer", "moe_expert_major_pair", "decode_chain"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 

@@ -207,6 +207,34 @@ int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residu
                                        int Q, RouteCand* cand, float* stats, float* logits_out, int tokens, int H,
                                        hipStream_t s);
 
+// ── the attention half of a MoE decode layer as one launch (chain.hip) ───────────────────────────────────────────────
+// [combine + add + norm of the previous layer's tail] → q|k|v → QK-norm / RoPE / KV write / attention → o_proj →
+// add + norm + router + top-k, as roles of one grid with in-launch hand-offs.  Buffers as the stand-alone kernels use them.
+struct DecodeChainDesc {
+    int T = 0, H = 0, nq = 0, nkv = 0, head_dim = 0;
+    bool has_a = false;          // the previous layer's tail runs as the first role (else norm1 / res_a come from an earlier launch)
+    int top_k = 0;               // role A: expert rows per token
+    const __half* down = nullptr; const float* comb_w = nullptr; const __half* res_in = nullptr; const __half* ln_in = nullptr;
+    float eps = 0.f;
+    __half* res_a = nullptr;     // residual after the tail (role A's output, role B's input)
+    __half* norm1 = nullptr;     // [T, H] input rows of the q|k|v projection
+    const W4Device* qkv = nullptr; __half* qkv_out = nullptr;
+    __half* k_pool = nullptr; __half* v_pool = nullptr; const int32_t* block_tables = nullptr; const uint32_t* kv_lens = nullptr;
+    const __half* q_norm_w = nullptr; const __half* k_norm_w = nullptr; const float* cos_t = nullptr; const float* sin_t = nullptr;
+    int qk_mode = 0, max_blocks = 0, sliding_window = 0;
+    __half* attn_out = nullptr;
+    const W4Device* o = nullptr; __half* o_out = nullptr;
+    __half* res_b_out = nullptr; const __half* post_ln = nullptr; __half* norm2 = nullptr; const __half* router_w = nullptr;
+    int E = 0, r_top_k = 0, Q = 0, norm_topk = 0;
+    RouteCand* cand = nullptr; float* stats = nullptr; unsigned* route_arrive = nullptr; int32_t* ids = nullptr; float* weights = nullptr;
+    unsigned* cnt = nullptr;       // decode_chain_counter_words() words, zero on entry
+    unsigned* cnt_next = nullptr;  // the other half of the double buffer: zeroed by this launch
+    unsigned* timeout = nullptr;   // host-visible word, bumped by a bounded wait that gave up
+};
+int decode_chain_counter_words();
+bool decode_chain_supports(const DecodeChainDesc& d);
+int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream);
+
 // ── sampling (sampling.hip) ──────────────────────────────────────────────────
 int argmax_rows_f16_ws(const __half* logits, uint32_t* out_ids, const uint8_t* valid_mask, int mask_len, int m, int n,
                        float* workspace, size_t workspace_bytes, hipStream_t s);

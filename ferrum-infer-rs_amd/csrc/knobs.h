@@ -27,6 +27,7 @@ struct Knobs {
     bool attn_flash32 = false;        // the flash form with 32-key steps (paged_prefill_attn_kernel) for head_dim 128 too
     // INT4 GEMMs (w4_gemm.hip)
     int moe_kw_pairs = 16;
+    int decode_chain = 1;             // MoE decode at ≤ 32 rows: tail + q|k|v + attention + o_proj + route as ONE launch (0 = five launches)
     int moe_em2 = 1;                  // decode: gate_up → down as one expert-major launch (0 = two launches)
     int w4_tile_min_m = 0;
     int w4_tile_wgs = 256;
@@ -89,6 +90,7 @@ enum Form : int {
     FORM_GATHER_COLUMNS,        // act-order input gather as a launch of its own (no producer wrote the permuted row)
     FORM_PERM_PRODUCER,         // act-order: the producing kernel (norm, gated activation via gate_up's column order, decode attention) wrote the permuted row
     FORM_MOE_EXPERT_MAJOR_PAIR, // gate_up → down in one expert-major launch (in-launch hand-off per expert)
+    FORM_DECODE_CHAIN,          // the attention half of a MoE decode layer as one launch (chain.hip)
     FORM_COUNT
 };
 

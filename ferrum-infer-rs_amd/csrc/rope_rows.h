@@ -21,7 +21,9 @@ struct RopeRow {
     int off0, off1;
 };
 
-template <int HD>
+// SC1: the source row was written by another workgroup of THIS launch (write-through stores behind a counter): it is read with
+// L1-bypassing loads (relaxed agent-scope 8-byte loads; head_dim 128 only).
+template <int HD, bool SC1 = false>
 __device__ __forceinline__ RopeRow<HD> rope_row16(const __half* src, const __half* nw, const float* cs, const float* sn,
                                                   int mode, bool have_nw, bool have_rope, float eps, int q16) {
 #pragma clang fp contract(off)
@@ -32,8 +34,17 @@ __device__ __forceinline__ RopeRow<HD> rope_row16(const __half* src, const __hal
     R r;
     r.off0 = m3 ? 2 * base : base;
     r.off1 = m3 ? 2 * base + PPL : base + HALF;
-    const typename R::hv c0 = *reinterpret_cast<const typename R::hv*>(src + r.off0);
-    const typename R::hv c1 = *reinterpret_cast<const typename R::hv*>(src + r.off1);
+    typename R::hv c0, c1;
+    if constexpr (SC1) {
+        static_assert(!SC1 || PPL == 4, "the in-launch hand-off form reads 8-byte pieces");
+        const unsigned long long u0 = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + r.off0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long u1 = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + r.off1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c0 = __builtin_bit_cast(typename R::hv, u0);
+        c1 = __builtin_bit_cast(typename R::hv, u1);
+    } else {
+        c0 = *reinterpret_cast<const typename R::hv*>(src + r.off0);
+        c1 = *reinterpret_cast<const typename R::hv*>(src + r.off1);
+    }
     typename R::hv w0, w1;
     typename R::fv cv, sv;
 #pragma unroll

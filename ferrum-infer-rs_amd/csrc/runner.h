@@ -79,6 +79,8 @@ struct FerrumHipModel {
     float* route_stats = nullptr;         // [T][Q][2]
     unsigned* route_arrive = nullptr;     // [T] arrival counters of the split route kernel (zero between launches)
     unsigned* em2_arrive = nullptr;       // [2][E] per-expert arrival counters of the merged gate_up → down launch (double buffer: each launch zeroes the other half) + [1] give-up count
+    size_t arrive_half_words = 0;         // words per half: pair counters + chain counters
+    int chain_parity = 0;                 // … and of the decode chain launch (chain.hip)
     int em2_parity = 0;                   // which half the next merged launch counts in (enqueue order = stream order)
     bool em2_failed = false;              // a bounded in-launch wait gave up once: the two-launch form from then on
     unsigned* inlaunch_timeouts = nullptr; // pinned host word (device-visible): bumped by any in-launch wait that gave up; read after every host sync

@@ -737,7 +737,9 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         rc |= dev_alloc(&m->route_stats, (size_t)512 * 2);
         // [64] arrival counters of the split route kernel (zeroed here; the kernel re-arms them) + [2][E] per-expert counters of the
         // merged gate_up → down launch + its give-up count; the head kernel of every forward zeroes the route counters and half 0
-        rc |= dev_alloc(&m->route_arrive, (size_t)64 + 2 * (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE + 4);
+        // layout: route [64] | pair half 0 | chain half 0 | pair half 1 | chain half 1
+        m->arrive_half_words = (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE + decode_chain_counter_words();
+        rc |= dev_alloc(&m->route_arrive, (size_t)64 + 2 * m->arrive_half_words + 4);
         if (!rc) m->em2_arrive = m->route_arrive + 64;
         if (!rc) {
             FH_CHECK_HIP(hipHostMalloc((void**)&m->inlaunch_timeouts, 64, hipHostMallocDefault));
@@ -996,8 +998,8 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
     if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts) {
         if (knobs().moe_em2 && m->em2_arrive && !m->em2_failed) {
             // one launch: down tiles wait for their expert's gate_up tiles inside it (w4_gemm_moe_em2_kernel)
-            unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * E * MOE_PAIR_COUNTER_STRIDE;
-            unsigned* nxt = m->em2_arrive + (size_t)(m->em2_parity ^ 1) * E * MOE_PAIR_COUNTER_STRIDE;
+            unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * m->arrive_half_words;
+            unsigned* nxt = m->em2_arrive + (size_t)(m->em2_parity ^ 1) * m->arrive_half_words;
             int took = 0;
             if (int rc = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, m->norm_out, m->moe_act, m->moe_down, ids, E, P, K, cur, nxt,
                                                        m->inlaunch_timeouts, &took, s)) return rc;
@@ -1116,19 +1118,84 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     // workgroup owns the row (every norm of the dense layer) or the rows are few (decode attention scatters); the gated
     // activation is permuted by gate_up's column order (pack_gate_up).  Only the prefill o_proj keeps a gather launch.
     RUN(embed_rms_norm_f16(m->embed, tokens, c.embed_scale, m->residual, sandwich ? m->residual_f32 : nullptr, m->layers[0].input_ln,
-                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 + m->ep_E * MOE_PAIR_COUNTER_STRIDE : 0, s, m->layers[0].qkv.perm));
-    m->em2_parity = 0;          // the head kernel zeroed half 0 of the merged MoE launch's counters; every such launch zeroes the other half
+                           c.rms_eps, m->norm_out, T, H, m->route_arrive, m->route_arrive ? 64 + (int)m->arrive_half_words : 0, s, m->layers[0].qkv.perm));
+    m->em2_parity = 0;          // the head kernel zeroed half 0 of the merged launches' counters; every such launch zeroes the other half
+    m->chain_parity = 0;
     bool qkv_in_perm = m->layers[0].qkv.perm != nullptr;      // norm_out holds the row in L.qkv's packed order
     // decode at ≤ 4 rows (MoE models): the tail of layer l — combine + residual add + next input norm — runs as the prologue of
     // layer l+1's q|k|v GEMM instead of as a launch of its own (every dependent launch costs ≈ 4 µs there)
     bool pending_tail = false;
     FusedCombineNorm tail{};
+    bool pending_chain_tail = false;
+    auto chain_desc = [&](int li) {
+        LayerWeights& L = m->layers[li];
+        DecodeChainDesc d;
+        d.T = T; d.H = H; d.nq = nq; d.nkv = nkv; d.head_dim = hd;
+        d.top_k = c.top_k; d.down = m->moe_down; d.comb_w = m->expert_w; d.res_in = m->residual2; d.ln_in = L.input_ln; d.eps = c.rms_eps;
+        d.res_a = m->residual; d.norm1 = m->norm_out;
+        d.qkv = &L.qkv; d.qkv_out = m->qkv_out;
+        d.k_pool = L.k_pool; d.v_pool = L.v_pool; d.block_tables = bt; d.kv_lens = kvl;
+        d.q_norm_w = L.q_norm ? L.q_norm : L.input_ln; d.k_norm_w = L.k_norm ? L.k_norm : L.input_ln;
+        const int pattern = c.sliding_window_pattern;
+        const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
+        d.sliding_window = pattern == 0 ? c.sliding_window : (is_global ? 0 : c.sliding_window);
+        d.cos_t = (!is_global && m->cos_local) ? m->cos_local : m->cos_t;
+        d.sin_t = (!is_global && m->sin_local) ? m->sin_local : m->sin_t;
+        d.qk_mode = qk_mode; d.max_blocks = m->max_blocks_per_seq;
+        d.attn_out = m->attn_out; d.o = &L.o; d.o_out = m->o_out;
+        d.res_b_out = m->residual2; d.post_ln = L.post_ln; d.norm2 = m->norm_out; d.router_w = L.router;
+        d.E = c.num_experts; d.r_top_k = c.top_k; d.norm_topk = c.norm_topk_prob;
+        int Q = m->route_parts;
+        const int tiles = (c.num_experts + 15) / 16;
+        while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
+        d.Q = Q;
+        d.cand = m->route_cand; d.stats = m->route_stats; d.route_arrive = m->route_arrive; d.ids = m->expert_ids; d.weights = m->expert_w;
+        d.timeout = m->inlaunch_timeouts;
+        return d;
+    };
+    auto chain_ok = [&](int li) {
+        if (c.num_experts <= 0 || !knobs().decode_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts) return false;
+        if (!sh.all_single_token || !m->fuse_rope_attn || T > 32 || m->taps_enabled || sandwich) return false;
+        if (c.tp_world > 1 && c.expert_parallel != 2) return false;             // (tensor-parallel attention: an all-reduce sits behind o_proj)
+        if (T * c.top_k > 1024 || c.top_k > 8 || T > 64) return false;
+        return decode_chain_supports(chain_desc(li));
+    };
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
         const __half* next_ln = li + 1 < c.num_layers ? m->layers[li + 1].input_ln : nullptr;
         const int32_t* next_qkv_perm = li + 1 < c.num_layers ? m->layers[li + 1].qkv.perm : nullptr;
         const int32_t* gu_perm = L.gate_up.perm;
+        // MoE decode at ≤ 32 rows: [the previous layer's tail] + q|k|v + attention + o_proj + add/norm/route as ONE launch
+        // (chain.hip), then the merged gate_up → down launch: two launches per layer instead of seven
+        if (chain_ok(li)) {
+            const int E = c.num_experts, K = c.top_k, P = T * K, sorted_max = P + E * 16;
+            const int max_blocks = std::min(sorted_max / 16, P / 16 + std::min(P, E));
+            DecodeChainDesc d = chain_desc(li);
+            d.has_a = pending_chain_tail;
+            d.cnt = m->em2_arrive + (size_t)m->chain_parity * m->arrive_half_words + (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE;
+            d.cnt_next = m->em2_arrive + (size_t)(m->chain_parity ^ 1) * m->arrive_half_words + (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE;
+            RUN(decode_chain_f16(d, s));
+            m->chain_parity ^= 1;
+            pending_chain_tail = false;
+            form_hit(d.Q > 1 ? FORM_ROUTE_SPLIT : FORM_ROUTE_FUSED);
+            if (c.expert_parallel) RUN(moe_remap_expert_ids(m->expert_ids, m->expert_ids_local, P, m->ep_e0, m->ep_E, s));
+            RUN(moe_decode_gemms(m, L, P, max_blocks, s));
+            if (!c.expert_parallel && li + 1 < c.num_layers && chain_ok(li + 1)) {
+                pending_chain_tail = true;          // combine + add + next input norm: the first role of the next layer's launch
+            } else if (!c.expert_parallel) {
+                RUN(moe_combine_add_rms_norm_f16(m->moe_down, m->expert_w, m->residual2, m->residual, next_ln, c.rms_eps, m->norm_out, T, K, H, s,
+                                                 next_qkv_perm));
+                qkv_in_perm = next_ln && next_qkv_perm != nullptr;
+            } else {
+                RUN(moe_combine_local_f16(m->moe_down, m->expert_w, m->expert_ids_local, m->mlp_out, T, K, H, s));
+                RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
+                RUN(moe_combine_add_rms_norm_f16(m->mlp_out, m->ones, m->residual2, m->residual, next_ln, c.rms_eps, m->norm_out, T, 1, H, s,
+                                                 next_qkv_perm));
+                qkv_in_perm = next_ln && next_qkv_perm != nullptr;
+            }
+            continue;
+        }
         if (pending_tail) {
             RUN(w4_gemm_dense(L.qkv, nullptr, m->qkv_out, T, m->workspace, m->workspace_bytes, s, &tail));
             pending_tail = false;

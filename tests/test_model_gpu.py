@@ -533,6 +533,91 @@ def _bench_dims_model(name):
     return _TM_CACHE[name]
 
 
+# ── the one-launch decode chain (chain.hip) + the merged gate_up → down launch across layers ─────────────────────────────
+# Three layers at Qwen3-30B-A3B's dimensions so that every role runs, the tail of a layer included (it is the first role of
+# the NEXT layer's launch): c rows decode for 3 steps; three rows are followed by the oracle (teacher-forced), and the same
+# steps run again with the seven-launch layer (knobs off) and in the hipGraph loop: logits agree, ids are the same.
+_CHAIN_TM = {}
+
+
+def _chain_model():
+    from tests import modelgen
+    if "tm" not in _CHAIN_TM:
+        kw = dict(BENCH_DIMS["qwen3-30b-a3b"])
+        _CHAIN_TM["tm"] = modelgen.TinyModel(kw.pop("moe"), layers=3, vocab=2048, seed=47, max_seq_len=64, **kw)
+    return _CHAIN_TM["tm"]
+
+
+@pytest.mark.parametrize("c", [32, 20, 9, 1])
+def test_decode_chain_and_merged_moe_launch_across_layers(pkg, c, forms, knobs):
+    from tests import modelgen
+    from oracle import oracle as O
+    tm = _chain_model()
+    plen, steps = 5, 3
+    followed = sorted({0, c // 2, c - 1})
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    rng = np.random.default_rng(48)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+
+    def drive(chain, check):
+        knobs.set(DECODE_CHAIN=chain, MOE_EM2=chain)
+        hm = tm.hip_model(pkg, kv_num_blocks=c * 2 + 4, max_seqs=c, max_tokens=max(c * plen, 64))
+        toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        cur = np.array(toks, np.uint32)
+        if check:
+            for oc, i in enumerate(followed):
+                cur[i] = check(f"prefill/{i}", om.forward(oc, prompts[i], 0), lg[i], toks[i])
+        else:
+            cur = drive.fed[0].copy()
+        fed, out = [cur.copy()], []
+        forms.reset()
+        for s in range(steps):
+            toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+            out.append((np.array(toks, np.uint32), lg.copy()))
+            cur = np.array(toks, np.uint32)
+            if check:
+                for oc, i in enumerate(followed):
+                    cur[i] = check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i])
+            else:
+                cur = drive.fed[s + 1].copy()
+            fed.append(cur.copy())
+        hits = forms.hits()
+        if chain and not check:
+            # (second instance, eager continuation) four more single forwards, fed the graph loop's ids
+            for s in range(4):
+                toks, _ = hm.unified_forward([(i, [int(cur[i])], plen + steps + s, True) for i in range(c)], greedy=True)
+                assert np.array_equal(np.array(toks, np.uint32), drive.graph_ids[s]), (s, np.nonzero(np.array(toks, np.uint32) != drive.graph_ids[s])[0])
+                cur = drive.graph_ids[s]
+        elif chain:
+            drive.graph_ids = hm.decode_steps(list(range(c)), fed[-1], 4)      # hipGraph loop from this state
+        return out, fed, hits, hm
+
+    par = modelgen.Parity(f"decode-chain-c{c}", cos_min=0.999, rel_max=5e-2)
+    gap = lambda: om.last_route_gap_rel()
+    out1, fed, hits, hm1 = drive(1, lambda tag, ref, lg, tok: par.check(tag, ref, lg, tok, gap()))
+    drive.fed = fed
+    assert hits.get("decode_chain", 0) == 3 * steps, hits             # one chain launch per layer and step
+    if c * 8 >= 2 * 128: assert hits.get("moe_expert_major_pair", 0) == 3 * steps, hits
+    assert "w4_wgsplit" not in hits and "attn_fused_qkv_wide" not in hits and "attn_fused_qkv_narrow" not in hits, hits
+    O.set_threads(1)
+    par.finish(max_mismatches=1, max_route_ties=1)
+    # graph ≡ eager for the merged launches: a second instance repeats the steps (teacher-forced on the same ids) and then
+    # continues with single forwards on the ids the hipGraph loop of the first instance sampled — identical ids
+    del hm1
+    _, _, _, hm1 = drive(1, None)
+    # the seven-launch layer on the same tokens: logits within fp16 summation-order noise, ids equal unless a near-tie
+    del hm1
+    out0, _, hits0, hm0 = drive(0, None)
+    assert "decode_chain" not in hits0 and "moe_expert_major_pair" not in hits0, hits0
+    for s, ((t1, l1), (t0, l0)) in enumerate(zip(out1, out0)):
+        err = np.abs(l1 - l0).max(axis=1)
+        assert float(err.max()) < 0.02 * float(np.abs(l0).max()), (s, float(err.max()))
+        srt = np.sort(l0, axis=1)
+        for r in np.nonzero(t1 != t0)[0]:
+            assert srt[r, -1] - srt[r, -2] <= 2 * err[r] + 1e-6, (s, int(r))
+
+
 @pytest.mark.parametrize("name", sorted(BENCH_DIMS))
 def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, forms):
     from tests import modelgen
@@ -567,7 +652,7 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
             cur[i] = par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i], gap())
         fed.append(cur.copy())
     # decode at c = 32, kv ≈ 260: fused rope + attention with 8 waves, and the 17–32-row chains
-    forms.require("attn_fused_qkv_wide", *(("route_split", "moe_expert_major_pair") if moe else ("dense_slab_chain", "w4_slabs_lds")))
+    forms.require(*(("decode_chain", "route_split", "moe_expert_major_pair") if moe else ("attn_fused_qkv_wide", "dense_slab_chain", "w4_slabs_lds")))
     O.set_threads(1)
     rep = par.finish(max_mismatches=1, max_route_ties=1 if moe else 0)   # 27 followed rows: exact ids, at most one excused row
     for oc, i in enumerate(followed[:2]):
