@@ -432,7 +432,10 @@ def main():
         barrier()
         return t_local, PL + warm + steps
 
+    _last_stage = ["start"]
+
     def stage(name):                                            # FERRUM_BENCH_STAGES=1: progress on stderr (fault triage)
+        _last_stage[0] = name
         if os.environ.get("FERRUM_BENCH_STAGES"):
             torch.cuda.synchronize()
             print(f"[bench] {name}", file=sys.stderr, flush=True)
@@ -510,15 +513,30 @@ def main():
                 b = cfg["vocab"] * cfg["hidden"] * 2 + c * cfg["vocab"] * 4
                 entry.update(bytes=b, gbs=round(b / us / 1e3, 1))
             kernels[name] = entry
-        dom = kernels[mlp_names[0]]
-        traffic = None                                          # HBM bytes per launch from the committed PMC passes
-        tp = os.path.join(ROOT, "profiles", "pmc_traffic_gate_up.json")
+        dom, dom_name = kernels[mlp_names[0]], ("w4_gemm_moe_em_kernel<false,2> (MoE gate_up INT4 grouped GEMM + silu*mul, expert-major)" if moe
+                                                else "w4_gemm dense gate_up INT4 GEMM")
+        traffic_file = "pmc_traffic_gate_up.json"
+        if moe:
+            # what the decode step launches since round 3: gate_up (+ silu·mul) AND down as one expert-major launch — the
+            # dominant kernel of the step (≈ 55 % of it); its algorithmic bytes are the two GEMMs' (the gated activations are
+            # written and read through memory inside the launch, counted on both sides)
+            try:
+                stage("time_kernel moe_pair")
+                us, blocks = model.time_kernel("moe_pair", c, kv_end, reps=3)
+                b = moe_gemm_bytes(cfg, blocks, c, "moe_gate_up") + moe_gemm_bytes(cfg, blocks, c, "moe_down")
+                kernels["moe_pair"] = {"avg_us": round(us, 2), "expert_blocks": blocks, "bytes": b, "gbs": round(b / us / 1e3, 1)}
+                dom, dom_name = kernels["moe_pair"], "w4_gemm_moe_em2_kernel<false> (MoE gate_up + silu*mul -> down INT4 grouped GEMMs, one expert-major launch)"
+                traffic_file = "pmc_traffic_moe_pair.json"
+            except Exception as e:       # batches that do not take the merged form (c < 32): the two-launch kernels above stand
+                kernels["moe_pair"] = {"unavailable": str(e)[:120]}
+        traffic, traffic_src = None, None                       # HBM bytes per launch from the committed PMC passes
+        tp = os.path.join(ROOT, "profiles", traffic_file)
         if moe and c == 32 and os.path.exists(tp):
             traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
-        extra["roofline"] = {"bound": "hbm", "kernel": "w4_gemm_moe_em_kernel<false,2> (MoE gate_up INT4 grouped GEMM + silu*mul, expert-major)" if moe
-                             else "w4_gemm dense gate_up INT4 GEMM",
+            traffic_src = f"committed profile profiles/{traffic_file} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        extra["roofline"] = {"bound": "hbm", "kernel": dom_name,
                              "achieved": dom["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                             "frac": round(dom["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                              "bytes_per_launch": dom["bytes"], "avg_launch_us": dom["avg_us"]}
         extra["kernels"] = kernels
         # whole-step roofline: weights touched + KV + lm_head per step
@@ -548,7 +566,7 @@ def main():
                                                    "tflops": round(tf2, 1), "peak_tflops": MFMA_PEAK_TFLOPS, "frac": round(tf2 / MFMA_PEAK_TFLOPS, 4)}
             mp = os.path.join(ROOT, "profiles", "pmc_mfma_busy.json")
             if os.path.exists(mp):
-                ns["int4_gemm_prefill"]["mfma_busy_pmc"] = json.load(open(mp))
+                ns["int4_gemm_prefill"]["mfma_busy_pmc"] = dict(json.load(open(mp)), source_kind="committed profile (profiles/pmc_mfma_busy.json), not measured by this run")
         stage("north-star: attention decode at long context")
         ns["attention_decode_long_ctx"] = attention_long_ctx(pkg, cfg, c, 4096)
         stage("north-star: attention prefill, long prompt")
@@ -661,9 +679,12 @@ def main():
         import threading
 
         def bail_out():
-            extra.setdefault("tp_scaling", {"error": f"the tensor-parallel extra did not finish within {TP_EXTRA_DEADLINE_S} s"})
+            # the line still goes out (the headline was measured before the extras), but the process leaves with a non-zero
+            # code: a hung collective must show in the run record, not only as a string inside the JSON
+            extra.setdefault("tp_scaling", {"error": f"the tensor-parallel extra did not finish within {TP_EXTRA_DEADLINE_S} s",
+                                            "stage": _last_stage[0]})
             emit()
-            os._exit(0)
+            os._exit(3)
         watchdog = threading.Timer(TP_EXTRA_DEADLINE_S, bail_out) if world > 1 else None
         if watchdog:
             watchdog.daemon = True

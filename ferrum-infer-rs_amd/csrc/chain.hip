@@ -49,6 +49,8 @@ constexpr int CH_ATTN_SLOT = 24, CH_ATTN_SH = 8, CH_ATTN_R = 4;         // atten
 constexpr int CH_QKV_SLOT = 56, CH_QKV_R = 4;                           // q|k|v → attention, one group per kv head: (G + 2)·row blocks arrivals, T pollers
 constexpr int CH_MAX_KVH = 16;
 constexpr int CH_SLOTS = CH_QKV_SLOT + CH_QKV_R * CH_MAX_KVH;
+constexpr int CH_GRAN = 10;              // granules per (token, router part): 8 candidates + max + Σexp
+constexpr int CH_GRAN_WORDS = 32 * 4 * CH_GRAN * 2;      // T ≤ 32 tokens × Q ≤ 4 parts, 8-byte granules
 constexpr int CH_SMEM = 8 * 16 * (128 + 4) * 4 + 2 * 8 * 16 * 4 + 16 * 128 * 2 + 2 * 128 * 2;     // the attention role's arena: 73,216 B
 
 constexpr int CH_QKV_NST = 2, CH_O_NST = 1;     // 64-column supertiles per workgroup: one head (128 columns) for q|k|v, 64 columns for o_proj; 16 rows each
@@ -664,31 +666,60 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
     __syncthreads();
     CH_TL(2);
     if (wave != 0) return;
-    unsigned long long* cand_g = reinterpret_cast<unsigned long long*>(p.cand) + (row * Q + q) * 8;
-    unsigned long long* stats_g = reinterpret_cast<unsigned long long*>(p.stats) + (row * Q + q);
-    if (lane < 8) __hip_atomic_store(cand_g + lane, cand_s[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lane == 8)
-        __hip_atomic_store(stats_g, ((unsigned long long)__float_as_uint(red[0] + red[1]) << 32) | __float_as_uint(mx),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned old = 0;
-    if (lane == 0) old = __hip_atomic_fetch_add(p.route_arrive + row, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    old = __builtin_amdgcn_readfirstlane(old);
-    if (old != (unsigned)(Q - 1)) return;
-    // (every candidate byte was stored write-through and drained before its part's ticket, and is read with sc1 loads below:
-    // the valid form without an agent acquire — which costs ≈ 1.5 µs on the layer's critical path here)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) __hip_atomic_store(p.route_arrive + row, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The Q parts of a token meet without a counter: every part but the first publishes its 8 candidates and its two softmax
+    // statistics as TAGGED 8-byte granules (one write-through store each — the data is the flag, Guideline 16 R2), and part 0
+    // sweeps the (Q − 1)·10 granules of its token until every tag is there, merges, and clears them for the launch after the
+    // next (the granules live in the double-buffered counter block: zero on entry).  One store → load latency instead of
+    // store → drain → returning ticket → loads: 3.4–3.8 µs → ≈ 1.5 µs on the layer's critical path.
+    //   candidate granule: [tag 1 : 16][expert id : 16][logit bits : 32]      statistic granule: [tag 1 : 32][value bits : 32]
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(p.cnt + CH_SLOTS * CH_STRIDE) + (row * Q) * CH_GRAN;
+    if (q != 0) {
+        unsigned long long g = 0;
+        if (lane < 8) g = (1ull << 48) | ((cand_s[lane] >> 32 & 0xffffull) << 32) | (cand_s[lane] & 0xffffffffull);
+        else if (lane == 8) g = (1ull << 32) | __float_as_uint(mx);
+        else if (lane == 9) g = (1ull << 32) | __float_as_uint(red[0] + red[1]);
+        if (lane < CH_GRAN) __hip_atomic_store(gran + q * CH_GRAN + lane, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    unsigned long long* gr = cand_s + 8;                               // LDS [Q][CH_GRAN] behind this part's own list
+    {
+        const int n = (Q - 1) * CH_GRAN;
+        unsigned long long* src = gran + CH_GRAN + lane;
+        const bool is_stat = (lane % CH_GRAN) >= 8;
+        unsigned long long g = 0;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            if (lane < n) g = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool have = lane >= n || (is_stat ? (g >> 32) == 1ull : (g >> 48) == 1ull);
+            if (__ballot(!have) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u && wall_clock64() - t0 > 2000000ull) {
+                if (lane == 0) __hip_atomic_fetch_add(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        if (lane < n) {
+            gr[CH_GRAN + lane] = g;
+            __hip_atomic_store(src, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (also cleared with the half by a later launch)
+        }
+        if (lane < 8) gr[lane] = (1ull << 48) | ((cand_s[lane] >> 32 & 0xffffull) << 32) | (cand_s[lane] & 0xffffffffull);
+        else if (lane == 8) gr[8] = (1ull << 32) | __float_as_uint(mx);
+        else if (lane == 9) gr[9] = (1ull << 32) | __float_as_uint(red[0] + red[1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // one wave: its own LDS writes, in order
+        __builtin_amdgcn_wave_barrier();
+    }
     const int ncand = Q * 8;
     unsigned long long c = (0x7fffffffull << 32) | __float_as_uint(-INFINITY);
-    if (lane < ncand)
-        c = __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.cand) + row * Q * 8 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < ncand) {
+        const unsigned long long g = gr[(lane >> 3) * CH_GRAN + (lane & 7)];
+        const unsigned id16 = (unsigned)(g >> 32) & 0xffffu;
+        c = ((unsigned long long)(id16 == 0xffffu ? 0x7fffffffu : id16) << 32) | (g & 0xffffffffull);
+    }
     float pmx = -INFINITY, psum = 0.f;
     if (lane < Q) {
-        const unsigned long long st = __hip_atomic_load(reinterpret_cast<unsigned long long*>(p.stats) + row * Q + lane,
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pmx = __uint_as_float((unsigned)st);
-        psum = __uint_as_float((unsigned)(st >> 32));
+        pmx = __uint_as_float((unsigned)gr[lane * CH_GRAN + 8]);
+        psum = __uint_as_float((unsigned)gr[lane * CH_GRAN + 9]);
     }
     const float gmax = wave_reduce_max(pmx);
     const float gsum = wave_reduce_sum(lane < Q ? psum * expf(pmx - gmax) : 0.f);
@@ -718,7 +749,10 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
     const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / (64 * CH_QKV_NST) * RH, n_attn = p.T * p.nkv, n_o = p.o.N / (64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
-    if (wg == 0 && threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;       // re-arm the other half
+    if (wg == 0) {                                                    // re-arm the other half: counters and route granules
+        if (threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;
+        for (int i = threadIdx.x; i < p.T * p.Q * CH_GRAN * 2; i += 512) p.cnt_next[CH_SLOTS * CH_STRIDE + i] = 0u;
+    }
     if (wg < n_a) { chain_role_a(p, wg, smem); return; }
     wg -= n_a;
     if (wg < n_qkv) {
@@ -749,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
 extern "C" __attribute__((visibility("default"))) void ferrum_hip_debug_set_chain_timeline(void* p) { g_chain_timeline = (unsigned long long*)p; }
 #endif
 
-int decode_chain_counter_words() { return CH_SLOTS * CH_STRIDE; }
+int decode_chain_counter_words() { return CH_SLOTS * CH_STRIDE + CH_GRAN_WORDS; }
 
 bool decode_chain_supports(const DecodeChainDesc& d) {
     const auto gemm_ok = [](const W4Device& w) {
@@ -761,11 +795,11 @@ bool decode_chain_supports(const DecodeChainDesc& d) {
     if (d.T < 1 || d.T > 32 || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
     if (d.H % 32 != 0 || d.H > 8192 || d.qkv->k != d.H || d.qkv->n != (d.nq + 2 * d.nkv) * 128 || d.o->k != d.nq * 128 || d.o->n != d.H) return false;
     const int tiles = (d.E + 15) / 16;
-    if (d.E <= 0 || d.Q < 1 || d.Q > 8 || tiles % d.Q != 0 || tiles / d.Q > 8 || d.r_top_k < 1 || d.r_top_k > 8) return false;
+    if (d.E <= 0 || d.E > 0xfff0 || d.Q < 1 || d.Q > 4 || tiles % d.Q != 0 || tiles / d.Q > 8 || d.r_top_k < 1 || d.r_top_k > 8) return false;
     if (d.has_a && (d.top_k < 1)) return false;
     // LDS of role B: the row + the part logits
     const int tiles_q = tiles / d.Q, ksplit = tiles_q >= 8 ? 1 : 8 / tiles_q;
-    if ((size_t)d.H * 2 + (size_t)tiles_q * 16 * (ksplit + 1) * 4 + 8 * 4 + 8 * 8 + 16 > (size_t)CH_SMEM) return false;
+    if ((size_t)d.H * 2 + (size_t)tiles_q * 16 * (ksplit + 1) * 4 + 8 * 4 + (8 + 4 * CH_GRAN) * 8 + 16 > (size_t)CH_SMEM) return false;
     return true;
 }
 

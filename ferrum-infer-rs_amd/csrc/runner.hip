@@ -1747,7 +1747,7 @@ int ferrum_hip_model_decode_steps(FerrumHipModel* m, const uint64_t* seq_ids, co
 // on the model's stream.  The launch is repeated over every layer's weights (L distinct weight sets,
 // far larger than the 256 MiB Infinity Cache) using the routing / index state the last forward left
 // in the scratch buffers, `reps` rounds.  which: 0 MoE gate_up (+silu·mul), 1 MoE down,
-// 2 paged decode attention, 3 qkv GEMM, 4 o GEMM, 5 lm_head GEMM.  Returns the mean microseconds per
+// 2 paged decode attention, 3 qkv GEMM, 4 o GEMM, 5 lm_head GEMM, 8 MoE gate_up → down as ONE launch.  Returns the mean microseconds per
 // launch and (for MoE) the number of 16-row expert blocks the routing holds.
 int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int max_kv_len, int reps, float* avg_us,
                                  int* moe_blocks) {
@@ -1761,7 +1761,7 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     int blocks = 0;
     const int P = T * std::max(c.top_k, 1), E = c.num_experts > 0 ? m->ep_E : 0;
     const int32_t* eids = moe_ids(m);
-    if (E > 0 && which < 2) {
+    if (E > 0 && (which < 2 || which == 8)) {
         FH_REQUIRE(P <= 1024, "time_kernel: MoE timing uses the decode (inline-align) path, pairs=%d > 1024", P);
         std::vector<int32_t> ids(P);
         FH_CHECK_HIP(hipMemcpyAsync(ids.data(), eids, (size_t)P * 4, hipMemcpyDeviceToHost, s));
@@ -1786,6 +1786,15 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
         case 1:
             if (em) return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, eids, E, P, 1, 0, s);
             return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
+        case 8: {   // gate_up → down as the step runs them: one merged launch (falls back to an error when the shapes do not take it)
+            unsigned* cur = m->em2_arrive + (size_t)(launches & 1) * m->arrive_half_words;
+            unsigned* nxt = m->em2_arrive + (size_t)((launches & 1) ^ 1) * m->arrive_half_words;
+            int took = 0;
+            if (int r_ = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, m->norm_out, m->moe_act, m->moe_down, eids, E, P, c.top_k,
+                                                       cur, nxt, m->inlaunch_timeouts, &took, s)) return r_;
+            if (!took) { fh::set_error("time_kernel: the merged gate_up → down launch does not take these shapes"); return FERRUM_HIP_UNSUPPORTED; }
+            return 0;
+        }
         case 2: return paged_batched_decode_attention_f16(m->q_out, L.k_pool, L.v_pool, m->attn_out, idx<int32_t>(m, m->il.block_tables),
                                                           idx<uint32_t>(m, m->il.kv_lens), T, max_kv_len, c.num_heads, c.num_kv_heads,
                                                           c.head_dim, KV_BLOCK, m->max_blocks_per_seq, m->workspace, m->workspace_bytes, s);
@@ -1798,11 +1807,17 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
         fh::set_error("time_kernel: which=%d", which);
         return FERRUM_HIP_INVALID;
     };
-    FH_REQUIRE(which >= 2 || E > 0, "time_kernel: MoE kernel on a dense model");
-    FH_REQUIRE(which < 6 || E == 0, "time_kernel: dense MLP kernel on a MoE model");
+    FH_REQUIRE((which >= 2 && which != 8) || E > 0, "time_kernel: MoE kernel on a dense model");
+    FH_REQUIRE(which < 6 || which == 8 || E == 0, "time_kernel: dense MLP kernel on a MoE model");
+    if (which == 8) {
+        FH_REQUIRE(em && knobs().moe_em2 && m->em2_arrive && !m->em2_failed, "time_kernel: the merged gate_up → down launch is not what this batch takes");
+        FH_CHECK_HIP(hipMemsetAsync(m->em2_arrive, 0, 2 * m->arrive_half_words * sizeof(unsigned), s));
+    }
     const bool same_layer = knobs().time_same_layer;   // experiment: weights resident in the Infinity Cache
     // warm-up round (code objects, TLBs), then the timed rounds
-    for (int li = 0; li < c.num_layers && !rc; li++) rc = one(li);
+    for (int li = 0; li < c.num_layers && !rc; li++) { rc = one(li); if (which == 8) launches++; }
+    if (which == 8 && (launches & 1)) { rc = rc ? rc : one(0); launches++; }      // (even count: the counter halves alternate)
+    launches = 0;
     if (rc) return rc;
     FH_CHECK_HIP(hipEventRecord(e0, s));
     for (int r = 0; r < reps && !rc; r++)

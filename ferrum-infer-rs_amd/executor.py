@@ -389,7 +389,7 @@ class HipModel:
 
     def time_kernel(self, which, n_seqs, max_kv_len, reps=3):
         """Mean µs per launch of a hot kernel (HIP events on the model stream) and the MoE block count."""
-        names = {"moe_gate_up": 0, "moe_down": 1, "attention": 2, "qkv": 3, "o": 4, "lm_head": 5, "gate_up": 6, "down": 7}
+        names = {"moe_gate_up": 0, "moe_down": 1, "attention": 2, "qkv": 3, "o": 4, "lm_head": 5, "gate_up": 6, "down": 7, "moe_pair": 8}
         us, blocks = C.c_float(), C.c_int()
         _check(self.lib.ferrum_hip_model_time_kernel(self.h, names[which], n_seqs, max_kv_len, reps, C.byref(us),
                                                      C.byref(blocks)), "time_kernel")
