@@ -3,7 +3,7 @@
 # the two PMC passes for roofline.traffic (FETCH_SIZE / WRITE_SIZE, separate runs, eager launches), and the extra models.
 # Usage (on the GPU box): bash tools/collect_round_profiles.sh r02x
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

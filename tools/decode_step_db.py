@@ -34,7 +34,7 @@ def main():
         for r in seg:
             d = (r[2] - r[1]) / 1e3
             busy += d
-            name = re.sub(r"\(.*", "", r[0]).replace("void ", "").replace("fh::", "").replace("(anonymous namespace)::", "")
+            name = re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", "")).replace("void ", "").replace("fh::", "")
             by.setdefault(f"{name[:78]} g={r[3]}x{r[4]}x{r[5]} wg={r[6]} vgpr={r[7]}+{r[8]}", []).append(d)
         med = sorted(steps_wall)[len(steps_wall) // 2]
         print(f"\n== decode run of {len(run)} steps: {len(seg)} launches per step, late-step wall {wall:.1f} us (median step {med:.1f} us), "
