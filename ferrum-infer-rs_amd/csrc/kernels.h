@@ -245,7 +245,7 @@ struct DecodeAdvance {
     int32_t* step_counter = nullptr; unsigned* ticket = nullptr; int n = 0;
 };
 // *fused = 1 when the advance ran inside the argmax launches (two-stage form), 0 when the caller still has to run it
-int argmax_pairs_f32(const float* logits, const uint32_t* local_ids, void* pairs, int rows, int n_local, int v0, hipStream_t s);
+int argmax_pairs_f32(const float* logits, const uint32_t* local_ids, void* pairs, int rows, int n_local, int v0, const uint8_t* mask, int mask_len, hipStream_t s);
 int argmax_merge_ranks(const void* gathered, uint32_t* out, int rows, int world, const DecodeAdvance* adv, hipStream_t s);
 int apply_repetition_penalties_sparse_f32_shard(float* logits, const uint32_t* row_offsets, const uint32_t* token_ids,
                                                 const float* penalties, int m, int n_local, int v0, hipStream_t s);

@@ -261,6 +261,14 @@ static void drop_graph(FerrumHipModel* m) {
 // Merged launches hand data over between workgroups and bound every wait; a wait that gave up has produced garbage.  Called
 // after every host synchronisation of a forward: the call fails, the captured graph is dropped and the merged forms stay off.
 static int check_inlaunch_waits(FerrumHipModel* m) {
+    // tensor / expert / vocabulary parallel: a one-shot all-reduce or all-gather whose wait for a peer gave up left the rank's
+    // un-reduced partial in the output — ids sampled from it must not be handed back as a success
+    if (const unsigned n = comm_take_timeouts(m->comm)) {
+        drop_graph(m);
+        fh::set_error("%u one-shot collective call(s) gave up waiting for a peer: the results of this call are invalid; the one-shot "
+                      "transport is off from now on (RCCL, where the communicator has a rank)", n);
+        return 3;
+    }
     if (!m->inlaunch_timeouts) return 0;
     const unsigned now = *reinterpret_cast<volatile unsigned*>(m->inlaunch_timeouts);
     if (now == m->inlaunch_timeouts_seen) return 0;
@@ -1484,7 +1492,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             const uint8_t* mask = gopts && gopts->mask ? gopts->mask + std::min(v0, gopts->mask_len) : nullptr;
             const int mask_len = gopts && gopts->mask ? std::max(0, gopts->mask_len - v0) : 0;
             RUN(argmax_rows_f32_ws(m->logits, m->out_tokens, mask, mask_len, sh.num_sampled, Vn, m->workspace, m->workspace_bytes, s));
-            RUN(argmax_pairs_f32(m->logits, m->out_tokens, m->vp_pairs, sh.num_sampled, Vn, v0, s));
+            RUN(argmax_pairs_f32(m->logits, m->out_tokens, m->vp_pairs, sh.num_sampled, Vn, v0, mask, mask_len, s));
             RUN(tp_all_gather(m, m->vp_pairs, m->vp_gathered, (size_t)sh.num_sampled * 8));
             RUN(argmax_merge_ranks(m->vp_gathered, m->out_tokens, sh.num_sampled, c.tp_world, advance, s));
             if (advance && advance_fused) *advance_fused = 1;

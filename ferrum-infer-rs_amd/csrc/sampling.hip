@@ -213,12 +213,18 @@ int argmax_rows_f32(const float* logits, uint32_t* out_ids, const uint8_t* valid
 // pairs[row] = (local winner's logit, GLOBAL id); after the all-gather the global winner is the first maximum over the ranks
 // in rank order — rank r's ids all lie below rank r+1's, so "strictly greater wins" keeps the lowest id among equal logits,
 // exactly the single-GPU tie-break (traits.rs:1547).
+// A rank whose vocabulary slice holds NO valid id (a sparse token mask, or a mask that ends below the slice) must not compete:
+// its local argmax fell back to local id 0, whose raw logit could beat the other ranks' valid maxima.  Such a row publishes
+// (−inf, 0xffffffff); the merge ignores it and falls back to id 0 only when every rank reports none (the single-GPU masked
+// argmax's own fallback, traits.rs:1571-1591).
 __global__ void argmax_pairs_kernel(const float* __restrict__ logits, const uint32_t* __restrict__ local_ids, float2* __restrict__ pairs,
-                                    int rows, int n_local, int v0) {
+                                    int rows, int n_local, int v0, const uint8_t* __restrict__ mask, int mask_len) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < rows) {
         const uint32_t id = local_ids[r];
-        pairs[r] = make_float2(logits[(long)r * n_local + id], __uint_as_float(id + (uint32_t)v0));
+        const bool valid = !mask || ((int)id < mask_len && mask[id] != 0);
+        pairs[r] = valid ? make_float2(logits[(long)r * n_local + id], __uint_as_float(id + (uint32_t)v0))
+                         : make_float2(-INFINITY, __uint_as_float(0xffffffffu));
     }
 }
 __global__ void argmax_merge_ranks_kernel(const float2* __restrict__ gathered, uint32_t* __restrict__ out, int rows, int world, DecodeAdvance adv) {
@@ -226,11 +232,13 @@ __global__ void argmax_merge_ranks_kernel(const float2* __restrict__ gathered, u
     const int step = adv.tokens ? *adv.step_counter : 0;
     if (r < rows) {
         float best = -INFINITY;
-        uint32_t best_id = 0;
-        for (int p = 0; p < world; p++) {
+        uint32_t best_id = 0xffffffffu;
+        for (int p = 0; p < world; p++) {                  // first maximum in rank order = the lowest id among equal logits
             const float2 v = gathered[(long)p * rows + r];
-            if (v.x > best || p == 0) { best = v.x; best_id = __float_as_uint(v.y); }
+            const uint32_t id = __float_as_uint(v.y);
+            if (id != 0xffffffffu && (best_id == 0xffffffffu || v.x > best)) { best = v.x; best_id = id; }
         }
+        if (best_id == 0xffffffffu) best_id = 0;           // no valid id on any rank
         out[r] = best_id;
         if (adv.tokens && r < adv.n) {
             adv.tokens[r] = best_id;
@@ -242,9 +250,9 @@ __global__ void argmax_merge_ranks_kernel(const float2* __restrict__ gathered, u
     __syncthreads();                                   // one block (rows ≤ 1024): every row has read `step`
     if (adv.tokens && threadIdx.x == 0 && blockIdx.x == 0) *adv.step_counter = step + 1;
 }
-int argmax_pairs_f32(const float* logits, const uint32_t* local_ids, void* pairs, int rows, int n_local, int v0, hipStream_t s) {
+int argmax_pairs_f32(const float* logits, const uint32_t* local_ids, void* pairs, int rows, int n_local, int v0, const uint8_t* mask, int mask_len, hipStream_t s) {
     if (rows <= 0) return 0;
-    hipLaunchKernelGGL(argmax_pairs_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, logits, local_ids, (float2*)pairs, rows, n_local, v0);
+    hipLaunchKernelGGL(argmax_pairs_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, s, logits, local_ids, (float2*)pairs, rows, n_local, v0, mask, mask_len);
     FH_CHECK_LAUNCH();
     return 0;
 }

@@ -12,5 +12,7 @@ int comm_world(const FerrumHipComm* c);
 int comm_all_reduce_f16(FerrumHipComm* c, __half* buf, size_t count, hipStream_t s);
 bool comm_oneshot_fits(const FerrumHipComm* c, size_t count);
 // small all-gather: `bytes` (multiple of 8) per rank → out[world][bytes] in rank order
+// new give-ups of the one-shot transport since the last call (the transport is switched off when there are any)
+unsigned comm_take_timeouts(FerrumHipComm* c);
 int comm_all_gather_bytes(FerrumHipComm* c, const void* in, void* out, size_t bytes, hipStream_t s);
 }  // namespace fh

@@ -78,6 +78,7 @@ struct OneShotArgs {
     long count;                 // fp16 elements, multiple of 4
     uint8_t* const* peers;      // device array [world]: comm buffer base of every rank (own included)
     unsigned* state;            // private device words: [0] epoch, [1] arrive ticket, [2] done ticket, [3] timeouts
+    unsigned* timeouts_host;    // pinned host word (device-visible): the same count where the host reads it after its next sync
     long parity_bytes;          // bytes of one data parity
     int world, rank;
 };
@@ -108,6 +109,10 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_reduce_kernel(OneShotArgs 
         const unsigned t = __hip_atomic_fetch_add(&a.state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (unsigned)nb - 1) {                   // last block of this rank: all of the partial is in memory
             __hip_atomic_store(&a.state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // system-scope release in front of the flags (the data went out write-through, so nothing is left to write back;
+            // the fence orders the flag stores behind the data for a peer GPU that polls them over xGMI)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             for (int p = 0; p < a.world; p++)
                 __hip_atomic_store(oneshot_flag(a.peers[p], parity, a.rank), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_reduce_kernel(OneShotArgs 
             __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - t0 > ONESHOT_SPIN_TICKS) { timed_out = 1; break; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");          // ONE system-scope acquire behind the relaxed polls
     }
     __syncthreads();
     // stage 3: rank-ordered fp32 sum of the `world` partials, one rounding (the same bits on every rank)
@@ -142,7 +148,10 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_reduce_kernel(OneShotArgs 
     }
     __syncthreads();
     if (tid == 0) {
-        if (timed_out) __hip_atomic_fetch_add(&a.state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timed_out) {
+            __hip_atomic_fetch_add(&a.state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.timeouts_host) __hip_atomic_fetch_add(a.timeouts_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         const unsigned t = __hip_atomic_fetch_add(&a.state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == (unsigned)nb - 1) {
             __hip_atomic_store(&a.state[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_reduce_kernel(OneShotArgs 
 // same buffers, flags, parity and epoch as the all-reduce above (one block, so it is its own last arriver).
 __global__ __launch_bounds__(256) void tp_oneshot_all_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long bytes,
                                                                     uint8_t* const* peers, unsigned* state, long parity_bytes, int world,
-                                                                    int rank) {
+                                                                    int rank, unsigned* timeouts_host) {
     const int tid = threadIdx.x;
     const unsigned epoch = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int parity = (int)(epoch & 1u);
@@ -170,7 +179,11 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_gather_kernel(const uint8_
     __syncthreads();
     __shared__ int timed_out;
     if (tid == 0) timed_out = 0;
-    if (tid < world) __hip_atomic_store(oneshot_flag(peers[tid], parity, rank), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < world) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(oneshot_flag(peers[tid], parity, rank), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     __syncthreads();
     if (tid < world) {
         const unsigned* f = oneshot_flag(peers[rank], parity, tid);
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_gather_kernel(const uint8_
             __builtin_amdgcn_s_sleep(4);
             if (__builtin_amdgcn_s_memrealtime() - t0 > ONESHOT_SPIN_TICKS) { timed_out = 1; break; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     if (!timed_out)
@@ -189,7 +203,10 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_gather_kernel(const uint8_
         }
     __syncthreads();
     if (tid == 0) {
-        if (timed_out) __hip_atomic_fetch_add(&state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (timed_out) {
+            __hip_atomic_fetch_add(&state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (timeouts_host) __hip_atomic_fetch_add(timeouts_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         __hip_atomic_store(&state[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -206,6 +223,10 @@ struct FerrumHipComm {
     bool peer_imported[8] = {};
     uint8_t** peers_dev = nullptr;        // device copy of peer_ptrs
     unsigned* state = nullptr;            // device: epoch, tickets, timeouts
+    unsigned* timeouts_host = nullptr;    // pinned host word bumped by a one-shot wait that gave up (read by the runner after every host sync)
+    unsigned timeouts_seen = 0;
+    bool oneshot_failed = false;          // a one-shot call timed out: its output was the rank's un-reduced partial and the epochs may have diverged — the transport stays off
+    bool finegrained = false;             // the comm buffer is fine-grained device memory (hipExtMallocWithFlags)
     bool oneshot_ready = false;
 };
 
@@ -215,7 +236,7 @@ int comm_world(const FerrumHipComm* c) { return c ? c->world : 1; }
 bool comm_graph_safe(const FerrumHipComm* c) { return c != nullptr; }   // RCCL and one-shot are both stream-ordered device work
 
 bool comm_oneshot_fits(const FerrumHipComm* c, size_t count) {
-    if (!c || !c->oneshot_ready || knobs().tp_oneshot == 0) return false;
+    if (!c || !c->oneshot_ready || c->oneshot_failed || knobs().tp_oneshot == 0) return false;
     if (count % 4 != 0 || count * 2 > c->parity_bytes) return false;
     return knobs().tp_oneshot == 1 || c->nccl == nullptr;      // auto: RCCL when there is one, one-shot for RCCL-less groups
 }
@@ -223,14 +244,14 @@ bool comm_oneshot_fits(const FerrumHipComm* c, size_t count) {
 int comm_all_reduce_f16(FerrumHipComm* c, __half* buf, size_t count, hipStream_t s) {
     if (!c || c->world <= 1 || count == 0) return 0;
     if (comm_oneshot_fits(c, count)) {
-        OneShotArgs a{buf, buf, (long)count, c->peers_dev, c->state, (long)c->parity_bytes, c->world, c->rank};
+        OneShotArgs a{buf, buf, (long)count, c->peers_dev, c->state, c->timeouts_host, (long)c->parity_bytes, c->world, c->rank};
         const int blocks = std::max(1, std::min(ONESHOT_MAX_BLOCKS, cdiv((long)count / 4, 256)));
         hipLaunchKernelGGL(tp_oneshot_all_reduce_kernel, dim3(blocks), dim3(256), 0, s, a);
         FH_CHECK_LAUNCH();
         form_hit(FORM_TP_ALLREDUCE_ONESHOT);
         return 0;
     }
-    FH_REQUIRE(c->nccl && g_all_reduce, "all_reduce: %zu fp16 elements exceed the one-shot buffer and the communicator has no RCCL rank", count);
+    FH_REQUIRE(c->nccl && g_all_reduce, "all_reduce: %zu fp16 elements: the one-shot transport is unavailable (message too large, or switched off after a call that gave up waiting for a peer) and the communicator has no RCCL rank", count);
     // ncclFloat16 = 6, ncclSum = 0 (rccl.h); in place like nccl_comm.rs all_reduce_in_place
     const int rc = g_all_reduce(buf, buf, count, 6, 0, c->nccl, s);
     FH_REQUIRE(rc == 0, "ncclAllReduce failed: %d", rc);
@@ -245,10 +266,10 @@ int comm_all_gather_bytes(FerrumHipComm* c, const void* in, void* out, size_t by
         return 0;
     }
     FH_REQUIRE(bytes % 8 == 0, "all_gather: %zu bytes per rank must be a multiple of 8", bytes);
-    const bool fits = c->oneshot_ready && knobs().tp_oneshot != 0 && bytes <= c->parity_bytes && bytes <= (64u << 10);
+    const bool fits = c->oneshot_ready && !c->oneshot_failed && knobs().tp_oneshot != 0 && bytes <= c->parity_bytes && bytes <= (64u << 10);
     if (fits && (knobs().tp_oneshot == 1 || c->nccl == nullptr)) {
         hipLaunchKernelGGL(tp_oneshot_all_gather_kernel, dim3(1), dim3(256), 0, s, (const uint8_t*)in, (uint8_t*)out, (long)bytes, c->peers_dev,
-                           c->state, (long)c->parity_bytes, c->world, c->rank);
+                           c->state, (long)c->parity_bytes, c->world, c->rank, c->timeouts_host);
         FH_CHECK_LAUNCH();
         form_hit(FORM_TP_ALLREDUCE_ONESHOT);
         return 0;
@@ -260,6 +281,17 @@ int comm_all_gather_bytes(FerrumHipComm* c, const void* in, void* out, size_t by
     return 0;
 }
 
+// Called by the runner after every host synchronisation of a forward: a one-shot wait that gave up skipped its reduction
+// (the output kept the rank's partial).  Returns the number of new give-ups and turns the transport off for good.
+unsigned comm_take_timeouts(FerrumHipComm* c) {
+    if (!c || !c->timeouts_host) return 0;
+    const unsigned now = *reinterpret_cast<volatile unsigned*>(c->timeouts_host);
+    const unsigned n = now - c->timeouts_seen;
+    c->timeouts_seen = now;
+    if (n) c->oneshot_failed = true;
+    return n;
+}
+
 }  // namespace fh
 
 namespace {
@@ -268,8 +300,20 @@ int oneshot_alloc(FerrumHipComm* c, size_t max_bytes) {
     FH_REQUIRE(max_bytes >= 4096 && max_bytes <= ((size_t)64 << 20), "comm: one-shot message cap %zu out of range", max_bytes);
     c->parity_bytes = (max_bytes + 255) / 256 * 256;
     const size_t total = ONESHOT_FLAG_BYTES + 2 * c->parity_bytes;
-    FH_CHECK_HIP(hipMalloc((void**)&c->buf, total));
+    // The flags of this buffer are polled by PEER GPUs inside a running kernel and the data parities are read by them while
+    // this rank's kernel is still in flight: plain hipMalloc memory is coarse-grained (cross-device visibility only at kernel
+    // boundaries), so the buffer is fine-grained device memory like RCCL's own flag / LL buffers; coarse-grained only as a
+    // fallback (single-GPU rehearsals work either way, a multi-GPU group then relies on the write-through system-scope stores).
+    if (hipExtMallocWithFlags((void**)&c->buf, total, hipDeviceMallocFinegrained) == hipSuccess) {
+        c->finegrained = true;
+    } else {
+        (void)hipGetLastError();
+        c->buf = nullptr;
+        FH_CHECK_HIP(hipMalloc((void**)&c->buf, total));
+    }
     FH_CHECK_HIP(hipMemset(c->buf, 0, total));
+    FH_CHECK_HIP(hipHostMalloc((void**)&c->timeouts_host, 64, hipHostMallocDefault));
+    *c->timeouts_host = 0u;
     FH_CHECK_HIP(hipMalloc((void**)&c->state, 64));
     FH_CHECK_HIP(hipMemset(c->state, 0, 64));
     FH_CHECK_HIP(hipMalloc((void**)&c->peers_dev, sizeof(void*) * 8));
@@ -379,6 +423,7 @@ int ferrum_hip_comm_destroy(FerrumHipComm* c) {
         if (c->peer_imported[p] && c->peer_ptrs[p]) (void)hipIpcCloseMemHandle(c->peer_ptrs[p]);
     if (c->buf) (void)hipFree(c->buf);
     if (c->state) (void)hipFree(c->state);
+    if (c->timeouts_host) (void)hipHostFree(c->timeouts_host);
     if (c->peers_dev) (void)hipFree(c->peers_dev);
     delete c;
     return 0;
@@ -418,6 +463,7 @@ int ferrum_hip_comm_oneshot_status(FerrumHipComm* c, unsigned* epoch, unsigned* 
     if (c->state) FH_CHECK_HIP(hipMemcpy(st, c->state, sizeof(st), hipMemcpyDeviceToHost));
     if (epoch) *epoch = st[0];
     if (timeouts) *timeouts = st[3];
+    if (st[3]) c->oneshot_failed = true;      // a call that gave up left un-reduced data behind and the ranks' epochs may differ: the transport stays off
     return 0;
 }
 

@@ -520,6 +520,11 @@ BENCH_DIMS = {
     "llama31-8b": dict(moe=False, hidden=4096, nq=32, nkv=8, hd=128, inter=14336, qk_norm=False, rope_theta=500000.0,
                        rope_scaling_kind=2, rope_p=(8.0, 1.0, 4.0, 8192.0)),
     "llama3-70b": dict(moe=False, hidden=8192, nq=64, nkv=8, hd=128, inter=28672, qk_norm=False, rope_theta=500000.0),
+    # BASELINE configs[3] at TP=1 dims, as the GPTQ pack it names: desc_act (act-order) with explicit zero points; two layers
+    # so that one is local (window 1024, θ 10k) and one global (linear-scaled θ 1M); sandwich norms on an fp32 residual, GeGLU
+    "gemma3-27b": dict(moe=False, hidden=5376, nq=32, nkv=16, hd=128, inter=21504, activation=1, sandwich=True,
+                       sliding_window=1024, sliding_window_pattern=2, rope_local_theta=10000.0, rope_theta=1e6,
+                       rope_scaling_kind=1, rope_p=(8.0, 0.0, 0.0, 0.0), embed_scale=73.5, layers=2, asym_act_order=True),
 }
 _TM_CACHE = {}
 
@@ -529,7 +534,7 @@ def _bench_dims_model(name):
     if name not in _TM_CACHE:
         _TM_CACHE.clear()                                        # one full-size layer of host weights at a time
         kw = dict(BENCH_DIMS[name])
-        _TM_CACHE[name] = modelgen.TinyModel(kw.pop("moe"), layers=1, vocab=2048, seed=43, max_seq_len=320, **kw)
+        _TM_CACHE[name] = modelgen.TinyModel(kw.pop("moe"), layers=kw.pop("layers", 1), vocab=2048, seed=43, max_seq_len=320, **kw)
     return _TM_CACHE[name]
 
 
@@ -635,7 +640,11 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
     # the forms the 8192-token prefill is meant to take: 96- / 256-row GEMM tiles with the scale folded into the fp16 B operand,
     # resident-K/V attention (256-token prompts: the whole context in one LDS image), and for the MoE model the router GEMM +
     # 96-pair grouped tiles through the same tall-tile kernel
-    forms.require("w4_big", "attn_resident", *(("route_gemm", "moe_tile_big") if moe else ()))
+    h = forms.require("w4_big", "attn_resident", *(("route_gemm", "moe_tile_big") if moe else ()))
+    act_order = name == "gemma3-27b"
+    if act_order:      # a desc_act pack: every norm / gated activation writes its row permuted; ONE gather launch per layer is left
+        forms.require("perm_producer")                                        # (o_proj behind the prefill attention forms)
+        assert h.get("gather_columns", 0) == tm.cfg["num_layers"], h
     par = modelgen.Parity(f"bench-workload-{name}", cos_min=0.999, rel_max=5e-2)
     gap = (lambda: om.last_route_gap_rel()) if moe else (lambda: float("inf"))
     cur = np.array(toks, np.uint32)                               # unfollowed rows continue on the device's own ids
@@ -653,6 +662,7 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
         fed.append(cur.copy())
     # decode at c = 32, kv ≈ 260: fused rope + attention with 8 waves, and the 17–32-row chains
     forms.require(*(("decode_chain", "route_split", "moe_expert_major_pair") if moe else ("attn_fused_qkv_wide", "dense_slab_chain", "w4_slabs_lds")))
+    if act_order: forms.require("perm_producer", absent=("gather_columns",))     # decode of a desc_act pack: no gather launch at all
     O.set_threads(1)
     rep = par.finish(max_mismatches=1, max_route_ties=1 if moe else 0)   # 27 followed rows: exact ids, at most one excused row
     for oc, i in enumerate(followed[:2]):
@@ -827,6 +837,43 @@ def _run_ranks(ranks, fn, timeout=300):
     return results
 
 
+def _oracle_follow(tm, label, prompts, rows, prefill, fed=None, step_logits=None, history=None, max_mismatches=1, max_route_ties=1):
+    """Rank 0 of a sharded run against the CPU ORACLE (not only against the unsharded HIP model: a bug both HIP sides share
+    would cancel out) on the followed `rows`, with the reference's own model-level criterion (qwen3_cuda_parity_test.rs:194-240:
+    same argmax and cosine > 0.999).  prefill = (ids [c], logits [c, V]); then either teacher-forced steps with logits —
+    fed[s] = the ids fed at step s, step_logits[s] = (ids, logits) the device produced — or a free-running id history
+    [steps, c] (ids only: the oracle is fed the device's own ids and its argmax must be the device's next id, except where the
+    oracle's own top-2 margin is within 2 % of its logit range)."""
+    from tests import modelgen
+    from oracle import oracle as O
+    moe = tm.cfg["num_experts"] > 0
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    par = modelgen.Parity(f"sharded-vs-oracle-{label}", cos_min=0.999, rel_max=5e-2)
+    gap = (lambda: om.last_route_gap_rel()) if moe else (lambda: float("inf"))
+    near = 0
+    for oc, i in enumerate(rows):
+        plen = len(prompts[i])
+        par.check(f"prefill/{i}", om.forward(oc, prompts[i], 0), prefill[1][i], prefill[0][i], gap())
+        if step_logits is not None:
+            for s, (ids, lg) in enumerate(step_logits):
+                par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[s][i]], np.uint32), plen + s), lg[i], ids[i], gap())
+        elif history is not None:
+            tok = int(prefill[0][i])
+            for s in range(history.shape[0]):
+                ol = om.forward(oc, np.array([tok], np.uint32), plen + s)
+                oi = int(O.argmax_rows(ol[None])[0])
+                if oi != int(history[s][i]):
+                    srt = np.sort(ol)
+                    assert srt[-1] - srt[-2] < 0.02 * float(np.abs(ol).max()), (label, i, s, oi, int(history[s][i]))
+                    near += 1
+                tok = int(history[s][i])
+    O.set_threads(1)
+    par.finish(max_mismatches=max_mismatches, max_route_ties=max_route_ties)
+    assert near <= 1 + len(rows) // 2, near
+    del om
+
+
 def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg, forms):
     """TP=2 of the runner, end to end on one GPU: two rank models run on two threads and meet in an in-process all-reduce
     after o_proj and down_proj (tp_decode.rs:363-366).  Both ranks must produce identical logits, equal to the unsharded
@@ -863,6 +910,9 @@ def test_tensor_parallel_forward_matches_single_gpu_through_loopback(pkg, forms)
         assert results[0][s][0] == ref[s][0]                                     # ids equal to TP=1
         assert modelgen.cosine(ref[s][1], results[0][s][1]) > 0.99999
         assert np.max(np.abs(ref[s][1] - results[0][s][1])) < 5e-3 * np.max(np.abs(ref[s][1]))
+    _oracle_follow(tm, "tp2-tiny", [prompt], [0], (np.array([results[0][0][0]]), results[0][0][1][None]),
+                   fed=[np.array([results[0][s][0]]) for s in range(3)],
+                   step_logits=[(np.array([results[0][s + 1][0]]), results[0][s + 1][1][None]) for s in range(3)], max_mismatches=0)
     del ranks
     lib.ferrum_hip_tp_loopback_destroy(lb)
 
@@ -928,6 +978,8 @@ def test_tp8_llama70b_rank_shard_shapes_through_loopback(pkg, forms):
     assert forms.hits().get("w4_tilep", 0) + forms.hits().get("w4_big", 0) > 0, forms.hits()      # the prefill's row tiles
     flips = _tp_vs_single(tm, full, {"ranks": res, "ref": ref}, c, steps, "llama70b-tp8")
     assert flips <= 1, flips                                     # 80 sampled rows: ids equal to TP=1 (at most one near-tie flip)
+    _oracle_follow(tm, "llama70b-tp8", prompts, (0, c // 2, c - 1), res[0][0], fed=[ref[s][0] for s in range(steps)],
+                   step_logits=res[0][1:])
     del ranks
     lib.ferrum_hip_tp_loopback_destroy(lb)
 
@@ -993,6 +1045,7 @@ def test_tp2_gemma27b_shards_graph_decode_with_oneshot_allreduce(pkg, forms, kno
         assert np.max(np.abs(ref[1][i] - one[0][1][i])) < 1e-2 * np.max(np.abs(ref[1][i]))
     same = sum(int(ref[0][i]) == int(one[0][0][i]) and np.array_equal(ref[2][:, i], one[0][2][:, i]) for i in range(c))
     assert same >= c - 1, same
+    _oracle_follow(tm, "gemma27b-tp2", prompts, (0, c - 1), (one[0][0], one[0][1]), history=one[0][2])
 
 
 @pytest.mark.parametrize("mode,world", [(1, 2), (2, 2), (2, 4)])
@@ -1050,6 +1103,7 @@ def test_expert_parallel_matches_single_gpu(pkg, forms, mode, world):
     assert np.array_equal(ref[0], res[0][0])                     # prefill ids equal to the unsharded model
     same = sum(np.array_equal(ref[2][:, i], res[0][2][:, i]) for i in range(len(prompts)))
     assert same >= len(prompts) - 1, same                        # free-running decode: whole histories (one near-tie flip allowed)
+    _oracle_follow(tm, f"ep-mode{mode}-w{world}", prompts, (1, 3), (res[0][0], res[0][1]), history=res[0][2])
 
 
 @pytest.mark.parametrize("moe,vocab", [(False, 1000), (True, 5003)])
@@ -1081,6 +1135,10 @@ def test_vocab_parallel_lm_head(pkg, forms, moe, vocab):
     mask = np.ones(vocab - 3, np.uint8)
     mask[int(np.argmax(raw[0]))] = 0
     pens = [(1.7, np.unique(np.concatenate([p, np.argsort(-raw[i])[:2]])).astype(np.uint32)) for i, p in enumerate(prompts)]
+    split = v0s[1][0]
+    mask_short = np.ones(split - 5, np.uint8)                     # every id of rank 1's slice is masked out
+    mask_high = np.zeros(vocab, np.uint8)
+    mask_high[split + 3::7] = 1                                   # … and here every id of rank 0's slice
 
     def drive(_r, m):
         t0, l0 = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
@@ -1088,7 +1146,17 @@ def test_vocab_parallel_lm_head(pkg, forms, moe, vocab):
         for i in ids:
             m.release(i)
         t1, _ = m.unified_forward([(10 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, token_mask=mask, repetition_penalties=pens)
-        return np.array(t0), l0.copy(), dec, np.array(t1)
+        for i in range(3):
+            m.release(10 + i)
+        # masks that leave ONE rank's vocabulary slice without a valid id: a mask that ends inside rank 0's slice (rank 1 holds
+        # none), and a sparse mask whose valid ids all lie in rank 1's slice — the empty rank must not compete with raw logits
+        t2, _ = m.unified_forward([(20 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, token_mask=mask_short)
+        for i in range(3):
+            m.release(20 + i)
+        t3, _ = m.unified_forward([(30 + i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, token_mask=mask_high)
+        for i in range(3):
+            m.release(30 + i)
+        return np.array(t0), l0.copy(), dec, np.array(t1), np.array(t2), np.array(t3)
 
     ref = drive(0, full)
     forms.reset()
@@ -1099,6 +1167,9 @@ def test_vocab_parallel_lm_head(pkg, forms, moe, vocab):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
     assert np.array_equal(ref[0], res[0][0])                     # prefill ids equal to the unsharded model
     assert np.array_equal(ref[3], res[0][3])                     # … also under the mask and the penalty
+    for k in (4, 5):                                              # … and when one rank's slice holds no valid id at all
+        assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(ref[k], res[0][k]), (k, ref[k], res[0][k])
+    assert (ref[4] < split - 5).all() and (ref[5] >= split).all()
     for r in range(world):
         v0, n = v0s[r]
         assert res[r][1].shape == (3, n)
@@ -1106,6 +1177,26 @@ def test_vocab_parallel_lm_head(pkg, forms, moe, vocab):
             assert modelgen.cosine(ref[1][i, v0:v0 + n], res[r][1][i]) > 0.9999
     same = sum(np.array_equal(ref[2][:, i], res[0][2][:, i]) for i in range(3))
     assert same >= 2, same
+    _oracle_follow(tm, f"vocab-parallel-{'moe' if moe else 'dense'}", prompts, (0, 1, 2),
+                   (res[0][0], np.concatenate([res[r][1] for r in range(world)], axis=1)), history=res[0][2])
+
+
+def test_oneshot_collective_that_gives_up_fails_the_forward(pkg, knobs):
+    """A one-shot all-reduce whose peer never shows up skips its reduction after its bounded wait (2 s): the forward that ran on
+    the rank's un-reduced partial must come back as an ERROR, not as sampled ids, and the transport stays off afterwards
+    (tp_comm.hip: host-visible give-up count read after every host synchronisation)."""
+    from tests import modelgen
+    tm = modelgen.TinyModel(False, layers=1, hidden=256, nq=4, nkv=2, hd=128, inter=256, vocab=256, seed=191)
+    ranks = _tp_rank_models(pkg, tm, 2, kv_num_blocks=8, max_seqs=2, max_tokens=16)
+    comms = pkg.Comm.local_group(2, 1 << 16)
+    ranks[0].set_comm(comms[0])                                   # rank 1 never runs
+    knobs.set(TP_ONESHOT=1)
+    prompt = np.arange(3, dtype=np.uint32)
+    with pytest.raises(RuntimeError, match="gave up waiting for a peer"):
+        ranks[0].unified_forward([(0, prompt, 0, True)], greedy=True)
+    assert comms[0].oneshot_status()["timeouts"] >= 1
+    with pytest.raises(RuntimeError):                             # no RCCL rank to fall back to: refused, not silently wrong
+        ranks[0].unified_forward([(1, prompt, 0, True)], greedy=True)
 
 
 def test_expert_parallel_qwen3_30b_dims(pkg, forms):
@@ -1148,6 +1239,8 @@ def test_expert_parallel_qwen3_30b_dims(pkg, forms):
     forms.require("tp_allreduce_loopback", "moe_expert_major_pair", "route_split")
     flips = _tp_vs_single(tm, full, {"ranks": res, "ref": ref}, c, steps, "qwen3-ep4")
     assert flips <= 2, flips                                     # 128 sampled rows
+    _oracle_follow(tm, "qwen3-ep4", prompts, (0, c // 2, c - 1), res[0][0], fed=[ref[s][0] for s in range(steps)],
+                   step_logits=res[0][1:])
     del ranks
     lib.ferrum_hip_tp_loopback_destroy(lb)
 
