@@ -2,9 +2,12 @@
 //!
 //! NOT COMPILED in the repository that ships the library (its image has no Rust toolchain): `ffi.rs` is generated from
 //! `include/ferrum_hip.h` and verified against the library's exports; the impls below follow the reference's trait
-//! signatures (`crates/ferrum-kernels/src/backend/traits.rs`, `capabilities.rs`) and are to be built inside the
-//! reference workspace.  `TRAIT_MAP` lists every trait method next to the C entry point that implements it; the CPU
-//! test suite checks that each named entry point exists in the library.
+//! signatures (`crates/ferrum-kernels/src/backend/traits.rs`, `capabilities.rs`, `ferrum-models/src/common/llm.rs`,
+//! `ferrum-interfaces/src/model_executor.rs`) and are to be built inside the reference workspace.  `TRAIT_MAP` lists
+//! every trait method next to the C entry point that implements it; the CPU test suite (tests/test_abi_symbols.py)
+//! checks that each named entry point exists in the library AND — parsing the reference's trait sources — that every
+//! required method of `Backend`, `BackendTimer`, `DecoderOnlyLLM` and `ModelExecutor` has an `fn` of the same name and
+//! the same number of parameters here.
 pub mod ffi;
 mod backend;
 mod collective;
@@ -13,8 +16,9 @@ mod moe;
 mod paged;
 mod quant;
 
-pub use backend::{HipBackend, HipBuf, HipCtx};
-pub use executor::HipModelExecutor;
+pub use backend::{HipBackend, HipBuf, HipCtx, HipEventTimer};
+pub use executor::{HipDecoderModel, HipModelExecutor};
+pub use paged::paged_pool_bytes;
 
 use ferrum_types::{FerrumError, Result};
 use std::ffi::CStr;
@@ -43,6 +47,23 @@ pub(crate) fn must(rc: c_int, what: &str) {
 /// (trait, method, reference file:line, C entry point) — one row per method the backend implements.
 pub const TRAIT_MAP: &[(&str, &str, &str, &str)] = &[
     ("Backend", "alloc", "traits.rs:118", "ferrum_hip_alloc"),
+    ("Backend", "alloc_typed", "traits.rs:98", "ferrum_hip_alloc"),
+    ("Backend", "from_slice_typed", "traits.rs:104", "ferrum_hip_memcpy_h2d"),
+    ("Backend", "write_typed", "traits.rs:110", "ferrum_hip_memcpy_h2d"),
+    ("Backend", "from_slice", "traits.rs:130", "ferrum_hip_memcpy_h2d"),
+    ("Backend", "to_vec", "traits.rs:124", "ferrum_hip_memcpy_d2h"),
+    ("Backend", "zero_buffer", "traits.rs:140", "ferrum_hip_memset_zero"),
+    ("Backend", "make_timer", "traits.rs:52", "ferrum_hip_event_create"),
+    ("BackendTimer", "record_start", "timer.rs:98", "ferrum_hip_event_record"),
+    ("BackendTimer", "elapsed_ms", "timer.rs:108", "ferrum_hip_event_elapsed_ms"),
+    ("Backend", "split_qkv", "traits.rs:823", "ferrum_hip_split_qkv_f16"),
+    ("Backend", "qk_norm_rope", "traits.rs:1238", "ferrum_hip_qk_norm_rope_f16"),
+    ("Backend", "transpose_token_to_head", "traits.rs:1294", "ferrum_hip_transpose_token_to_head_f16"),
+    ("Backend", "scaled_add_inplace", "traits.rs:1322", "ferrum_hip_scaled_add_inplace_f16"),
+    ("Backend", "add_bias", "traits.rs:1359", "ferrum_hip_add_bias_f16"),
+    ("Backend", "layer_norm", "traits.rs:1370", "ferrum_hip_layer_norm_f16"),
+    ("Backend", "gelu", "traits.rs:1384", "ferrum_hip_gelu_f16"),
+    ("Backend", "argmax_rows_f16_sparse_repetition_penalty", "traits.rs:1571", "ferrum_hip_apply_repetition_penalties_sparse_f16"),
     ("Backend", "sync", "traits.rs:88", "ferrum_hip_stream_synchronize"),
     ("Backend", "gemm", "traits.rs:190", "ferrum_hip_gemm_f16"),
     ("Backend", "rms_norm", "traits.rs:202", "ferrum_hip_rms_norm_f16"),
@@ -82,7 +103,9 @@ pub const TRAIT_MAP: &[(&str, &str, &str, &str)] = &[
     ("BackendCollective", "all_reduce", "capabilities.rs:92", "ferrum_hip_all_reduce_f16"),
     ("BackendCollective", "all_gather", "capabilities.rs:95", "ferrum_hip_all_gather_f16"),
     ("BackendCollective", "broadcast", "capabilities.rs:104", "ferrum_hip_broadcast_f16"),
-    ("ModelExecutor", "reserve_kv_slots", "model_executor.rs:484", "ferrum_hip_model_reserve_kv_slots"),
-    ("ModelExecutor", "unified_decode", "model_executor.rs:456", "ferrum_hip_model_unified_forward_ex"),
-    ("ModelExecutor", "release", "model_executor.rs:651", "ferrum_hip_model_release"),
+    ("DecoderOnlyLLM", "reserve_kv_slots", "common/llm.rs:133", "ferrum_hip_model_reserve_kv_slots"),
+    ("DecoderOnlyLLM", "kv_slot_capacity_snapshot", "common/llm.rs:141", "ferrum_hip_model_kv_capacity_snapshot"),
+    ("DecoderOnlyLLM", "unified_forward_with_logits_policy", "common/llm.rs:260", "ferrum_hip_model_unified_forward_ex"),
+    ("DecoderOnlyLLM", "release", "common/llm.rs:278", "ferrum_hip_model_release"),
+    ("ModelExecutor", "unified_decode", "model_executor.rs:567", "ferrum_hip_model_unified_forward_ex"),
 ];

@@ -232,6 +232,14 @@ class HipBackend:
                "embedding_lookup")
 
     @staticmethod
+    def layer_norm(ctx, x, gamma, beta, eps, out, tokens, dim):
+        _check(ctx.lib.ferrum_hip_layer_norm_f16(_ptr(x), _ptr(gamma), _ptr(beta), C.c_float(eps), _ptr(out), tokens, dim, ctx.stream), "layer_norm")
+
+    @staticmethod
+    def gelu(ctx, x, out, length):
+        _check(ctx.lib.ferrum_hip_gelu_f16(_ptr(x), _ptr(out), C.c_size_t(length), ctx.stream), "gelu")
+
+    @staticmethod
     def fused_silu_mul_split(ctx, gate_up, out, tokens, im):
         _check(ctx.lib.ferrum_hip_fused_silu_mul_split_f16(_ptr(gate_up), _ptr(out), tokens, im, ctx.stream), "fused_silu_mul_split")
 

@@ -224,6 +224,39 @@ int ferrum_hip_add_bias_f16(void* data, const void* bias, int rows, int cols, vo
     return add_bias_f16(H(data), CH(bias), rows, cols, ST(stream));
 }
 
+int ferrum_hip_layer_norm_f16(const void* x, const void* gamma, const void* beta, float eps, void* out, int tokens, int dim, void* stream) {
+    FH_REQUIRE(tokens == 0 || (x && gamma && beta && out), "layer_norm: null buffer");
+    return layer_norm_f16(CH(x), CH(gamma), CH(beta), eps, H(out), tokens, dim, ST(stream));
+}
+int ferrum_hip_gelu_f16(const void* x, void* out, size_t len, void* stream) {
+    FH_REQUIRE(len == 0 || (x && out), "gelu: null buffer");
+    return gelu_f16(CH(x), H(out), (long)len, ST(stream));
+}
+
+// ── device timer (Backend::Timer, backend/timer.rs:88-109: record on the context's stream, elapsed after both fired) ──
+int ferrum_hip_event_create(void** event) {
+    FH_REQUIRE(event, "event_create: null");
+    hipEvent_t e;
+    FH_CHECK_HIP(hipEventCreate(&e));
+    *event = (void*)e;
+    return 0;
+}
+int ferrum_hip_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+    return 0;
+}
+int ferrum_hip_event_record(void* event, void* stream) {
+    FH_REQUIRE(event, "event_record: null");
+    FH_CHECK_HIP(hipEventRecord((hipEvent_t)event, ST(stream)));
+    return 0;
+}
+int ferrum_hip_event_elapsed_ms(void* start, void* end, float* ms) {
+    FH_REQUIRE(start && end && ms, "event_elapsed_ms: null");
+    FH_CHECK_HIP(hipEventSynchronize((hipEvent_t)end));
+    FH_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)end));
+    return 0;
+}
+
 // ── dense GEMM ──────────────────────────────────────────────────────────────
 int ferrum_hip_gemm_f16(const void* a, const void* b, void* out, int m, int n, int k, FerrumHipWorkspace* ws, void* stream) {
     FH_REQUIRE(m == 0 || (a && b && out), "gemm: null buffer");

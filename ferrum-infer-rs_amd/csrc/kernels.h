@@ -124,6 +124,8 @@ int flash_attention_contig_f16(const __half* q, const __half* k, const __half* v
                                int sliding_window, hipStream_t s);
 int scale_inplace_f16(__half* buf, float scale, long len, hipStream_t s);
 int add_bias_f16(__half* data, const __half* bias, int rows, int cols, hipStream_t s);
+int layer_norm_f16(const __half* x, const __half* gamma, const __half* beta, float eps, __half* out, int tokens, int dim, hipStream_t s);
+int gelu_f16(const __half* x, __half* out, long len, hipStream_t s);
 int gather_columns_f16(const __half* in, const int32_t* perm, __half* out, int rows, int cols, hipStream_t s);
 int gather_rows_f16(const __half* in, const int32_t* row_idx, __half* out, int n_rows, int dim, hipStream_t s);
 

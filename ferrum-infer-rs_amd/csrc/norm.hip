@@ -479,6 +479,61 @@ int add_bias_f16(__half* data, const __half* bias, int rows, int cols, hipStream
     return 0;
 }
 
+// Backend::layer_norm (traits.rs; CPU cpu.rs:2081-2113): out = (x − mean)·(1/√(var + eps))·γ + β over `dim`, one workgroup per
+// token row (mean and variance in two passes over the row held in registers, fp32 — the CPU path accumulates them in f64).
+__global__ __launch_bounds__(256) void layer_norm_kernel(const __half* __restrict__ x, const __half* __restrict__ gamma,
+                                                        const __half* __restrict__ beta, float eps, __half* __restrict__ out, int dim) {
+    __shared__ float red[4];
+    const long row = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float v[32];                                       // dim ≤ 8192
+    float s = 0.f;
+    int n = 0;
+    for (int i = threadIdx.x; i < dim; i += 256) { v[n] = __half2float(x[row * dim + i]); s += v[n]; n++; }
+    s = wave_reduce_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)dim;
+    __syncthreads();
+    float q = 0.f;
+    for (int j = 0; j < n; j++) { const float d = v[j] - mean; q += d * d; }
+    q = wave_reduce_sum(q);
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    const float inv = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)dim + eps);
+    n = 0;
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        out[row * dim + i] = __float2half((v[n] - mean) * inv * __half2float(gamma[i]) + __half2float(beta[i]));
+        n++;
+    }
+}
+int layer_norm_f16(const __half* x, const __half* gamma, const __half* beta, float eps, __half* out, int tokens, int dim, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(dim > 0 && dim <= 8192, "layer_norm: dim=%d must be in [1, 8192]", dim);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(tokens), dim3(256), 0, s, x, gamma, beta, eps, out, dim);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
+// Backend::gelu (CPU cpu.rs:2115-2122): exact-form GELU 0.5·x·(1 + erf(x/√2)) with the reference's own erf — the
+// Abramowitz–Stegun 7.1.26 polynomial of cpu.rs:2263-2273 — so both sides round the same function.
+__global__ void gelu_kernel(const __half* __restrict__ x, __half* __restrict__ out, long len) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    const float xi = __half2float(x[i]);
+    const float z = xi / 1.41421356237309504880f;
+    const float sign = z < 0.f ? -1.0f : 1.0f, az = fabsf(z);
+    const float t = 1.0f / (1.0f + 0.3275911f * az);
+    const float y = 1.0f - (((((1.0614054f * t - 1.4531521f) * t) + 1.4214138f) * t - 0.28449672f) * t + 0.2548296f) * t * expf(-az * az);
+    out[i] = __float2half(0.5f * xi * (1.0f + sign * y));
+}
+int gelu_f16(const __half* x, __half* out, long len, hipStream_t s) {
+    if (len <= 0) return 0;
+    hipLaunchKernelGGL(gelu_kernel, dim3(cdiv(len, 256)), dim3(256), 0, s, x, out, len);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 // act-order input gather A'[m, j] = A[m, perm[j]] (kernels/gather_columns.cu:15).
 __global__ void gather_columns_kernel(const __half* __restrict__ in, const int32_t* __restrict__ perm,
                                       __half* __restrict__ out, int cols) {

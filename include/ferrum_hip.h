@@ -83,6 +83,16 @@ int ferrum_hip_fused_gelu_tanh_mul_split_f16(const void* gate_up, void* out, int
 int ferrum_hip_scale_inplace_f16(void* buf, float scale, size_t len, void* stream);
 int ferrum_hip_add_inplace_f16(void* residual, const void* x, size_t len, void* stream);
 int ferrum_hip_add_bias_f16(void* data, const void* bias, int rows, int cols, void* stream);
+/* Backend::layer_norm / Backend::gelu (traits.rs, required core ops; CPU cpu.rs:2081-2122 — exact-form GELU with the
+ * reference's own erf polynomial, cpu.rs:2263-2273).  Not on the LLM decode path; present so that the binding returns
+ * "unsupported" for no required method. */
+int ferrum_hip_layer_norm_f16(const void* x, const void* gamma, const void* beta, float eps, void* out, int tokens, int dim, void* stream);
+int ferrum_hip_gelu_f16(const void* x, void* out, size_t len, void* stream);
+/* Backend::Timer (backend/timer.rs:88-109): device events recorded on a context's stream; elapsed_ms waits for `end`. */
+int ferrum_hip_event_create(void** event);
+int ferrum_hip_event_destroy(void* event);
+int ferrum_hip_event_record(void* event, void* stream);
+int ferrum_hip_event_elapsed_ms(void* start, void* end, float* ms);
 
 /* ── dense fp16 GEMM: Backend::gemm (traits.rs:190; cpu.rs:438-493): out[m,n] = a[m,k]·b[n,k]ᵀ.
  *    Used for the MoE router and the unquantised lm_head.  `_f32out` keeps fp32 logits. ─────────── */

@@ -107,6 +107,34 @@ FO_API void fo_rms_norm(const float *x, const float *w, float eps, float *out,
     }
 }
 
+/* cpu.rs:2081-2113 layer_norm: mean and variance over `dim` in f64, then (x − mean)·inv·γ + β in f32. */
+FO_API void fo_layer_norm(const float *x, const float *gamma, const float *beta, float eps, float *out, int tokens, int dim) {
+    for (int t = 0; t < tokens; t++) {
+        long off = (long)t * dim;
+        double mean = 0.0;
+        for (int i = 0; i < dim; i++) mean += (double)x[off + i];
+        mean /= (double)dim;
+        double var = 0.0;
+        for (int i = 0; i < dim; i++) { double d = (double)x[off + i] - mean; var += d * d; }
+        var /= (double)dim;
+        float inv = 1.0f / sqrtf((float)var + eps);
+        float mean_f32 = (float)mean;
+        for (int i = 0; i < dim; i++) out[off + i] = (x[off + i] - mean_f32) * inv * gamma[i] + beta[i];
+    }
+}
+
+/* cpu.rs:2263-2273 libm_erf (Abramowitz–Stegun 7.1.26) and cpu.rs:2115-2122 gelu = 0.5·x·(1 + erf(x/√2)). */
+static float fo_libm_erf(float x) {
+    float sign = x < 0.0f ? -1.0f : 1.0f;
+    x = fabsf(x);
+    float t = 1.0f / (1.0f + 0.3275911f * x);
+    float y = 1.0f - (((((1.0614054f * t - 1.4531521f) * t) + 1.4214138f) * t - 0.28449672f) * t + 0.2548296f) * t * expf(-x * x);
+    return sign * y;
+}
+FO_API void fo_gelu(const float *x, float *out, long len) {
+    for (long i = 0; i < len; i++) out[i] = 0.5f * x[i] * (1.0f + fo_libm_erf(x[i] / 1.41421356237309504880f));
+}
+
 /* cpu.rs:515-538 fused_add_rms_norm: residual += x; out = rms(residual)·w. */
 FO_API void fo_fused_add_rms_norm(float *residual, const float *x, const float *w,
                                   float eps, float *out, int tokens, int dim) {

@@ -70,6 +70,8 @@ def _declare(l):
     l.fo_bf16_round.argtypes = [C.c_float]
     l.fo_rms_norm.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
                               C.POINTER(C.c_float), C.c_int, C.c_int]
+    l.fo_layer_norm.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int]
+    l.fo_gelu.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_long]
     l.fo_fused_add_rms_norm.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_float, C.POINTER(C.c_float),
                                                                      C.c_int, C.c_int]
     l.fo_scale_inplace.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_long]
@@ -186,6 +188,21 @@ def rms_norm(x, w, eps):
     t, d = x.shape
     out = np.zeros_like(x)
     lib().fo_rms_norm(_f(x), _f(w), eps, _f(out), t, d)
+    return out
+
+
+def layer_norm(x, gamma, beta, eps):
+    x, gamma, beta = f32(x), f32(gamma), f32(beta)
+    t, d = x.shape
+    out = np.zeros_like(x)
+    lib().fo_layer_norm(_f(x), _f(gamma), _f(beta), eps, _f(out), t, d)
+    return out
+
+
+def gelu(x):
+    x = f32(x)
+    out = np.zeros_like(x)
+    lib().fo_gelu(_f(x), _f(out), x.size)
     return out
 
 

@@ -262,3 +262,109 @@ def test_rust_ffi_crate_matches_the_library(pkg):
                 names += [first.split()[-1].lstrip("*")] + [r.strip().lstrip("*") for r in rest]
         body = re.search(r"pub struct %s \{(.*?)\n\}" % m.group(2), ffi, flags=re.S).group(1)
         assert re.findall(r"pub (\w+):", body) == names, m.group(2)
+
+
+# ── the trait impls of crates/ferrum-hip against the reference's trait sources ──────────────────────────────────────────
+REF = "/root/reference/crates"
+
+
+def _trait_methods(path, trait):
+    """(name, number of parameters, has a default body) of every fn of `pub trait <trait>` in a Rust source file."""
+    src = open(path).read()
+    i = src.index("pub trait " + trait)
+    j = src.index("{", i)
+    depth, k = 0, j
+    while True:
+        depth += {"{": 1, "}": -1}.get(src[k], 0)
+        if depth == 0:
+            break
+        k += 1
+    body = src[j + 1:k]
+    out = []
+    for m in re.finditer(r"\n    (?:async )?(?:unsafe )?fn (\w+)", body):
+        p, pd, params, start = m.end(), 0, None, None
+        while True:                                              # the parameter list, then `;` (required) or `{` (default body)
+            ch = body[p]
+            if ch == "(" and pd == 0 and params is None:
+                start = p
+            if ch in "([<":
+                pd += 1
+            elif ch in ")]>" and not (ch == ">" and body[p - 1] == "-"):
+                pd -= 1
+                if ch == ")" and pd == 0 and params is None:
+                    params = body[start + 1:p]
+            elif ch == ";" and pd <= 0:
+                default = False
+                break
+            elif ch == "{" and pd <= 0:
+                default = True
+                break
+            p += 1
+        out.append((m.group(1), _count_params(params), default))
+    return out
+
+
+def _count_params(params):
+    params = re.sub(r"//[^\n]*", "", params)
+    depth, n, cur = 0, 0, ""
+    for ch in params:
+        if ch in "([<{":
+            depth += 1
+        elif ch in ")]>}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            n += bool(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    return n + bool(cur.strip())
+
+
+def _crate_fns():
+    """name → set of parameter counts of every `fn` in crates/ferrum-hip/src (ffi.rs excluded)."""
+    crate = os.path.join(ROOT, "crates", "ferrum-hip", "src")
+    fns = {}
+    for f in os.listdir(crate):
+        if not f.endswith(".rs") or f == "ffi.rs":
+            continue
+        src = open(os.path.join(crate, f)).read()
+        for m in re.finditer(r"\bfn (\w+)\s*(?:<[^>]*>)?\s*\(", src):
+            p, depth = m.end(), 1
+            while depth:
+                depth += {"(": 1, ")": -1}.get(src[p], 0)
+                p += 1
+            fns.setdefault(m.group(1), set()).add(_count_params(src[m.end():p - 1]))
+    return fns
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is not on this machine")
+def test_rust_crate_implements_every_required_trait_method():
+    """crates/ferrum-hip cannot be compiled here (no Rust toolchain), so the next best check runs instead: the REQUIRED methods
+    (no default body) of the reference's `Backend`, `BackendTimer`, `DecoderOnlyLLM` and `ModelExecutor` traits — parsed out of
+    the reference's own sources — must each have an `fn` of the same name and the same number of parameters in the crate, and
+    so must the defaulted methods the drop-in needs to override (paged KV, graph capture, unified forward, admission)."""
+    fns = _crate_fns()
+    need = {
+        ("ferrum-kernels/src/backend/traits.rs", "Backend"): (),
+        ("ferrum-kernels/src/backend/timer.rs", "BackendTimer"): (),
+        ("ferrum-models/src/common/llm.rs", "DecoderOnlyLLM"): ("reserve_kv_slots", "kv_slot_capacity_snapshot", "unified_forward",
+                                                                "unified_forward_with_logits_policy", "decode_batch"),
+        ("ferrum-interfaces/src/model_executor.rs", "ModelExecutor"): ("unified_decode", "reserve_kv_slots", "kv_slot_capacity_snapshot",
+                                                                       "release_cache", "supports_native_unified_decode"),
+        ("ferrum-kernels/src/backend/traits.rs", "BackendPagedKv"): ("split_qkv_norm_rope_into_paged_cache_varlen", "paged_varlen_attention",
+                                                                      "paged_batched_decode_attention", "paged_decode_attention"),
+        ("ferrum-kernels/src/backend/capabilities.rs", "BackendGraph"): ("begin_graph_capture", "end_graph_capture", "replay_graph", "reset_graph"),
+    }
+    checked = 0
+    for (rel, trait), also in need.items():
+        methods = _trait_methods(os.path.join(REF, rel), trait)
+        required = [(n, c) for n, c, d in methods if not d]
+        if trait == "Backend":
+            assert len(required) == 24, (len(required), [n for n, _ in required])          # the count VERDICT r2 quotes
+        wanted = required + [(n, c) for n, c, d in methods if d and n in also]
+        assert set(also) <= {n for n, _, _ in methods}, (trait, set(also) - {n for n, _, _ in methods})
+        for name, count in wanted:
+            assert name in fns, f"{trait}::{name} has no fn in crates/ferrum-hip/src"
+            assert count in fns[name], f"{trait}::{name}: the reference takes {count} parameters, the crate's fn takes {sorted(fns[name])}"
+            checked += 1
+    assert checked >= 45, checked

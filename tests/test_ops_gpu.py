@@ -42,6 +42,29 @@ def host(t):
 
 
 # ── norms / elementwise ──────────────────────────────────────────────────────
+@pytest.mark.parametrize("tokens,dim", [(1, 768), (7, 1024), (3, 4100), (2, 8192)])
+def test_layer_norm_and_gelu_core_ops(env, tokens, dim):
+    # Backend::layer_norm / Backend::gelu (required core ops of the trait; CPU cpu.rs:2081-2122) + the event timer
+    pkg, B, ctx, O, torch = env
+    import ctypes as C
+    rng = np.random.default_rng(dim * 3 + tokens)
+    x = f16r(rng.standard_normal((tokens, dim)) * 3 + 0.7)
+    g, b = f16r(1 + 0.2 * rng.standard_normal(dim)), f16r(0.1 * rng.standard_normal(dim))
+    out = torch.empty(tokens, dim, dtype=torch.float16, device="cuda")
+    lib = ctx.lib
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    assert lib.ferrum_hip_event_create(C.byref(e0)) == 0 and lib.ferrum_hip_event_create(C.byref(e1)) == 0
+    assert lib.ferrum_hip_event_record(e0, ctx.stream) == 0
+    B.layer_norm(ctx, dev16(torch, x), dev16(torch, g), dev16(torch, b), 1e-5, out, tokens, dim)
+    assert lib.ferrum_hip_event_record(e1, ctx.stream) == 0
+    ms = C.c_float(-1.0)
+    assert lib.ferrum_hip_event_elapsed_ms(e0, e1, C.byref(ms)) == 0 and 0.0 <= ms.value < 1000.0
+    lib.ferrum_hip_event_destroy(e0); lib.ferrum_hip_event_destroy(e1)
+    assert nmse(O.layer_norm(x, g, b, 1e-5), host(out)) < NMSE_FP16_TOL
+    B.gelu(ctx, dev16(torch, x), out, tokens * dim)
+    assert nmse(O.gelu(x), host(out)) < NMSE_FP16_TOL
+
+
 @pytest.mark.parametrize("tokens,dim", [(1, 1024), (5, 2048), (32, 4096), (3, 5376), (2, 8192), (7, 128)])
 def test_rms_norm_and_fused_add(env, tokens, dim):
     pkg, B, ctx, O, torch = env

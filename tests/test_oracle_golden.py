@@ -478,3 +478,22 @@ def test_siphash_published_vectors_and_block_hash_chain_properties(oracle):
     # explicit construction: parent u64 LE ‖ token u32 LE, SipHash-1-3, zero key
     msg = struct.pack("<Q4I", 0, 1, 2, 3, 4)
     assert O.siphash(1, 3, 0, 0, msg) == int(chain[0])
+
+
+def test_layer_norm_and_gelu_follow_cpu_rs(oracle):
+    O = oracle
+    """cpu.rs:2081-2122: layer_norm (f64 mean / variance, f32 affine) and the exact-form GELU whose erf is the reference's own
+    Abramowitz-Stegun polynomial (cpu.rs:2263-2273: |error| <= 1.5e-7 against the true erf)."""
+    from scipy.special import erf
+    x = np.array([[1.0, 2.0, 3.0, 4.0], [-2.0, 0.0, 2.0, 0.0]], np.float32)
+    g = np.array([1.0, 0.5, 2.0, 1.0], np.float32)
+    b = np.array([0.0, 1.0, -1.0, 0.5], np.float32)
+    out = O.layer_norm(x, g, b, 0.0)
+    # row 0: mean 2.5, var 1.25 -> (x - 2.5) / sqrt(1.25); row 1: mean 0, var 2
+    exp0 = (x[0] - 2.5) / np.sqrt(1.25) * g + b
+    exp1 = x[1] / np.sqrt(2.0) * g + b
+    assert np.allclose(out[0], exp0, atol=1e-6) and np.allclose(out[1], exp1, atol=1e-6)
+    v = np.linspace(-6, 6, 97).astype(np.float32)
+    ref = 0.5 * v * (1.0 + erf(v / np.sqrt(2.0)))
+    assert np.max(np.abs(O.gelu(v[None])[0] - ref)) < 1e-6
+    assert O.gelu(np.zeros((1, 3), np.float32)).tolist() == [[0.0, 0.0, 0.0]]
