@@ -333,7 +333,6 @@ int ferrum_hip_gptq_load_stacked(FerrumHipGptq** handle, const int32_t* const* q
                                  int n_per_expert, int num_experts, int fuse_gate_up) {
     FH_REQUIRE(handle && qweights && scales && qzeros && num_experts > 0, "gptq_load_stacked: null argument");
     if (int rc = check_gptq_args(bits, group_size, k, n_per_expert)) return rc;
-    if (g_idx) { fh::set_error("gptq_load_stacked: act-order experts are not supported"); return FERRUM_HIP_UNSUPPORTED; }
     const int n = n_per_expert;
     std::vector<int32_t> col_perm;
     if (fuse_gate_up) {
@@ -351,7 +350,9 @@ int ferrum_hip_gptq_load_stacked(FerrumHipGptq** handle, const int32_t* const* q
     bool any_asym = false;
     std::vector<W4HostPacked> packed(num_experts);
     for (int e = 0; e < num_experts; e++) {
-        if (int rc = w4_repack_host(qweights[e], scales[e], qzeros[e], nullptr, fuse_gate_up ? col_perm.data() : nullptr,
+        // one g_idx for the whole stack (capabilities.rs:180-189; cuda/quant.rs:862 ff. samples expert 0's): act-order rows
+        // are packed in sorted-group order and the phase entry points gather the input columns to match
+        if (int rc = w4_repack_host(qweights[e], scales[e], qzeros[e], g_idx, fuse_gate_up ? col_perm.data() : nullptr,
                                     group_size, k, n, &packed[e])) { delete g; return rc; }
         any_asym |= !packed[e].symmetric;
     }
@@ -372,10 +373,29 @@ int ferrum_hip_gptq_load_stacked(FerrumHipGptq** handle, const int32_t* const* q
     int rc = upload(all_qw.data(), all_qw.size() * 4, (void**)&g->dev.qw);
     if (!rc) rc = upload(all_sc.data(), all_sc.size() * 2, (void**)&g->dev.sc);
     if (!rc && any_asym) rc = upload(all_zp.data(), all_zp.size() * 2, (void**)&g->dev.zp);
+    if (!rc && !packed[0].perm.empty()) rc = upload(packed[0].perm.data(), packed[0].perm.size() * 4, (void**)&g->dev.perm);
     if (rc) { ferrum_hip_gptq_free(g); return rc; }
     *handle = g;
     return 0;
 }
+
+// Act-order stack: the phase entry points read gathered input rows x'[r][j] = x[r][perm[j]] (`rows` input rows of K columns).
+// The scratch grows outside of graph capture only; an outgrown buffer stays alive with the handle (a captured graph may hold it).
+static int stack_input(const FerrumHipGptq* stack, const void* input, int rows, hipStream_t s, const __half** x) {
+    *x = CH(input);
+    if (!stack->dev.perm || rows <= 0) return 0;
+    auto* g = const_cast<FerrumHipGptq*>(stack);
+    if (g->gather_rows < rows) {
+        if (g->gather_scratch) g->retired_scratch.push_back(g->gather_scratch);
+        g->gather_scratch = nullptr;
+        FH_CHECK_HIP(hipMalloc((void**)&g->gather_scratch, (size_t)rows * g->dev.k * 2));
+        g->gather_rows = rows;
+    }
+    if (int rc = gather_columns_f16(CH(input), g->dev.perm, g->gather_scratch, rows, g->dev.k, s)) return rc;
+    *x = g->gather_scratch;
+    return 0;
+}
+static inline int input_rows(int prob_m, int top_k) { return (prob_m + top_k - 1) / top_k; }      // pair p reads row p / top_k
 
 int ferrum_hip_gptq_free(FerrumHipGptq* g) {
     if (!g) return 0;
@@ -445,10 +465,12 @@ int ferrum_hip_moe_gemm_phase_f16(const FerrumHipGptq* stack, const void* input,
     FH_REQUIRE(top_k >= 1, "moe_gemm_phase: top_k=%d", top_k);
     FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase: fused epilogue needs a stack loaded with fuse_gate_up");
     FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase: stack was loaded with fuse_gate_up; plain output is column-permuted");
+    const __half* x = nullptr;
+    if (int rc = stack_input(stack, input, input_rows(prob_m, top_k), ST(stream), &x)) return rc;
     if (moe_block_size >= 32)   // prefill-sized batches: 128-, 64- or 32-row LDS tiles
-        return w4_gemm_moe_tile(stack->dev, CH(input), H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
+        return w4_gemm_moe_tile(stack->dev, x, H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
                                 max_blocks, moe_block_size, top_k, fused_silu_mul, ST(stream));
-    return w4_gemm_moe(stack->dev, CH(input), H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
+    return w4_gemm_moe(stack->dev, x, H(output), sorted_token_ids, expert_ids, num_tokens_past_padded, prob_m,
                        max_blocks, top_k, fused_silu_mul, ST(stream));
 }
 
@@ -461,7 +483,9 @@ int ferrum_hip_moe_gemm_phase_inline_align_f16(const FerrumHipGptq* stack, const
     FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase_inline_align: fused epilogue needs a stack loaded with fuse_gate_up");
     FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase_inline_align: stack was loaded with fuse_gate_up; plain output is column-permuted");
     if (prob_m > 1024) { fh::set_error("moe_gemm_phase_inline_align: prob_m=%d > 1024 (use moe_align_block_size + moe_gemm_phase)", prob_m); return FERRUM_HIP_UNSUPPORTED; }
-    return w4_gemm_moe_inline_align(stack->dev, CH(input), H(output), expert_ids_per_pair, num_experts, prob_m, max_blocks,
+    const __half* x = nullptr;
+    if (int rc = stack_input(stack, input, input_rows(prob_m, top_k), ST(stream), &x)) return rc;
+    return w4_gemm_moe_inline_align(stack->dev, x, H(output), expert_ids_per_pair, num_experts, prob_m, max_blocks,
                                     top_k, fused_silu_mul, nullptr, nullptr, nullptr, ST(stream));
 }
 
@@ -473,7 +497,9 @@ int ferrum_hip_moe_gemm_phase_expert_major_f16(const FerrumHipGptq* stack, const
     FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "moe_gemm_phase_expert_major: fused epilogue needs a stack loaded with fuse_gate_up");
     FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "moe_gemm_phase_expert_major: stack was loaded with fuse_gate_up; plain output is column-permuted");
     if (prob_m > 1024) { fh::set_error("moe_gemm_phase_expert_major: prob_m=%d > 1024 (use moe_align_block_size + moe_gemm_phase)", prob_m); return FERRUM_HIP_UNSUPPORTED; }
-    return w4_gemm_moe_expert_major(stack->dev, CH(input), H(output), expert_ids_per_pair, num_experts, prob_m, top_k,
+    const __half* x = nullptr;
+    if (int rc = stack_input(stack, input, input_rows(prob_m, top_k), ST(stream), &x)) return rc;
+    return w4_gemm_moe_expert_major(stack->dev, x, H(output), expert_ids_per_pair, num_experts, prob_m, top_k,
                                     fused_silu_mul, ST(stream));
 }
 
@@ -485,6 +511,12 @@ int ferrum_hip_moe_gemm_phase_expert_major_pair_f16(FerrumHipGptq* gate_up_stack
     FH_REQUIRE(gate_up_stack->dev.fused_gate_up && !down_stack->dev.fused_gate_up,
                "moe_gemm_phase_expert_major_pair: gate_up stack must be loaded with fuse_gate_up, the down stack without");
     if (prob_m > 1024) { fh::set_error("moe_gemm_phase_expert_major_pair: prob_m=%d > 1024", prob_m); return FERRUM_HIP_UNSUPPORTED; }
+    if (down_stack->dev.perm) {       // the gated activations would need a gather between the two GEMMs of the launch
+        fh::set_error("moe_gemm_phase_expert_major_pair: act-order down stack (run the two phases separately)");
+        return FERRUM_HIP_UNSUPPORTED;
+    }
+    const __half* x_in = nullptr;
+    if (int rc = stack_input(gate_up_stack, input, input_rows(prob_m, top_k), ST(stream), &x_in)) return rc;
     FerrumHipGptq* g = gate_up_stack;
     if (g->pair_experts < num_experts) {
         // (a captured graph may still hold the old counters: retired with the handle, like outgrown gather buffers)
@@ -501,7 +533,7 @@ int ferrum_hip_moe_gemm_phase_expert_major_pair_f16(FerrumHipGptq* gate_up_stack
     const size_t half = (size_t)g->pair_experts * MOE_PAIR_COUNTER_STRIDE;
     FH_CHECK_HIP(hipMemsetAsync(arrive, 0, half * sizeof(unsigned), ST(stream)));
     int took = 0;
-    if (int rc = w4_gemm_moe_expert_major_pair(g->dev, down_stack->dev, CH(input), H(act_out), H(output), expert_ids_per_pair, num_experts,
+    if (int rc = w4_gemm_moe_expert_major_pair(g->dev, down_stack->dev, x_in, H(act_out), H(output), expert_ids_per_pair, num_experts,
                                                prob_m, top_k, arrive, arrive + half, arrive + 2 * half, &took, ST(stream)))
         return rc;
     if (!took) { fh::set_error("moe_gemm_phase_expert_major_pair: shapes not taken by the merged form"); return FERRUM_HIP_UNSUPPORTED; }
@@ -789,6 +821,8 @@ int ferrum_hip_moe_gemm_phase_batched_f16(FerrumHipGptq* stack, const void* inpu
         if (dispatches[4 * i + 3] > 0 && std::find(deltas.begin(), deltas.end(), dl) == deltas.end()) deltas.push_back(dl);
     }
     const int ldo = fused_silu_mul ? stack->dev.n / 2 : stack->dev.n;
+    const __half* x_in = nullptr;
+    if (int rc = stack_input(stack, input, (int)max_row, ST(stream), &x_in)) return rc;
     for (long dl : deltas) {
         std::vector<int32_t> sorted, blocks;
         for (int i = 0; i < num_dispatches; i++) {
@@ -820,9 +854,9 @@ int ferrum_hip_moe_gemm_phase_batched_f16(FerrumHipGptq* stack, const void* inpu
         const int32_t* d_blocks = sl.dev + sorted.size();
         const int32_t* d_total = sl.dev + sorted.size() + nb;
         __half* out_shift = H(output) + dl * ldo;                        // row (in_off + r) of the shifted view = out_off + r
-        int rc = br == 64 ? w4_gemm_moe_tile(stack->dev, CH(input), out_shift, d_sorted, d_blocks, d_total, (int)max_row, (int)nb, 64, 1,
+        int rc = br == 64 ? w4_gemm_moe_tile(stack->dev, x_in, out_shift, d_sorted, d_blocks, d_total, (int)max_row, (int)nb, 64, 1,
                                              fused_silu_mul, ST(stream))
-                          : w4_gemm_moe(stack->dev, CH(input), out_shift, d_sorted, d_blocks, d_total, (int)max_row, (int)nb, 1,
+                          : w4_gemm_moe(stack->dev, x_in, out_shift, d_sorted, d_blocks, d_total, (int)max_row, (int)nb, 1,
                                         fused_silu_mul, ST(stream));
         if (rc) return rc;
         FH_CHECK_HIP(hipEventRecord(sl.done, ST(stream)));
@@ -883,7 +917,9 @@ int ferrum_hip_moe_gemm_phase_merge_route_f16(const FerrumHipGptq* stack, const 
     FH_REQUIRE(stack && input && cand && stats && output && expert_ids_out && expert_weights_out, "merge_route: null argument");
     FH_REQUIRE(!fused_silu_mul || stack->dev.fused_gate_up, "merge_route: fused epilogue needs a stack loaded with fuse_gate_up");
     FH_REQUIRE(fused_silu_mul || !stack->dev.fused_gate_up, "merge_route: stack was loaded with fuse_gate_up; plain output is column-permuted");
-    return w4_gemm_moe_merge_route(stack->dev, CH(input), H(output), reinterpret_cast<const RouteCand*>(cand), stats, tokens,
+    const __half* x_in = nullptr;
+    if (int rc = stack_input(stack, input, tokens, ST(stream), &x_in)) return rc;
+    return w4_gemm_moe_merge_route(stack->dev, x_in, H(output), reinterpret_cast<const RouteCand*>(cand), stats, tokens,
                                    num_parts, top_k, norm_topk_prob, num_experts, max_blocks, fused_silu_mul, expert_ids_out,
                                    expert_weights_out, sorted_token_ids_out, block_ids_out, total_post_pad_out, ST(stream));
 }

@@ -30,6 +30,7 @@ struct LayerWeights {
     bool down_set = false;
     W4Device exp_gate_up, exp_down;   // stacked experts
     std::vector<uint8_t> exp_loaded;   // per expert: bit0 gate_up, bit1 down
+    std::vector<int32_t> exp_gate_up_perm_host, exp_down_perm_host;   // act-order stacks: the row permutation every expert of the stack must share
     __half* k_pool = nullptr;
     __half* v_pool = nullptr;
 };
@@ -73,7 +74,7 @@ struct FerrumHipModel {
     // scratch
     __half *residual = nullptr, *norm_out = nullptr, *qkv_out = nullptr, *q_out = nullptr, *attn_out = nullptr,
            *o_out = nullptr, *gate_up_out = nullptr, *act_out = nullptr, *mlp_out = nullptr, *sampled_hidden = nullptr,
-           *moe_act = nullptr, *moe_down = nullptr;
+           *moe_act = nullptr, *moe_down = nullptr, *moe_gather_x = nullptr, *moe_gather_h = nullptr;
     __half* residual2 = nullptr;          // ping-pong partner of `residual` for the Q-part route kernel
     fh::RouteCand* route_cand = nullptr;  // [T ≤ 64][Q][8]
     float* route_stats = nullptr;         // [T][Q][2]

@@ -382,7 +382,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
     for (void* p : {(void*)m->embed, (void*)m->lm_head, (void*)m->lm_head_t, (void*)m->final_norm, (void*)m->cos_t, (void*)m->sin_t,
                     (void*)m->residual, (void*)m->norm_out, (void*)m->qkv_out, (void*)m->q_out, (void*)m->attn_out,
                     (void*)m->o_out, (void*)m->gate_up_out, (void*)m->act_out, (void*)m->mlp_out,
-                    (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->router_logits,
+                    (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->moe_gather_x, (void*)m->moe_gather_h, (void*)m->router_logits,
                     (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
                     (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
@@ -505,17 +505,38 @@ int ferrum_hip_model_set_gptq(FerrumHipModel* m, int layer, int which, int exper
     FH_REQUIRE(c.num_experts > 0 && expert >= 0 && expert < c.num_experts, "model_set_gptq: expert=%d of %d", expert, c.num_experts);
     if (expert < m->ep_e0 || expert >= m->ep_e0 + m->ep_E) return 0;     // expert parallel: another rank's expert (a loader may offer all of them)
     expert -= m->ep_e0;
-    FH_REQUIRE(!g_idx, "model_set_gptq: act-order experts unsupported");
     const bool gu = which == 4;
     if (int rc = gu ? check_shape("expert gate_up", k, n, H, 2 * c.expert_inter) : check_shape("expert down", k, n, c.expert_inter, H)) return rc;
     std::vector<int32_t> perm;
     if (gu) perm = gate_up_col_perm(n);
-    if (int r = w4_repack_host(qweight, scales, qzeros, nullptr, gu ? perm.data() : nullptr, c.group_size, k, n, &hp)) return r;
-    FH_REQUIRE(hp.symmetric, "model_set_gptq: asymmetric expert zero points are not supported by the runner (use the op API)");
+    // act-order (desc_act) expert stacks (cuda/quant.rs:862 ff.): the packed rows are sorted by quant group, and — as the reference
+    // takes ONE g_idx for a stack (capabilities.rs:180-189: the experts share their K-axis quantisation) — every expert must
+    // bring the same row permutation; the grouped GEMMs then read gathered input rows (moe_gemm_inputs below).
+    if (int r = w4_repack_host(qweight, scales, qzeros, g_idx, gu ? perm.data() : nullptr, c.group_size, k, n, &hp)) return r;
     W4Device* w = gu ? &L.exp_gate_up : &L.exp_down;
+    std::vector<int32_t>& perm_host = gu ? L.exp_gate_up_perm_host : L.exp_down_perm_host;
+    const bool first = L.exp_loaded.empty() || std::none_of(L.exp_loaded.begin(), L.exp_loaded.end(), [&](uint8_t b) { return (b & (gu ? 1 : 2)) != 0; });
     if (int rc = ensure_expert_stack(w, k, n, m->ep_E, gu)) return rc;
+    if (first) {
+        perm_host = hp.perm;
+        if (!hp.perm.empty())
+            if (int rc = upload_perm(hp.perm, w)) return rc;
+    } else {
+        FH_REQUIRE(perm_host == hp.perm, "model_set_gptq: layer %d expert %d %s brings a different g_idx than the experts before it (a stack shares one)",
+                   layer, expert + m->ep_e0, gu ? "gate_up" : "down");
+    }
+    // explicit zero points (asymmetric packs; cuda/quant.rs:795-839 sends those to the vLLM MoE lane): the stack gets a zero-point
+    // array as soon as one expert needs it; symmetric experts of such a stack carry the implicit zero 8
+    const size_t sc_elems = hp.sc.size();
+    if (!hp.symmetric && !w->zp) {
+        FH_CHECK_HIP(hipMalloc((void**)&w->zp, sc_elems * 2 * (size_t)m->ep_E));
+        std::vector<uint16_t> eight(sc_elems * (size_t)m->ep_E, (uint16_t)0x4800);          // fp16 8.0
+        FH_CHECK_HIP(hipMemcpy(w->zp, eight.data(), eight.size() * 2, hipMemcpyHostToDevice));
+    }
     FH_CHECK_HIP(hipMemcpy(w->qw + (size_t)expert * hp.qw.size(), hp.qw.data(), hp.qw.size() * 4, hipMemcpyHostToDevice));
     FH_CHECK_HIP(hipMemcpy(w->sc + (size_t)expert * hp.sc.size(), hp.sc.data(), hp.sc.size() * 2, hipMemcpyHostToDevice));
+    if (w->zp && !hp.symmetric)
+        FH_CHECK_HIP(hipMemcpy(reinterpret_cast<uint16_t*>(w->zp) + (size_t)expert * sc_elems, hp.zp.data(), sc_elems * 2, hipMemcpyHostToDevice));
     if (L.exp_loaded.empty()) L.exp_loaded.assign(m->ep_E, 0);
     L.exp_loaded[expert] |= gu ? 1 : 2;
     return 0;
@@ -755,6 +776,10 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         }
         rc |= dev_alloc(&m->moe_act, P * c.expert_inter);
         rc |= dev_alloc(&m->moe_down, P * H);
+        bool gx_perm = false, dn_perm = false;                  // act-order expert stacks: gathered GEMM inputs
+        for (const LayerWeights& L : m->layers) { gx_perm |= L.exp_gate_up.perm != nullptr; dn_perm |= L.exp_down.perm != nullptr; }
+        if (gx_perm) rc |= dev_alloc(&m->moe_gather_x, T * H);
+        if (dn_perm) rc |= dev_alloc(&m->moe_gather_h, P * c.expert_inter);
     } else {
         rc |= dev_alloc(&m->gate_up_out, T * 2 * c.intermediate);
         rc |= dev_alloc(&m->act_out, T * (size_t)c.intermediate);
@@ -998,27 +1023,51 @@ T* idx(FerrumHipModel* m, size_t off) { return reinterpret_cast<T*>(m->idx_dev +
 // every form) and the local expert count.
 static const int32_t* moe_ids(const FerrumHipModel* m) { return m->cfg.expert_parallel ? m->expert_ids_local : m->expert_ids; }
 
+// Inputs of the two grouped GEMMs.  Act-order (desc_act) expert stacks read x'[j] = x[perm[j]] (the packed rows are in sorted-g_idx
+// order): the normalised rows / the gated activations are gathered by a launch in front of the GEMM (one per act-order stack and
+// layer: kernels/gather_columns.cu:15 in the reference sits in front of every Marlin call).  Natural-order stacks: no launch.
+static int moe_gate_up_input(FerrumHipModel* m, LayerWeights& L, int T, hipStream_t s, const __half** x) {
+    *x = m->norm_out;
+    if (!L.exp_gate_up.perm) return 0;
+    FH_REQUIRE(m->moe_gather_x, "MoE act-order gate_up stack without gather scratch");
+    if (int rc = gather_columns_f16(m->norm_out, L.exp_gate_up.perm, m->moe_gather_x, T, L.exp_gate_up.k, s)) return rc;
+    *x = m->moe_gather_x;
+    return 0;
+}
+static int moe_down_input(FerrumHipModel* m, LayerWeights& L, int P, hipStream_t s, const __half** h) {
+    *h = m->moe_act;
+    if (!L.exp_down.perm) return 0;
+    FH_REQUIRE(m->moe_gather_h, "MoE act-order down stack without gather scratch");
+    if (int rc = gather_columns_f16(m->moe_act, L.exp_down.perm, m->moe_gather_h, P, L.exp_down.k, s)) return rc;
+    *h = m->moe_gather_h;
+    return 0;
+}
+
 static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_blocks, hipStream_t s) {
     const FerrumHipModelConfig& c = m->cfg;
     const int E = m->ep_E, K = c.top_k;
     const int32_t* ids = moe_ids(m);
+    const __half *gx = nullptr, *hx = nullptr;
+    if (int rc = moe_gate_up_input(m, L, P / K, s, &gx)) return rc;
     // (the expert-major threshold compares pairs per expert: P pairs over num_experts, whatever share of them is local)
     if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts) {
-        if (knobs().moe_em2 && m->em2_arrive && !m->em2_failed) {
+        if (knobs().moe_em2 && m->em2_arrive && !m->em2_failed && !L.exp_down.perm) {
             // one launch: down tiles wait for their expert's gate_up tiles inside it (w4_gemm_moe_em2_kernel)
             unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * m->arrive_half_words;
             unsigned* nxt = m->em2_arrive + (size_t)(m->em2_parity ^ 1) * m->arrive_half_words;
             int took = 0;
-            if (int rc = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, m->norm_out, m->moe_act, m->moe_down, ids, E, P, K, cur, nxt,
+            if (int rc = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, gx, m->moe_act, m->moe_down, ids, E, P, K, cur, nxt,
                                                        m->inlaunch_timeouts, &took, s)) return rc;
             if (took) { m->em2_parity ^= 1; return 0; }
         }
-        if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, m->norm_out, m->moe_act, ids, E, P, K, 1, s)) return rc;
-        return w4_gemm_moe_expert_major(L.exp_down, m->moe_act, m->moe_down, ids, E, P, 1, 0, s);
+        if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, gx, m->moe_act, ids, E, P, K, 1, s)) return rc;
+        if (int rc = moe_down_input(m, L, P, s, &hx)) return rc;
+        return w4_gemm_moe_expert_major(L.exp_down, hx, m->moe_down, ids, E, P, 1, 0, s);
     }
-    if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, m->norm_out, m->moe_act, ids, E, P, max_blocks, K, 1,
+    if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, gx, m->moe_act, ids, E, P, max_blocks, K, 1,
                                           m->sorted_ids, m->block_ids, m->total_post_pad, s)) return rc;
-    return w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
+    if (int rc = moe_down_input(m, L, P, s, &hx)) return rc;
+    return w4_gemm_moe(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
 }
 
 // gate_up (+silu·mul) and down grouped GEMMs for any batch size, straight from expert_ids: decode-sized batches (≤ 1024
@@ -1028,6 +1077,8 @@ static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted
     const FerrumHipModelConfig& c = m->cfg;
     const int E = m->ep_E, K = c.top_k, Eg = c.num_experts;     // block shapes are chosen by pairs per expert over ALL experts
     const int32_t* ids = moe_ids(m);
+    const __half *gx = nullptr, *hx = nullptr;
+    if (P > 1024) FH_TRY(moe_gate_up_input(m, L, P / K, s, &gx));            // (decode-sized batches: moe_decode_gemms gathers for itself)
     if (P <= 1024) {
         FH_TRY(moe_decode_gemms(m, L, P, max_blocks, s));
     } else if (P >= (long)m->moe_tile96_min_pairs_per_expert * Eg && L.exp_gate_up.G % 2 == 0 && L.exp_down.G % 2 == 0) {
@@ -1035,27 +1086,30 @@ static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted
         const int sorted_max96 = P + E * 96, max_blocks96 = std::min(sorted_max96 / 96, P / 96 + std::min(P, E));
         FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 96, sorted_max96, s));
         {
-            FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+            FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, gx, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                                  max_blocks96, 96, K, 1, s));
         }
-        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(moe_down_input(m, L, P, s, &hx));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks96, 96, 1, 0, s));
     } else if (P >= (long)m->moe_tile128_min_pairs_per_expert * Eg && L.exp_gate_up.G % 2 == 0 && L.exp_down.G % 2 == 0) {
         // long prefill: 128-row blocks through w4_gemm_big_kernel (group scale folded into the fp16 B operand: the matrix pipe, not
         // vector issue, bounds it; twice the padding of 64-row blocks, hence only from a few hundred pairs per expert)
         const int sorted_max128 = P + E * 128, max_blocks128 = std::min(sorted_max128 / 128, P / 128 + std::min(P, E));
         FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 128, sorted_max128, s));
-        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, gx, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks128, 128, K, 1, s));
-        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(moe_down_input(m, L, P, s, &hx));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks128, 128, 1, 0, s));
     } else if (P >= m->moe_tile_min_pairs_per_expert * Eg) {
         // prefill: ≥ 32 pairs per expert on average → 64-row blocks through the LDS-tiled kernel
         const int sorted_max64 = P + E * 64, max_blocks64 = std::min(sorted_max64 / 64, P / 64 + std::min(P, E));
         FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 64, sorted_max64, s));
-        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, gx, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks64, 64, K, 1, s));
-        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(moe_down_input(m, L, P, s, &hx));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks64, 64, 1, 0, s));
     } else if (P >= m->moe_tile32_min_pairs_per_expert * Eg) {
         // a few hundred tokens (a fresh prompt riding along with the decode batch, a lone short prefill: 8–31 pairs
@@ -1063,15 +1117,17 @@ static int moe_batch_gemms(FerrumHipModel* m, LayerWeights& L, int P, int sorted
         // once per 16 pairs
         const int sorted_max32 = P + E * 32, max_blocks32 = std::min(sorted_max32 / 32, P / 32 + std::min(P, E));
         FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 32, sorted_max32, s));
-        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(w4_gemm_moe_tile(L.exp_gate_up, gx, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks32, 32, K, 1, s));
-        FH_TRY(w4_gemm_moe_tile(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(moe_down_input(m, L, P, s, &hx));
+        FH_TRY(w4_gemm_moe_tile(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                              max_blocks32, 32, 1, 0, s));
     } else {
         FH_TRY(moe_align_block_size(ids, m->sorted_ids, m->block_ids, m->total_post_pad, P, E, 16, sorted_max, s));
-        FH_TRY(w4_gemm_moe(L.exp_gate_up, m->norm_out, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(w4_gemm_moe(L.exp_gate_up, gx, m->moe_act, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                         max_blocks, K, 1, s));
-        FH_TRY(w4_gemm_moe(L.exp_down, m->moe_act, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
+        FH_TRY(moe_down_input(m, L, P, s, &hx));
+        FH_TRY(w4_gemm_moe(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P,
                         max_blocks, 1, 0, s));
     }
     return 0;

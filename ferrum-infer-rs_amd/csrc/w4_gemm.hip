@@ -878,7 +878,14 @@ __device__ __forceinline__ void w4_em2_role(const W4Em2Args& p, int tile, int* s
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) s_out[(4 * a + r) * 64 + nt * 16 + b] = (_Float16)acc[0][nt][r];
+                for (int nt = 0; nt < 4; nt++) {
+                    // (the f32 sum is rounded to f32 first, like every other form: left alone, the asymmetric instantiation folds the
+                    // last group's fma and this conversion into one v_fma_mixlo_f16 — a single rounding, one fp16 ulp apart on
+                    // about one output in 2^13)
+                    float v = acc[0][nt][r];
+                    asm volatile("" : "+v"(v));
+                    s_out[(4 * a + r) * 64 + nt * 16 + b] = (_Float16)v;
+                }
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int hh = 0; hh < 2; hh++) {

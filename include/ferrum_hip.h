@@ -123,7 +123,11 @@ int ferrum_hip_gptq_load(FerrumHipGptq** handle, const int32_t* qweight, const f
                          const int32_t* qzeros, const int32_t* g_idx, const float* bias, int bits,
                          int group_size, int k, int n);
 /* Stacked experts, contiguous per expert.  fuse_gate_up != 0 declares the N axis as [gate(I)|up(I)]
- * and enables the fused silu·mul epilogue of ferrum_hip_moe_gemm_phase (output width N/2). */
+ * and enables the fused silu·mul epilogue of ferrum_hip_moe_gemm_phase (output width N/2).
+ * Zero points may be asymmetric (the reference's vLLM-Marlin branch, cuda/quant.rs:795-839);
+ * g_idx, when it describes act-order, is ONE [K] array for the whole stack (cuda/quant.rs:862 ff.
+ * samples expert 0's): rows are packed in sorted-group order and every phase entry point gathers
+ * its input columns to match.  The one-launch gate_up→down pair refuses an act-order DOWN stack. */
 int ferrum_hip_gptq_load_stacked(FerrumHipGptq** handle, const int32_t* const* qweights,
                                  const float* const* scales, const int32_t* const* qzeros,
                                  const int32_t* g_idx, int bits, int group_size, int k, int n_per_expert,

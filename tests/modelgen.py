@@ -29,7 +29,7 @@ class TinyModel:
                  expert_inter=128, qk_norm=True, seed=0, max_seq_len=256, activation=0, sliding_window=0,
                  rope_theta=1e6, rope_scaling_kind=0, rope_p=(0.0, 0.0, 0.0, 0.0), tied=False, sandwich=False,
                  sliding_window_pattern=0, rope_local_theta=0.0, embed_scale=0.0, asym_act_order=False, mlp_down_first=False,
-                 qkv_bias=False, dense_proj=False):
+                 qkv_bias=False, dense_proj=False, expert_asym=False, expert_act_order=False):
         self.cfg = dict(num_layers=layers, hidden=hidden, num_heads=nq, num_kv_heads=nkv, head_dim=hd,
                         intermediate=0 if moe else inter, vocab=vocab, max_seq_len=max_seq_len, has_qk_norm=int(qk_norm),
                         activation=activation, num_experts=experts if moe else 0, top_k=top_k if moe else 0,
@@ -74,8 +74,14 @@ class TinyModel:
                 L["dense"]["router"] = f16r(rng.standard_normal((experts, H)) * 0.5)
                 for e in range(experts):
                     L["experts"][e] = {
-                        "expert_gate_up": (H, 2 * expert_inter) + synth_gptq(H, 2 * expert_inter, s0 + 100 + 2 * e),
-                        "expert_down": (expert_inter, H) + synth_gptq(expert_inter, H, s0 + 101 + 2 * e, gain=0.3)}
+                        "expert_gate_up": (H, 2 * expert_inter) + synth_gptq(H, 2 * expert_inter, s0 + 100 + 2 * e,
+                                                                             symmetric=not expert_asym),
+                        "expert_down": (expert_inter, H) + synth_gptq(expert_inter, H, s0 + 101 + 2 * e, gain=0.3,
+                                                                      symmetric=not expert_asym)}
+                if expert_act_order:      # ONE g_idx per expert stack (cuda/quant.rs:862 ff. samples expert 0's)
+                    erng = np.random.default_rng(s0 + 55)
+                    L["expert_g_idx"] = {"expert_gate_up": erng.permutation(np.arange(H) // 128).astype(np.int32),
+                                         "expert_down": erng.permutation(np.arange(expert_inter) // 128).astype(np.int32)}
             else:
                 L["gptq"]["gate_up"] = (H, 2 * inter) + synth_gptq(H, 2 * inter, s0 + 3, symmetric=sym)
                 L["gptq"]["down"] = (inter, H) + synth_gptq(inter, H, s0 + 4, symmetric=sym, gain=0.3)
@@ -102,10 +108,11 @@ class TinyModel:
                     model.set_gptq(li, name, qw, sc, qz, k, n, g_idx=gi)
             for e, d in L["experts"].items():
                 for name, (k, n, qw, sc, qz) in d.items():
+                    gi = L.get("expert_g_idx", {}).get(name)
                     if is_oracle:
-                        model.set_gptq(li, name, qw, sc, qz, 128, k, n, expert=e)
+                        model.set_gptq(li, name, qw, sc, qz, 128, k, n, expert=e, g_idx=gi)
                     else:
-                        model.set_gptq(li, name, qw, sc, qz, k, n, expert=e)
+                        model.set_gptq(li, name, qw, sc, qz, k, n, expert=e, g_idx=gi)
 
     def oracle_model(self):
         m = O.OracleModel(**self.cfg)

@@ -86,8 +86,8 @@ def test_asymmetric_act_order_checkpoint_style(pkg, prompt_len, style, forms):
 
 @pytest.mark.parametrize("prompt_len", [9, 70])
 def test_act_order_attention_projections_in_a_moe_model(pkg, prompt_len, forms):
-    """A MoE checkpoint whose ATTENTION projections are desc_act packs (the expert stacks are natural order: act-order experts are
-    refused at load): the decode attention scatters for o_proj and the split-route / slab fast path stays on; q|k|v gets its rows
+    """A MoE checkpoint whose ATTENTION projections are desc_act packs (the expert stacks are natural order here; act-order
+    stacks: test_asymmetric_and_act_order_expert_stacks_at_qwen3_dims): the decode attention scatters for o_proj and the split-route / slab fast path stays on; q|k|v gets its rows
     permuted by the embedding norm (layer 0) and by the MoE tail kernel (combine + add + norm) of the layer before."""
     from tests import modelgen
     seen = {}
@@ -621,6 +621,63 @@ def test_decode_chain_and_merged_moe_launch_across_layers(pkg, c, forms, knobs):
         srt = np.sort(l0, axis=1)
         for r in np.nonzero(t1 != t0)[0]:
             assert srt[r, -1] - srt[r, -2] <= 2 * err[r] + 1e-6, (s, int(r))
+
+
+@pytest.mark.parametrize("asym,desc_act", [(True, False), (False, True), (True, True)])
+def test_asymmetric_and_act_order_expert_stacks_at_qwen3_dims(pkg, asym, desc_act, forms):
+    """Expert stacks with explicit zero points (cuda/quant.rs:795-839: the reference sends those to its vLLM-Marlin lane) and/or
+    one act-order g_idx per stack (cuda/quant.rs:862 ff., capabilities.rs:180-189) in a Qwen3-30B-A3B-shaped layer pair: a
+    32 × 64-token prefill (grouped tiles), a 5-token prefill (16-row blocks) and decode at c = 32 (expert-major grid), three rows
+    followed by the oracle.  Natural-order stacks keep the one-launch gate_up → down pair; an act-order stack gathers its input
+    columns in front of each grouped GEMM (kernels/gather_columns.cu:15 sits in front of every Marlin call of the reference)."""
+    from tests import modelgen
+    from oracle import oracle as O
+    kw = dict(BENCH_DIMS["qwen3-30b-a3b"])
+    tm = modelgen.TinyModel(kw.pop("moe"), layers=2, vocab=2048, seed=47 + 2 * asym + desc_act, max_seq_len=128,
+                            expert_asym=asym, expert_act_order=desc_act, **kw)
+    c, plen, steps, followed = 32, 64, 3, (0, 13, 31)
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    hm = tm.hip_model(pkg, kv_num_blocks=(c + 1) * 6, max_seqs=c + 1, max_tokens=c * plen)
+    rng = np.random.default_rng(45)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    par = modelgen.Parity(f"expert-stacks-asym{int(asym)}-desc{int(desc_act)}", cos_min=0.999, rel_max=5e-2)
+    gap = lambda: om.last_route_gap_rel()
+    forms.reset()
+    toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+    h = forms.hits()
+    assert h.get("gather_columns", 0) == (4 if desc_act else 0), h             # gate_up + down input of both layers
+    cur = np.array(toks, np.uint32)
+    for oc, i in enumerate(followed):
+        cur[i] = par.check(f"prefill/{i}", om.forward(oc, prompts[i], 0), lg[i], toks[i], gap())
+    fed = [cur.copy()]
+    forms.reset()
+    for s in range(steps):
+        toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+        cur = np.array(toks, np.uint32)
+        for oc, i in enumerate(followed):
+            cur[i] = par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i], gap())
+        fed.append(cur.copy())
+    h = forms.require("decode_chain")
+    if desc_act:
+        assert h.get("gather_columns", 0) == 4 * steps and "moe_expert_major_pair" not in h, h
+    else:
+        forms.require("moe_expert_major_pair", absent=("gather_columns",))
+    # a short prompt on its own: 40 pairs → the inline-align 16-row blocks
+    short = rng.integers(0, 2048, size=5).astype(np.uint32)
+    forms.reset()
+    toks, lg = hm.unified_forward([(c, short, 0, True)], greedy=True, want_logits=True)
+    par.check("short", om.forward(3, short, 0), lg[0], toks[0], gap())
+    O.set_threads(1)
+    par.finish(max_mismatches=1, max_route_ties=1)
+    # hipGraph decode loop ≡ eager steps on the same state (unfollowed rows ran on their own ids throughout)
+    hm2 = tm.hip_model(pkg, kv_num_blocks=(c + 1) * 6, max_seqs=c + 1, max_tokens=c * plen)
+    t2, _ = hm2.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+    free = [i for i in range(c) if i not in followed]
+    assert np.array_equal(np.array(t2, np.uint32)[free], fed[0][free])
+    g = hm2.decode_steps(list(range(c)), fed[0], steps)
+    for s in range(steps):
+        assert np.array_equal(g[s][free], fed[s + 1][free]), s
 
 
 @pytest.mark.parametrize("name", sorted(BENCH_DIMS))

@@ -980,6 +980,82 @@ def test_moe_grouped_gemm_and_combine(env, tokens, E, K, H, I, forms):
             assert torch.equal(act, act2) and torch.equal(down, down2)
 
 
+@pytest.mark.parametrize("tokens,E,K,H,I", [(9, 8, 2, 256, 128), (32, 128, 8, 2048, 768), (80, 128, 8, 2048, 768)])
+@pytest.mark.parametrize("asym,desc_act", [(True, False), (False, True), (True, True)])
+def test_moe_asymmetric_and_act_order_expert_stacks(env, tokens, E, K, H, I, asym, desc_act, forms):
+    """Expert stacks with non-8 zero points (the reference's vLLM-Marlin branch, cuda/quant.rs:795-839) and with an act-order
+    g_idx shared by the stack (cuda/quant.rs:862 ff., capabilities.rs:180-189) against moe_forward_cpu on weights dequantised
+    WITH g_idx (cpu.rs:2283-2315): every phase entry point, at Qwen3-30B-A3B expert dims."""
+    pkg, B, ctx, O, torch = env
+    rng = np.random.default_rng(tokens * E + H + 2 * asym + desc_act)
+    gu = [O.make_synthetic_gptq(H, 2 * I, 128, 300 + e, symmetric=not asym) for e in range(E)]
+    dn = [O.make_synthetic_gptq(I, H, 128, 500 + e, symmetric=not asym) for e in range(E)]
+    gu = [(q, f16r(s / (0.28 * np.sqrt(H))), z) for q, s, z in gu]
+    dn = [(q, f16r(s / (0.28 * np.sqrt(I))), z) for q, s, z in dn]
+    gi_gu = O.make_desc_act_g_idx(H, 128) if desc_act else None
+    gi_dn = O.make_desc_act_g_idx(I, 128) if desc_act else None
+    x = f16r(rng.standard_normal((tokens, H)))
+    rid, rw = O.route_topk(rng.standard_normal((tokens, E)).astype(np.float32), E, K, True)
+    gw = np.stack([O.dequant_gptq(q, s, z, 128, H, 2 * I, g_idx=gi_gu) for q, s, z in gu])
+    dw = np.stack([O.dequant_gptq(q, s, z, 128, I, H, g_idx=gi_dn) for q, s, z in dn])
+    ref = O.moe_forward_cpu(x, H, I, K, rid, rw, gw, dw)
+    P = tokens * K
+    ids_d = torch.from_numpy(rid.astype(np.int32).reshape(-1).copy()).cuda()
+    xd, x_keep = dev16(torch, x), dev16(torch, x)
+    wd = torch.from_numpy(rw.reshape(-1).copy()).cuda()
+    stack = B.load_gptq_stacked([q for q, _, _ in gu], [s for _, s, _ in gu], [z for _, _, z in gu], gi_gu, 4, 128, H, 2 * I,
+                                fuse_gate_up=True)
+    down_stack = B.load_gptq_stacked([q for q, _, _ in dn], [s for _, s, _ in dn], [z for _, _, z in dn], gi_dn, 4, 128, I, H)
+
+    def combine(down):
+        out = torch.zeros(tokens, H, dtype=torch.float16, device="cuda")
+        B.moe_combine(ctx, down, wd, out, tokens, K, H)
+        ctx.sync()
+        return host(out)
+
+    base = None
+    for blk in (16, 64):
+        sd = torch.empty(P + E * blk, dtype=torch.int32, device="cuda")
+        bd = torch.empty((P + E * blk) // blk + 1, dtype=torch.int32, device="cuda")
+        td = torch.zeros(1, dtype=torch.int32, device="cuda")
+        B.moe_align_block_size_pair_ids(ctx, ids_d, sd, bd, td, P, E, blk, P + E * blk)
+        mb = (P + E * blk) // blk
+        act = torch.full((P, I), float("nan"), dtype=torch.float16, device="cuda")
+        down = torch.full((P, H), float("nan"), dtype=torch.float16, device="cuda")
+        stack.gemm_phase_vllm(ctx, xd, sd, bd, td, act, P, blk, K, mb, fused_silu_mul=True)
+        down_stack.gemm_phase_vllm(ctx, act, sd, bd, td, down, P, blk, 1, mb)
+        assert nmse(ref, combine(down)) < 3e-6, blk
+        if base is None: base = (act, down)
+        else: assert torch.equal(act, base[0]) and torch.equal(down, base[1])      # block shape does not change a row's sum
+    act, down = base
+    act3 = torch.full((P, I), float("nan"), dtype=torch.float16, device="cuda")
+    down3 = torch.full((P, H), float("nan"), dtype=torch.float16, device="cuda")
+    stack.gemm_phase_expert_major(ctx, xd, ids_d, act3, P, E, K, fused_silu_mul=True)
+    down_stack.gemm_phase_expert_major(ctx, act3, ids_d, down3, P, E, 1)
+    ctx.sync()
+    assert torch.equal(act, act3) and torch.equal(down, down3)
+    act2 = torch.full((P, I), float("nan"), dtype=torch.float16, device="cuda")
+    down2 = torch.full((P, H), float("nan"), dtype=torch.float16, device="cuda")
+    stack.gemm_phase_inline_align(ctx, xd, ids_d, act2, P, E, K, P // 16 + E, fused_silu_mul=True)
+    down_stack.gemm_phase_inline_align(ctx, act2, ids_d, down2, P, E, 1, P // 16 + E)
+    ctx.sync()
+    assert torch.equal(act, act2) and torch.equal(down, down2)
+    if I >= 256:
+        act4 = torch.full((P, I), float("nan"), dtype=torch.float16, device="cuda")
+        down4 = torch.full((P, H), float("nan"), dtype=torch.float16, device="cuda")
+        if desc_act:        # the down stack's input gather cannot sit inside the one launch: refused, callers run two phases
+            with pytest.raises(pkg.backend.Unsupported, match="act-order down stack"):
+                stack.gemm_phase_expert_major_pair(ctx, down_stack, xd, ids_d, act4, down4, P, E, K)
+        else:
+            forms.reset()
+            stack.gemm_phase_expert_major_pair(ctx, down_stack, xd, ids_d, act4, down4, P, E, K)
+            ctx.sync()
+            assert stack.pair_timeouts(ctx) == 0
+            assert torch.equal(act, act4) and torch.equal(down, down4)
+            forms.require("moe_expert_major_pair")
+    assert torch.equal(xd, x_keep)                                         # the gather works on a scratch copy
+
+
 @pytest.mark.parametrize("tokens,H,E,K", [(1, 2048, 128, 8), (32, 2048, 128, 8), (5, 1024, 64, 4), (3, 4096, 16, 2)])
 def test_fused_add_rms_norm_route_equals_op_chain(env, tokens, H, E, K):
     # fused.hip B ≡ fused_add_rms_norm → gemm(router) → route_topk_softmax, each as the oracle defines it

@@ -17,10 +17,13 @@ def f16r(a):
     return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
 
 
+SYM = os.environ.get('DBG_ASYM', '0') != '1'
+
+
 def run(tokens, E, K, H, I, fill):
     rng = np.random.default_rng(tokens * E + H)
-    gu = [O.make_synthetic_gptq(H, 2 * I, 128, 100 + e, symmetric=True) for e in range(E)]
-    dn = [O.make_synthetic_gptq(I, H, 128, 200 + e, symmetric=True) for e in range(E)]
+    gu = [O.make_synthetic_gptq(H, 2 * I, 128, 100 + e, symmetric=SYM) for e in range(E)]
+    dn = [O.make_synthetic_gptq(I, H, 128, 200 + e, symmetric=SYM) for e in range(E)]
     gu = [(q, f16r(s / (0.28 * np.sqrt(H))), z) for q, s, z in gu]
     dn = [(q, f16r(s / (0.28 * np.sqrt(I))), z) for q, s, z in dn]
     x = f16r(rng.standard_normal((tokens, H)))
