@@ -85,7 +85,7 @@ static float fo_dot(const float *a, const float *b, long n) {
 /* cpu.rs:438-493 CpuBackend::gemm, non-macOS branch: out[i,j] =
  * (f32) Σ_p (f64)a[i,p]·(f64)b[j,p];  b is [n,k] row-major. */
 FO_API void fo_gemm(const float *a, const float *b, float *out, int m, int n, int k) {
-#pragma omp parallel for collapse(2) schedule(static) num_threads(fo_threads) if (fo_threads > 1 && (long)m * n * k > (1L << 22))
+#pragma omp parallel for collapse(2) schedule(static) num_threads(fo_threads) if (fo_threads > 1 && (long)m * n * k >= (1L << 18))
     for (int i = 0; i < m; i++)
         for (int j = 0; j < n; j++) {
             double sum = 0.0;
