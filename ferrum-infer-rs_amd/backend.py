@@ -158,6 +158,14 @@ class ExpertStack(GptqLinear):
                                                                        prob_m, num_experts, top_k, ctx.stream),
                "moe_gemm_phase_expert_major_pair")
 
+    def gemm_phase_block_major_pair(self, ctx, down_stack, inp, expert_ids_per_pair, act_out, output, prob_m, num_experts, top_k,
+                                    max_blocks):
+        """≤ 64 pairs: gate_up (+ silu·mul) and down as ONE block-major launch; self is the fused gate_up stack."""
+        _check(ctx.lib.ferrum_hip_moe_gemm_phase_block_major_pair_f16(self.handle, down_stack.handle, _ptr(inp),
+                                                                      _ptr(expert_ids_per_pair), _ptr(act_out), _ptr(output),
+                                                                      prob_m, num_experts, top_k, max_blocks, ctx.stream),
+               "moe_gemm_phase_block_major_pair")
+
     def pair_timeouts(self, ctx):
         import ctypes
         t = ctypes.c_uint(0)

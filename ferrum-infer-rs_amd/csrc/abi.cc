@@ -41,6 +41,8 @@ void reload_knobs() {
     k.moe_kw_pairs = env_int("FERRUM_HIP_MOE_KW_PAIRS", 16);
     k.moe_em2 = env_int("FERRUM_HIP_MOE_EM2", 1);
     k.decode_chain = env_int("FERRUM_HIP_DECODE_CHAIN", 1);
+    k.moe_deferred_merge = env_int("FERRUM_HIP_MOE_DEFERRED_MERGE", 1);
+    k.moe_bm2 = env_int("FERRUM_HIP_MOE_BM2", 0);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
@@ -70,7 +72,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk", "gather_columns",
-    "perm_producer", "moe_expert_major_pair", "decode_chain"};
+    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "moe_block_major_pair"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 
@@ -537,6 +539,44 @@ int ferrum_hip_moe_gemm_phase_expert_major_pair_f16(FerrumHipGptq* gate_up_stack
                                                prob_m, top_k, arrive, arrive + half, arrive + 2 * half, &took, ST(stream)))
         return rc;
     if (!took) { fh::set_error("moe_gemm_phase_expert_major_pair: shapes not taken by the merged form"); return FERRUM_HIP_UNSUPPORTED; }
+    return 0;
+}
+
+/* ≤ 64 pairs (decode at c ≤ 8): the same pair of phases as ONE block-major launch — (gate_up + down tiles) × 16-row blocks,
+ * four waves per tile splitting K with the whole tile in flight, one arrival counter per block. */
+int ferrum_hip_moe_gemm_phase_block_major_pair_f16(FerrumHipGptq* gate_up_stack, const FerrumHipGptq* down_stack, const void* input,
+                                                   const int32_t* expert_ids_per_pair, void* act_out, void* output, int prob_m,
+                                                   int num_experts, int top_k, int max_blocks, void* stream) {
+    FH_REQUIRE(gate_up_stack && down_stack && input && expert_ids_per_pair && act_out && output, "moe_gemm_phase_block_major_pair: null argument");
+    FH_REQUIRE(top_k >= 1 && num_experts >= 1 && max_blocks >= 1, "moe_gemm_phase_block_major_pair: top_k=%d num_experts=%d max_blocks=%d", top_k,
+               num_experts, max_blocks);
+    FH_REQUIRE(gate_up_stack->dev.fused_gate_up && !down_stack->dev.fused_gate_up,
+               "moe_gemm_phase_block_major_pair: gate_up stack must be loaded with fuse_gate_up, the down stack without");
+    if (prob_m > 64) { fh::set_error("moe_gemm_phase_block_major_pair: prob_m=%d > 64", prob_m); return FERRUM_HIP_UNSUPPORTED; }
+    if (down_stack->dev.perm) {
+        fh::set_error("moe_gemm_phase_block_major_pair: act-order down stack (run the two phases separately)");
+        return FERRUM_HIP_UNSUPPORTED;
+    }
+    const __half* x_in = nullptr;
+    if (int rc = stack_input(gate_up_stack, input, input_rows(prob_m, top_k), ST(stream), &x_in)) return rc;
+    FerrumHipGptq* g = gate_up_stack;
+    if (g->pair_experts < num_experts) {
+        if (g->pair_arrive) g->retired_scratch.push_back(g->pair_arrive);
+        g->pair_arrive = nullptr;
+        const size_t words = (size_t)2 * num_experts * MOE_PAIR_COUNTER_STRIDE + 4;
+        FH_CHECK_HIP(hipMalloc((void**)&g->pair_arrive, words * sizeof(unsigned)));
+        FH_CHECK_HIP(hipMemset(g->pair_arrive, 0, words * sizeof(unsigned)));
+        g->pair_experts = num_experts;
+    }
+    unsigned* arrive = g->pair_arrive;
+    const size_t half = (size_t)g->pair_experts * MOE_PAIR_COUNTER_STRIDE;
+    FH_CHECK_HIP(hipMemsetAsync(arrive, 0, half * sizeof(unsigned), ST(stream)));
+    int took = 0;
+    if (int rc = w4_gemm_moe_block_major_pair(g->dev, down_stack->dev, x_in, H(act_out), H(output), expert_ids_per_pair, num_experts, prob_m,
+                                              std::min(max_blocks, num_experts), top_k, arrive, arrive + half, arrive + 2 * half, &took,
+                                              ST(stream)))
+        return rc;
+    if (!took) { fh::set_error("moe_gemm_phase_block_major_pair: shapes not taken by the merged form"); return FERRUM_HIP_UNSUPPORTED; }
     return 0;
 }
 

@@ -32,6 +32,7 @@
 #include "kv_layout.h"
 #include "rope_rows.h"
 #include "w4_device.h"
+#include "route_merge.h"
 
 namespace fh {
 
@@ -83,7 +84,7 @@ struct ChainArgs {
     __half* o_out;                // [T, H]
     // role B
     __half* res_b_out; const __half* post_ln; __half* norm2; const __half* router_w;
-    int E, r_top_k, Q, norm_topk;
+    int E, r_top_k, Q, norm_topk, defer_merge;
     RouteCand* cand; float* stats; unsigned* route_arrive; int32_t* ids; float* weights;
     unsigned* cnt; unsigned* cnt_next; unsigned* timeout;
 #ifdef FERRUM_HIP_EXPERIMENTS
@@ -666,6 +667,16 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
     __syncthreads();
     CH_TL(2);
     if (wave != 0) return;
+    if (p.defer_merge) {
+        // the consumer is the NEXT launch (the grouped gate_up GEMM merges the Q lists of every token in its prologue, under its
+        // first weight loads): plain stores, no meeting of the parts here — the ≈ 3.7 µs merge leaves the layer's critical path
+        unsigned long long* cand_g = reinterpret_cast<unsigned long long*>(p.cand) + (row * Q + q) * 8;
+        if (lane < 8) cand_g[lane] = cand_s[lane];
+        if (lane == 8) reinterpret_cast<unsigned long long*>(p.stats)[row * Q + q] =
+            ((unsigned long long)__float_as_uint(red[0] + red[1]) << 32) | __float_as_uint(mx);
+        CH_TL(3);
+        return;
+    }
     // The Q parts of a token meet without a counter: every part but the first publishes its 8 candidates and its two softmax
     // statistics as TAGGED 8-byte granules (one write-through store each — the data is the flag, Guideline 16 R2), and part 0
     // sweeps the (Q − 1)·10 granules of its token until every tag is there, merges, and clears them for the launch after the
@@ -721,23 +732,10 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
         pmx = __uint_as_float((unsigned)gr[lane * CH_GRAN + 8]);
         psum = __uint_as_float((unsigned)gr[lane * CH_GRAN + 9]);
     }
-    const float gmax = wave_reduce_max(pmx);
-    const float gsum = wave_reduce_sum(lane < Q ? psum * expf(pmx - gmax) : 0.f);
-    const float my_l = __uint_as_float((unsigned)c);
-    const int my_id = (int)(c >> 32);
-    int rank = 0;
-    for (int j = 0; j < ncand; j++) {
-        const float lj = __uint_as_float(__builtin_amdgcn_readlane((int)(unsigned)c, j));
-        const int ij = __builtin_amdgcn_readlane((int)(c >> 32), j);
-        rank += (lj > my_l || (lj == my_l && ij < my_id)) ? 1 : 0;
-    }
-    const float pr = expf(my_l - gmax) * (1.0f / gsum);
-    float sel_sum = 0.f;
-    for (int k = 0; k < top_k; k++) sel_sum += wave_reduce_sum(rank == k ? pr : 0.f);
+    float ww = 0.f;
+    const int rank = route_merge_token(c, ncand, pmx, psum, Q, top_k, p.norm_topk, true, &ww);
     if (rank < top_k) {
-        float ww = pr;
-        if (p.norm_topk) ww = sel_sum > 0.f ? ww * (1.0f / sel_sum) : 1.0f / (float)top_k;
-        p.ids[row * top_k + rank] = my_id;
+        p.ids[row * top_k + rank] = (int)(c >> 32);
         p.weights[row * top_k + rank] = ww;
     }
     CH_TL(3);
@@ -819,7 +817,7 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     a.o = ChainGemm{d.o->qw, d.o->sc, d.o->zp, d.o->G, d.o->n, d.o->k};
     a.o_out = d.o_out;
     a.res_b_out = d.res_b_out; a.post_ln = d.post_ln; a.norm2 = d.norm2; a.router_w = d.router_w;
-    a.E = d.E; a.r_top_k = d.r_top_k; a.Q = d.Q; a.norm_topk = d.norm_topk;
+    a.E = d.E; a.r_top_k = d.r_top_k; a.Q = d.Q; a.norm_topk = d.norm_topk; a.defer_merge = d.defer_merge ? 1 : 0;
     a.cand = d.cand; a.stats = d.stats; a.route_arrive = d.route_arrive; a.ids = d.ids; a.weights = d.weights;
     a.cnt = d.cnt; a.cnt_next = d.cnt_next; a.timeout = d.timeout;
 #ifdef FERRUM_HIP_EXPERIMENTS

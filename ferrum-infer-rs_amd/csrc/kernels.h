@@ -63,9 +63,25 @@ int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, co
 // words between the per-expert arrival counters of the merged launch (one 256-byte line each): `arrive` / `arrive_next` hold
 // num_experts · MOE_PAIR_COUNTER_STRIDE words
 constexpr int MOE_PAIR_COUNTER_STRIDE = 64;
+// routing handed over as the router's Q per-part candidate lists of every token (fused.hip part kernel / chain.hip role B
+// with defer_merge) instead of merged pair ids: the grouped GEMM merges them in its prologue and publishes ids + combine weights
+struct MoeRouteLists {
+    const RouteCand* cand = nullptr; const float* stats = nullptr;
+    int T = 0, Q = 0, norm_topk = 0;
+    int32_t* pub_expert_ids = nullptr; float* pub_expert_w = nullptr;
+};
+bool w4_gemm_moe_expert_major_pair_supports(const W4Device& gu, const W4Device& dn, int num_experts, int num_valid_pairs,
+                                            const MoeRouteLists* route);
 int w4_gemm_moe_expert_major_pair(const W4Device& gu, const W4Device& dn, const __half* x, __half* h, __half* out,
                                   const int32_t* pair_expert_ids, int num_experts, int num_valid_pairs, int top_k,
-                                  unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream);
+                                  unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream,
+                                  const MoeRouteLists* route = nullptr);
+bool w4_gemm_moe_block_major_pair_supports(const W4Device& gu, const W4Device& dn, int num_experts, int num_valid_pairs, int max_blocks,
+                                           const MoeRouteLists* route);
+int w4_gemm_moe_block_major_pair(const W4Device& gu, const W4Device& dn, const __half* x, __half* h, __half* out,
+                                 const int32_t* pair_expert_ids, int num_experts, int num_valid_pairs, int max_blocks, int top_k,
+                                 unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream,
+                                 const MoeRouteLists* route = nullptr);
 int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
                              int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
                              int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream);
@@ -228,6 +244,7 @@ struct DecodeChainDesc {
     const W4Device* o = nullptr; __half* o_out = nullptr;
     __half* res_b_out = nullptr; const __half* post_ln = nullptr; __half* norm2 = nullptr; const __half* router_w = nullptr;
     int E = 0, r_top_k = 0, Q = 0, norm_topk = 0;
+    bool defer_merge = false;    // role B stops at the per-part candidate lists (cand / stats); the grouped GEMM that follows merges them
     RouteCand* cand = nullptr; float* stats = nullptr; unsigned* route_arrive = nullptr; int32_t* ids = nullptr; float* weights = nullptr;
     unsigned* cnt = nullptr;       // decode_chain_counter_words() words, zero on entry
     unsigned* cnt_next = nullptr;  // the other half of the double buffer: zeroed by this launch

@@ -1043,7 +1043,29 @@ static int moe_down_input(FerrumHipModel* m, LayerWeights& L, int P, hipStream_t
     return 0;
 }
 
-static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_blocks, hipStream_t s) {
+// `route` (decode chain with a deferred merge): the routing arrives as per-part candidate lists; only forms that merge them in
+// their own prologue may run (moe_deferred_merge_ok decides that BEFORE the chain launch).
+static bool moe_pair_form(const FerrumHipModel* m, const LayerWeights& L, int P) {
+    return m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * m->cfg.num_experts && knobs().moe_em2 &&
+           m->em2_arrive && !m->em2_failed && !L.exp_down.perm;
+}
+static bool moe_deferred_merge_ok(const FerrumHipModel* m, const LayerWeights& L, int T, int Q) {
+    const int mode = knobs().moe_deferred_merge;
+    if (!mode || m->cfg.expert_parallel || Q < 2 || Q > 4 || m->cfg.top_k > 8) return false;
+    const int P = T * m->cfg.top_k;
+    // few pairs (block-major grid): every workgroup runs the full merge + align on a few hundred bytes of lists
+    // (T ≤ 4: c = 1 1.99 → 1.88 ms per step, c = 2 2.16 → 2.03, c = 4 ±0; at c = 8 the four merge passes in each of the ≈ 1500
+    // one-wave workgroups cost the gate_up launch more than role B's merge costs the chain: 2.89 → 3.03)
+    if (T <= 4 && P <= 64 && !moe_pair_form(m, L, P)) return true;
+    // expert-major merged launch: each tile only checks its own expert against the lists; measured at c = 32 the ≈ 8 KiB of lists
+    // read by all 7168 workgroups cost the launch what role B's merge cost the chain (47.4 → 50.3 µs vs ≈ −3 µs): off unless asked for
+    if (mode < 2) return false;
+    MoeRouteLists r;
+    r.cand = m->route_cand; r.stats = m->route_stats; r.T = T; r.Q = Q; r.pub_expert_ids = m->expert_ids; r.pub_expert_w = m->expert_w;
+    return moe_pair_form(m, L, P) && !L.exp_gate_up.perm && w4_gemm_moe_expert_major_pair_supports(L.exp_gate_up, L.exp_down, m->ep_E, P, &r);
+}
+
+static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_blocks, hipStream_t s, const MoeRouteLists* route = nullptr) {
     const FerrumHipModelConfig& c = m->cfg;
     const int E = m->ep_E, K = c.top_k;
     const int32_t* ids = moe_ids(m);
@@ -1051,18 +1073,38 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
     if (int rc = moe_gate_up_input(m, L, P / K, s, &gx)) return rc;
     // (the expert-major threshold compares pairs per expert: P pairs over num_experts, whatever share of them is local)
     if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts) {
-        if (knobs().moe_em2 && m->em2_arrive && !m->em2_failed && !L.exp_down.perm) {
+        if (moe_pair_form(m, L, P)) {
             // one launch: down tiles wait for their expert's gate_up tiles inside it (w4_gemm_moe_em2_kernel)
             unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * m->arrive_half_words;
             unsigned* nxt = m->em2_arrive + (size_t)(m->em2_parity ^ 1) * m->arrive_half_words;
             int took = 0;
             if (int rc = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, gx, m->moe_act, m->moe_down, ids, E, P, K, cur, nxt,
-                                                       m->inlaunch_timeouts, &took, s)) return rc;
-            if (took) { m->em2_parity ^= 1; return 0; }
+                                                       m->inlaunch_timeouts, &took, s, route)) return rc;
+            if (took) { m->em2_parity ^= 1; if (route) form_hit(FORM_MOE_DEFERRED_MERGE); return 0; }
         }
+        FH_REQUIRE(!route, "MoE decode: the routing was left as candidate lists but the merged launch did not take the shapes");
         if (int rc = w4_gemm_moe_expert_major(L.exp_gate_up, gx, m->moe_act, ids, E, P, K, 1, s)) return rc;
         if (int rc = moe_down_input(m, L, P, s, &hx)) return rc;
         return w4_gemm_moe_expert_major(L.exp_down, hx, m->moe_down, ids, E, P, 1, 0, s);
+    }
+    if (knobs().moe_bm2 && m->em2_arrive && !m->em2_failed && !L.exp_down.perm && max_blocks <= E &&
+        w4_gemm_moe_block_major_pair_supports(L.exp_gate_up, L.exp_down, E, P, max_blocks, route)) {
+        // ≤ 64 pairs: one block-major launch, down tiles wait for their block's gate_up tiles inside it (w4_gemm_moe_bm2_kernel)
+        unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * m->arrive_half_words;
+        unsigned* nxt = m->em2_arrive + (size_t)(m->em2_parity ^ 1) * m->arrive_half_words;
+        int took = 0;
+        if (int rc = w4_gemm_moe_block_major_pair(L.exp_gate_up, L.exp_down, gx, m->moe_act, m->moe_down, ids, E, P, max_blocks, K, cur, nxt,
+                                                  m->inlaunch_timeouts, &took, s, route)) return rc;
+        if (took) { m->em2_parity ^= 1; if (route) form_hit(FORM_MOE_DEFERRED_MERGE); return 0; }
+    }
+    if (route) {
+        // gate_up merges the lists, aligns, and publishes ids / weights / align arrays; down reads the align arrays
+        if (int rc = w4_gemm_moe_merge_route(L.exp_gate_up, gx, m->moe_act, route->cand, route->stats, route->T, route->Q, K, route->norm_topk,
+                                             E, max_blocks, 1, route->pub_expert_ids, route->pub_expert_w, m->sorted_ids, m->block_ids,
+                                             m->total_post_pad, s)) return rc;
+        form_hit(FORM_MOE_DEFERRED_MERGE);
+        if (int rc = moe_down_input(m, L, P, s, &hx)) return rc;
+        return w4_gemm_moe(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
     }
     if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, gx, m->moe_act, ids, E, P, max_blocks, K, 1,
                                           m->sorted_ids, m->block_ids, m->total_post_pad, s)) return rc;
@@ -1239,12 +1281,18 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             d.has_a = pending_chain_tail;
             d.cnt = m->em2_arrive + (size_t)m->chain_parity * m->arrive_half_words + (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE;
             d.cnt_next = m->em2_arrive + (size_t)(m->chain_parity ^ 1) * m->arrive_half_words + (size_t)c.num_experts * MOE_PAIR_COUNTER_STRIDE;
+            // the Q candidate lists of a token are merged by the grouped GEMM's prologue (under its first weight loads) where that
+            // form runs, instead of by role B's first part at the end of the chain (≈ 3.7 µs of every layer)
+            d.defer_merge = d.Q > 1 && moe_deferred_merge_ok(m, L, T, d.Q);
+            MoeRouteLists lists;
+            lists.cand = m->route_cand; lists.stats = m->route_stats; lists.T = T; lists.Q = d.Q; lists.norm_topk = c.norm_topk_prob;
+            lists.pub_expert_ids = m->expert_ids; lists.pub_expert_w = m->expert_w;
             RUN(decode_chain_f16(d, s));
             m->chain_parity ^= 1;
             pending_chain_tail = false;
             form_hit(d.Q > 1 ? FORM_ROUTE_SPLIT : FORM_ROUTE_FUSED);
             if (c.expert_parallel) RUN(moe_remap_expert_ids(m->expert_ids, m->expert_ids_local, P, m->ep_e0, m->ep_E, s));
-            RUN(moe_decode_gemms(m, L, P, max_blocks, s));
+            RUN(moe_decode_gemms(m, L, P, max_blocks, s, d.defer_merge ? &lists : nullptr));
             if (!c.expert_parallel && li + 1 < c.num_layers && chain_ok(li + 1)) {
                 pending_chain_tail = true;          // combine + add + next input norm: the first role of the next layer's launch
             } else if (!c.expert_parallel) {
@@ -1854,8 +1902,16 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
             unsigned* cur = m->em2_arrive + (size_t)(launches & 1) * m->arrive_half_words;
             unsigned* nxt = m->em2_arrive + (size_t)((launches & 1) ^ 1) * m->arrive_half_words;
             int took = 0;
+            // (as the step runs it: with the routing taken from the candidate lists the last forward's chain left behind)
+            int Q = m->route_parts;
+            const int tiles = (c.num_experts + 15) / 16;
+            while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
+            MoeRouteLists lists;
+            lists.cand = m->route_cand; lists.stats = m->route_stats; lists.T = T; lists.Q = Q; lists.norm_topk = c.norm_topk_prob;
+            lists.pub_expert_ids = m->expert_ids; lists.pub_expert_w = m->expert_w;
+            const bool defer = knobs().decode_chain && Q > 1 && moe_deferred_merge_ok(m, L, T, Q);
             if (int r_ = w4_gemm_moe_expert_major_pair(L.exp_gate_up, L.exp_down, m->norm_out, m->moe_act, m->moe_down, eids, E, P, c.top_k,
-                                                       cur, nxt, m->inlaunch_timeouts, &took, s)) return r_;
+                                                       cur, nxt, m->inlaunch_timeouts, &took, s, defer ? &lists : nullptr)) return r_;
             if (!took) { fh::set_error("time_kernel: the merged gate_up → down launch does not take these shapes"); return FERRUM_HIP_UNSUPPORTED; }
             return 0;
         }

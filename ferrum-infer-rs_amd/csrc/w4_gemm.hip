@@ -20,6 +20,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "knobs.h"
+#include "route_merge.h"
 #include "w4_device.h"
 
 namespace fh {
@@ -258,21 +259,72 @@ __device__ __forceinline__ void merge_route_candidates(const RouteCand* __restri
     __syncthreads();
 }
 
+// LDS hand-over between the lanes of ONE wave (the other waves of the workgroup are elsewhere) or of the whole workgroup
+template <bool ONE_WAVE>
+__device__ __forceinline__ void lds_sync() {
+    if constexpr (ONE_WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        __syncthreads();
+    }
+}
+
+// The same merge for a handful of tokens (T ≤ 8: decode at c ≤ 8), lane-parallel and without LDS staging: the lists of all
+// tokens are requested at once (one 8-byte load per lane and token pair), every pair of tokens then takes route_merge_pair's
+// 4-probe searches — short enough to sit in the prologue of every workgroup of the gate_up launch (role B of the decode chain
+// then stops at the lists: chain.hip, defer_merge).  Only the publishing workgroup derives the combine weights.  One wave;
+// results in s_ids[t·K + k].  Q ∈ {1, 2, 4}.
+template <bool ONE_WAVE = false>
+__device__ __forceinline__ void merge_route_lists_fast(const RouteCand* __restrict__ cand, const float* __restrict__ stats, int T,
+                                                       int Q, int K, int norm_topk, int* s_ids, bool publish, int32_t* pub_ids,
+                                                       float* pub_w) {
+    const int lane = threadIdx.x & 63;
+    const int half = lane >> 5, li = lane & 31, ncand = Q * 8;
+    const unsigned long long* cg = reinterpret_cast<const unsigned long long*>(cand);
+    const unsigned long long none = (0x7fffffffull << 32) | 0xff800000ull;
+    unsigned long long c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int t = 2 * r + half;
+        c[r] = (t < T && li < ncand) ? cg[t * ncand + li] : none;           // RouteCand {logit, id}: low word logit, high word id
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (2 * r < T) {
+            const int t = 2 * r + half;
+            const bool valid = t < T && li < ncand;
+            int id;
+            const int rank = route_merge_pair(c[r], Q, &id);
+            if (id == 0x7fffffff) id = 0;                                     // (fewer than K experts in all: as merge_route_candidates)
+            const bool keep = valid && rank < K;
+            if (keep) s_ids[t * K + rank] = id;
+            if (publish) {
+                const float ww = route_merge_pair_weight(c[r], rank, valid, stats + (long)(t < T ? t : 0) * Q * 2, Q, K, norm_topk);
+                if (keep) { pub_ids[t * K + rank] = id; pub_w[t * K + rank] = ww; }
+            }
+        }
+    }
+    lds_sync<ONE_WAVE>();
+}
+
 // Align-block-size computed INSIDE the grouped GEMM (P ≤ 1024 pairs) from the per-pair expert ids staged in
 // LDS: LDS histogram, wave scan of the padded counts, ballot compaction — identical result to
 // moe_align_block_size (ascending pair id inside an expert) without the separate ≈8 µs launch.
 // One wave per workgroup.
+template <bool ONE_WAVE = false>
 __device__ __forceinline__ bool inline_align_block(const int* s_ids, int P, int E, int rb, int* s_cnt, int* s_rows,
                                                    int* expert_out, int* total_blocks_out) {
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < E; i += 64) s_cnt[i] = 0;
     if (lane < 16) s_rows[lane] = P;      // sentinel
-    __syncthreads();
+    lds_sync<ONE_WAVE>();
     for (int p = lane; p < P; p += 64) {
         int e = s_ids[p];
         if (e >= 0 && e < E) atomicAdd(&s_cnt[e], 1);
     }
-    __syncthreads();
+    lds_sync<ONE_WAVE>();
     // lane owns experts [8·lane, 8·lane+8): blocks per expert, then an exclusive wave scan
     int nb[8], local = 0;
 #pragma unroll
@@ -312,7 +364,38 @@ __device__ __forceinline__ bool inline_align_block(const int* s_ids, int P, int 
         if (mine && (r >> 4) == j) s_rows[r & 15] = p;
         base += __popcll(bal);
     }
-    __syncthreads();
+    lds_sync<ONE_WAVE>();
+    *expert_out = e_star;
+    return true;
+}
+
+// The align for a handful of tokens routed from candidate lists (P ≤ 64 pairs, E ≤ 128 experts, every expert at most once per
+// token and T ≤ 16 tokens — so one 16-row block per active expert): no histogram, no scan.  The active experts are two 64-bit
+// ballots' worth of presence bits; block rb is the rb-th set bit; its rows are the lanes holding that expert, compacted in
+// ascending pair order — the arrays moe_align_block_size would produce.  One wave, ≈ 0.3 µs instead of inline_align_block's ≈ 1.5.
+template <bool ONE_WAVE = false>
+__device__ __forceinline__ bool align_block_few_pairs(const int* s_ids, int P, int rb, unsigned* s_bits, int* s_rows, int* expert_out,
+                                                      int* total_blocks_out) {
+    const int lane = threadIdx.x & 63;
+    if (lane < 4) s_bits[lane] = 0u;
+    if (lane < 16) s_rows[lane] = P;      // sentinel
+    lds_sync<ONE_WAVE>();
+    const int e = lane < P ? s_ids[lane] : -1;
+    if (e >= 0 && e < 128) atomicOr(&s_bits[e >> 5], 1u << (e & 31));
+    lds_sync<ONE_WAVE>();
+    const unsigned long long lo = ((unsigned long long)s_bits[1] << 32) | s_bits[0], hi = ((unsigned long long)s_bits[3] << 32) | s_bits[2];
+    const int n_lo = __popcll(lo), total = n_lo + __popcll(hi);
+    *total_blocks_out = total;
+    if (rb >= total) return false;
+    // lane l ↔ bit l of the word that holds the rb-th set bit
+    const unsigned long long w = rb < n_lo ? lo : hi;
+    const int want = rb < n_lo ? rb : rb - n_lo;
+    const bool hit = ((w >> lane) & 1ull) && __popcll(w & ((1ull << lane) - 1ull)) == want;
+    const int e_star = (__ffsll((long long)__ballot(hit)) - 1) + (rb < n_lo ? 0 : 64);
+    const bool mine = e == e_star;
+    const unsigned long long bal = __ballot(mine);
+    if (mine) s_rows[__popcll(bal & ((1ull << lane) - 1ull)) & 15] = lane;
+    lds_sync<ONE_WAVE>();
     *expert_out = e_star;
     return true;
 }
@@ -362,7 +445,10 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
             int* s_rows = s_rows_all[KW == 1 ? 0 : wave];
             int* s_cnt = reinterpret_cast<int*>(s_raw);
             const bool publisher = blockIdx.x == 0 && rb == 0 && wave == 0;
-            if (KW == 1 && p.cand) {
+            if (p.cand && p.route_T <= 8 && (p.route_Q == 1 || p.route_Q == 2 || p.route_Q == 4)) {
+                merge_route_lists_fast(p.cand, p.stats, p.route_T, p.route_Q, p.route_K, p.norm_topk, s_ids, publisher,
+                                       p.pub_expert_ids, p.pub_expert_w);
+            } else if (p.cand) {      // (KW = 4: every wave merges on its own slice — ≤ 256 candidates, ≤ 64 pairs; launch_w4 checks)
                 merge_route_candidates(p.cand, p.stats, p.route_T, p.route_Q, p.route_K, p.norm_topk,
                                        reinterpret_cast<RouteCand*>(s_raw), s_ids, publisher, p.pub_expert_ids, p.pub_expert_w);
             } else {
@@ -370,7 +456,9 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
                 __syncthreads();
             }
             int total_blocks;
-            if (!inline_align_block(s_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
+            if (p.cand && p.route_T <= 8 && p.M <= 64 && p.num_experts <= 128) {
+                if (!align_block_few_pairs(s_ids, p.M, rb, reinterpret_cast<unsigned*>(s_cnt), s_rows, &e, &total_blocks)) return;
+            } else if (!inline_align_block(s_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
             id = s_rows[b];
             if (p.pub_sorted_token_ids && blockIdx.x == 0 && wave == 0) {
                 if (threadIdx.x < 16) p.pub_sorted_token_ids[rb * 16 + threadIdx.x] = s_rows[threadIdx.x];
@@ -685,6 +773,10 @@ struct W4Em2Args {
     __half* h;                       // [P, I] gated activations: written and read inside the launch
     __half* out;                     // [P, H] expert outputs
     const int32_t* pair_expert_ids;  // [P]
+    // … or the router's Q candidate lists per token (role B of the decode chain, chain.hip): every workgroup merges them in its
+    // prologue, under its first weight loads; workgroup 0 publishes the merged ids / combine weights for the layer's tail
+    const RouteCand* cand; const float* stats; int route_T, route_Q, norm_topk;
+    int32_t* pub_expert_ids; float* pub_expert_w;
     int P, top_k, E, K, I, H;
     unsigned* arrive;                // [E · EM2_STRIDE] one counter per expert, each on a 256-byte line of its own; zero on entry
     unsigned* arrive_next;           // the same for the launch after this one: zeroed here
@@ -703,7 +795,7 @@ constexpr int EM2_STRIDE = MOE_PAIR_COUNTER_STRIDE;
 #define FH_TL2(i) do {} while (0)
 #endif
 
-template <bool HAS_ZP, bool IS_GU>
+template <bool HAS_ZP, bool IS_GU, bool CAND>
 __device__ __forceinline__ void w4_em2_role(const W4Em2Args& p, int tile, int* s_rows, _Float16* s_out) {
     const int lane = threadIdx.x;
     const int a = lane >> 4, b = lane & 15;
@@ -730,20 +822,66 @@ __device__ __forceinline__ void w4_em2_role(const W4Em2Args& p, int tile, int* s
     FH_TL2(0);
     int ids[16];
     const int P = p.P, chunks = (P + 63) >> 6;
+    if constexpr (!CAND) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) ids[i] = (i < chunks && i * 64 + lane < P) ? p.pair_expert_ids[i * 64 + lane] : -1;
+        for (int i = 0; i < 16; i++) ids[i] = (i < chunks && i * 64 + lane < P) ? p.pair_expert_ids[i * 64 + lane] : -1;
+    }
     issue_w(0, 0);
     if (!IS_GU) issue_w(1, 1);         // (down: G ≥ 2, checked by the launcher) both ring slots are on their way before the wait
     __builtin_amdgcn_sched_barrier(0);
     int n_e = 0;
+    if constexpr (!CAND) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (i < chunks) {
-            const bool mine = ids[i] == e;
-            const unsigned long long bal = __ballot(mine);
-            if (mine) s_rows[n_e + __popcll(bal & ((1ull << lane) - 1ull))] = i * 64 + lane;
-            n_e += __popcll(bal);
+        for (int i = 0; i < 16; i++) {
+            if (i < chunks) {
+                const bool mine = ids[i] == e;
+                const unsigned long long bal = __ballot(mine);
+                if (mine) s_rows[n_e + __popcll(bal & ((1ull << lane) - 1ull))] = i * 64 + lane;
+                n_e += __popcll(bal);
+            }
         }
+    } else {
+        // Candidate mode: lane t looks at token t's Q ≤ 4 lists of 8 (logit, id) pairs.  Is expert e among the token's top-K, and
+        // at which rank?  The merged order is (logit descending, ties → lower id) (merge_route_candidates / router.rs:159-178):
+        // rank = the number of the token's candidates that come before e's.  Pair id = t·K + rank — ascending with the lane, the
+        // order moe_align_block_size produces.  The list of e's own part first (64 bytes per lane); the other parts only for the
+        // lanes that found e there (every workgroup of the launch reads these few KiB: the fewer bytes the better).
+        const int tiles = (p.E + 15) >> 4, EQ = (tiles / p.route_Q) * 16, qe = e / EQ;
+        const bool tok = lane < p.route_T;
+        const u32x4* cg = reinterpret_cast<const u32x4*>(p.cand) + (long)(tok ? lane : 0) * p.route_Q * 4;
+        u32x4 own[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) own[j] = cg[qe * 4 + j];
+        float le = 0.f;
+        int rank = -1;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+                if ((int)own[j][2 * h + 1] == e) { rank = 2 * j + h; le = __uint_as_float(own[j][2 * h]); }      // (a sorted list: the ones before it beat it)
+        const bool found = tok && rank >= 0;
+        if (found) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (q < p.route_Q && q != qe) {
+                    u32x4 o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o[j] = cg[q * 4 + j];
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const float l = __uint_as_float(o[j][2 * h]);
+                            const int id = (int)o[j][2 * h + 1];
+                            rank += (l > le || (l == le && id < e)) ? 1 : 0;
+                        }
+                }
+            }
+        }
+        const bool mine = found && rank < p.top_k;
+        const unsigned long long bal = __ballot(mine);
+        if (mine) s_rows[__popcll(bal & ((1ull << lane) - 1ull))] = lane * p.top_k + rank;
+        n_e = __popcll(bal);
     }
     FH_TL2(1);
     if (n_e == 0) return;
@@ -906,13 +1044,227 @@ __device__ __forceinline__ void w4_em2_role(const W4Em2Args& p, int tile, int* s
 
 // (three waves per SIMD are what keeps all gate_up tiles resident: without the attribute the two inlined roles take 154 + 36
 // registers — two waves per SIMD; with it 168, and one 8-byte spill in the prologue, outside every loop)
-template <bool HAS_ZP>
+template <bool HAS_ZP, bool CAND>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3))) void w4_gemm_moe_em2_kernel(W4Em2Args p) {
-    __shared__ int s_rows[1024];
+    __shared__ __attribute__((aligned(16))) int s_rows[1024];
     __shared__ __attribute__((aligned(16))) _Float16 s_out[16 * 64];     // the tile's output rows, for 16-byte stores
-    const int n_gu = p.gu_n64 * p.E;
-    if ((int)blockIdx.x < n_gu) w4_em2_role<HAS_ZP, true>(p, blockIdx.x, s_rows, s_out);
-    else w4_em2_role<HAS_ZP, false>(p, blockIdx.x - n_gu, s_rows, s_out);
+    const int n_gu = p.gu_n64 * p.E, n_dn = p.dn_n64 * p.E;
+    if ((int)blockIdx.x < n_gu) { w4_em2_role<HAS_ZP, true, CAND>(p, blockIdx.x, s_rows, s_out); return; }
+    if ((int)blockIdx.x < n_gu + n_dn) { w4_em2_role<HAS_ZP, false, CAND>(p, blockIdx.x - n_gu, s_rows, s_out); return; }
+    if constexpr (CAND) {
+        // behind every tile: the merged ids and combine weights of 16 tokens per workgroup, for the layer's tail (the next
+        // launch) — the full merge with the softmax statistics, which the tiles above did not need
+        const int t0 = ((int)blockIdx.x - n_gu - n_dn) * 16, tn = p.route_T - t0 < 16 ? p.route_T - t0 : 16;
+        if (tn <= 0) return;
+        merge_route_candidates(p.cand + (long)t0 * p.route_Q * 8, p.stats + (long)t0 * p.route_Q * 2, tn, p.route_Q, p.top_k, p.norm_topk,
+                               reinterpret_cast<RouteCand*>(s_rows), reinterpret_cast<int*>(s_out), true,
+                               p.pub_expert_ids + t0 * p.top_k, p.pub_expert_w + t0 * p.top_k);
+    }
+}
+
+// ── MoE gate_up (+ silu·mul) → down of a SMALL decode batch (≤ 64 pairs: c ≤ 8) as ONE block-major launch ───────────────
+// Few pairs means few active experts (8 at c = 1): the expert-major grid above would launch 7168 workgroups to find 448 with
+// work, and the two block-major launches it replaces (w4_gemm_kernel MODE 2 / MODE 1) each pay a launch boundary, their own
+// routing prologue and one quant group per memory round trip.  Here the grid is (gate_up tiles + down tiles) × 16-row blocks,
+// block index slowest, so every down tile is dispatched after the gate_up tiles of its block:
+//   * wave 0 of a workgroup derives the routing (the router's candidate lists merged in place — merge_route_lists_fast — or the
+//     pair ids), runs the align, and hands expert + rows to the other three waves through LDS;
+//   * the four waves split K (the same split as w4_gemm_kernel's KW = 4 form: identical partial sums, identical bits) and every
+//     wave has ALL its quant groups in flight at once — the whole 64-KiB tile of a gate_up workgroup — instead of two;
+//   * gate_up tiles write the gated activations with write-through stores, drain, and count an arrival for their block; down
+//     tiles request their weights first, wait for the block's gu_n64 arrivals, then read the activations with sc1 loads
+//     (the hand-off of w4_gemm_moe_em2_kernel, one counter per block on a 256-byte line of its own).
+struct W4Bm2Args {
+    const uint32_t* gu_qw; const __half* gu_sc; const __half* gu_zp; long gu_stride_qw, gu_stride_sc; int gu_G, gu_n64;
+    const uint32_t* dn_qw; const __half* dn_sc; const __half* dn_zp; long dn_stride_qw, dn_stride_sc; int dn_G, dn_n64;
+    const __half* x; __half* h; __half* out;
+    const int32_t* pair_expert_ids;
+    const RouteCand* cand; const float* stats; int route_T, route_Q, norm_topk;
+    int32_t* pub_expert_ids; float* pub_expert_w;
+    int P, top_k, E, K, I, H;
+    unsigned* arrive; unsigned* arrive_next; unsigned* timeout;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    unsigned long long* tl;
+#endif
+};
+#ifdef FERRUM_HIP_EXPERIMENTS
+#define FH_TL3(i) do { if (p.tl && threadIdx.x == 0) p.tl[((long)blockIdx.y * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define FH_TL3(i) do {} while (0)
+#endif
+
+template <bool HAS_ZP>
+__global__ __launch_bounds__(256) void w4_gemm_moe_bm2_kernel(W4Bm2Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[2048];   // align histogram (E ≤ 512 counters)
+    __shared__ int s_ids[64], s_rows[16], s_hdr[2];
+    __shared__ float kred[4][16][64];
+    __shared__ __attribute__((aligned(16))) _Float16 s_out[16 * 64];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int rb = blockIdx.y;
+    const bool is_gu = (int)blockIdx.x < p.gu_n64;
+    const int st = is_gu ? blockIdx.x : blockIdx.x - p.gu_n64;
+    if (blockIdx.x == 0 && threadIdx.x == 0) p.arrive_next[rb * EM2_STRIDE] = 0u;
+    FH_TL3(0);
+    const int P = p.P;
+    if (wave == 0) {
+        // routing and align by ONE wave (wave-level LDS hand-overs); the other three meet it at the barrier below
+        const bool publisher = (int)blockIdx.x == p.gu_n64 && rb == 0;      // a down tile: it waits for its block anyway
+        if (p.cand) {
+            merge_route_lists_fast<true>(p.cand, p.stats, p.route_T, p.route_Q, p.top_k, p.norm_topk, s_ids, publisher,
+                                         p.pub_expert_ids, p.pub_expert_w);
+        } else {
+            if (lane < P) s_ids[lane] = p.pair_expert_ids[lane];
+            lds_sync<true>();
+        }
+        int e0 = 0, total = 0;
+        const bool ok = (p.cand && p.E <= 128)
+                            ? align_block_few_pairs<true>(s_ids, P, rb, reinterpret_cast<unsigned*>(s_raw), s_rows, &e0, &total)
+                            : inline_align_block<true>(s_ids, P, p.E, rb, reinterpret_cast<int*>(s_raw), s_rows, &e0, &total);
+        if (lane == 0) { s_hdr[0] = ok ? e0 : -1; s_hdr[1] = total; }
+    }
+    __syncthreads();
+    const int e = s_hdr[0];
+    FH_TL3(1);
+    if (e < 0) return;
+    const int id = s_rows[b];
+    const bool row_ok = id < P;
+
+    const int G = is_gu ? p.gu_G : p.dn_G;
+    const int g0 = G * wave / 4, g1 = G * (wave + 1) / 4, ng = g1 - g0;                    // this wave's quarter of K (≤ 4 groups)
+    const uint32_t* qw0 = is_gu ? p.gu_qw : p.dn_qw;
+    const __half* sc0 = is_gu ? p.gu_sc : p.dn_sc;
+    const __half* zp0 = is_gu ? p.gu_zp : p.dn_zp;
+    const long sqw = is_gu ? p.gu_stride_qw : p.dn_stride_qw, ssc = is_gu ? p.gu_stride_sc : p.dn_stride_sc;
+    const u32x4* qw_lane = reinterpret_cast<const u32x4*>(qw0 + (long)e * sqw) + ((long)st * G * 4) * 64 + lane;
+    const uint2* sc_lane = reinterpret_cast<const uint2*>(sc0 + (long)e * ssc) + ((long)st * G) * 16 + b;
+    const uint2* zp_lane = HAS_ZP ? reinterpret_cast<const uint2*>(zp0 + (long)e * ssc) + ((long)st * G) * 16 + b : nullptr;
+    u32x4 wq[4][4];
+    uint2 scv[4], zpv[4];
+    half8 af[4][1][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < ng) {
+            const int g = g0 + i;
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) wq[i][nt] = __builtin_nontemporal_load(qw_lane + ((long)g * 4 + nt) * 64);
+            scv[i] = sc_lane[(long)g * 16];
+            if (HAS_ZP) zpv[i] = zp_lane[(long)g * 16];
+        }
+    }
+    float4v acc[1][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) acc[0][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    if (is_gu) {
+        const __half* xrow = p.x + (long)(row_ok ? id / p.top_k : 0) * p.K + 8 * a;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < ng) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) af[i][0][s] = *reinterpret_cast<const half8*>(xrow + (g0 + i) * 128 + 32 * s);
+            }
+    } else {
+        // down: the weights are on their way; now the block's gate_up tiles (bounded wait, ≈ 20 ms of the 100 MHz clock)
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned need = (unsigned)p.gu_n64;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        for (;;) {
+            unsigned c = lane == 0 ? __hip_atomic_load(p.arrive + rb * EM2_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= need) break;
+            __builtin_amdgcn_s_sleep(4);
+            if ((++spins & 255u) == 0u && wall_clock64() - t0 > 2000000ull) {
+                if (lane == 0) __hip_atomic_fetch_add(p.timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        FH_TL3(2);
+        const __amdgpu_buffer_rsrc_t h_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, P * p.I * 2, 0x00020000);
+        const int hoff = row_ok ? (id * p.I + 8 * a) * 2 : 0x7ffffff0 - 8192;      // (no row: past the end — zeros, no request)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (i < ng) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(h_rsrc, hoff + ((g0 + i) * 128 + 32 * s) * 2, 0, 16);   // sc1
+                    af[i][0][s] = __builtin_bit_cast(half8, v);
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        if (i < ng) {
+            const unsigned long long sb = ((unsigned long long)scv[i].y << 32) | scv[i].x;
+            const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[i].y << 32) | zpv[i].x) : 0ull;
+            w4_consume_group<1, 4, HAS_ZP>(wq[i], sb, zb, 0, af[i], acc);
+        }
+    // the four K-quarters meet in LDS; wave 0 adds them in wave order (as w4_gemm_kernel's KW = 4 form) and owns the epilogue
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) kred[wave][nt * 4 + r][lane] = acc[0][nt][r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float s = kred[0][nt * 4 + r][lane];
+#pragma unroll
+            for (int k = 1; k < 4; k++) s += kred[k][nt * 4 + r][lane];
+            acc[0][nt][r] = s;
+        }
+    if (is_gu) {
+        // silu(gate)·up → the 16 × 32 block in LDS → one 16-byte write-through store per lane (row lane/4, 8 columns)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const float gt = acc[0][jj][r], up = acc[0][2 + jj][r];
+                s_out[(4 * a + r) * 32 + jj * 16 + b] = (_Float16)((gt / (1.0f + __expf(-gt))) * up);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int row = lane >> 2, c8 = (lane & 3) * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&s_out[row * 32 + c8]);
+            const int rid = s_rows[row];
+            const int col = st * 32 + c8;
+            if (rid < P && col + 7 < p.I) {
+                const __amdgpu_buffer_rsrc_t hw = __builtin_amdgcn_make_buffer_rsrc(p.h, 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(v, hw, (rid * p.I + col) * 2, 0, 16);      // aux 16 = sc1
+            }
+        }
+        FH_TL3(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(p.arrive + rb * EM2_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        FH_TL3(3);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int nt = 0; nt < 4; nt++) {
+                float v = acc[0][nt][r];
+                asm volatile("" : "+v"(v));           // (f32 → f16 as its own rounding, like every other form; see the em2 epilogue)
+                s_out[(4 * a + r) * 64 + nt * 16 + b] = (_Float16)v;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int row = hh * 8 + (lane >> 3), c8 = (lane & 7) * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&s_out[row * 64 + c8]);
+            const int rid = s_rows[row];
+            const int col = st * 64 + c8;
+            if (rid < P && col + 7 < p.H) *reinterpret_cast<u32x4*>(p.out + (long)rid * p.H + col) = v;
+        }
+#ifdef FERRUM_HIP_EXPERIMENTS
+        if (p.tl) { __builtin_amdgcn_s_waitcnt(0); FH_TL3(3); }
+#endif
+    }
 }
 
 // Sum S fp32 slabs in fixed order → fp16 [M, N] (optionally gathering padded MoE rows).
@@ -2069,12 +2421,12 @@ static int launch_w4(const W4Args& a, int mt, bool has_zp, dim3 grid, hipStream_
 #define FH_W4_CASE(MTV, ZPV)                                                       \
     hipLaunchKernelGGL((w4_gemm_kernel<MTV, ZPV, MODE>), grid, dim3(MODE == 0 ? 256 : 64), 0, stream, a)
     if constexpr (MODE != 0) {
-        // few pairs (decode at c ≤ 8): 4 waves per workgroup split K (see KW); the candidate-merge prologue keeps KW = 1
+        // few pairs (decode at c ≤ 8): 4 waves per workgroup split K (see KW)
         // default 16 pairs, measured on Qwen3-30B-A3B: c=1 + 10 %, c=2 + 5.5 % (756 → 798 tok/s), c=3 ±0, c=4 − 2.7 %, c=8 − 6.5 %.
         // Never beyond 64 pairs: the K-split form keeps its per-wave pair list in 64 LDS slots.
         const int kw_pairs = std::min(knobs().moe_kw_pairs, 64);
         const bool rt = a.cand != nullptr || a.pair_expert_ids != nullptr;      // routing prologue inside the launch (owns LDS)
-        const bool kw4 = a.M <= kw_pairs && a.cand == nullptr && a.G >= 4;
+        const bool kw4 = a.M <= kw_pairs && (a.cand == nullptr || a.route_T * a.route_Q * 8 <= 256) && a.G >= 4;
 #define FH_W4_MOE(ZPV, KWV, RTV) hipLaunchKernelGGL((w4_gemm_kernel<1, ZPV, MODE, KWV, RTV>), grid, dim3(64 * KWV), 0, stream, a)
 #define FH_W4_MOE_ZP(ZPV)                                                                    \
         if (kw4) { if (rt) FH_W4_MOE(ZPV, 4, true); else FH_W4_MOE(ZPV, 4, false); }         \
@@ -2305,15 +2657,28 @@ int w4_gemm_moe_expert_major(const W4Device& w, const __half* x, __half* out, co
 // gate_up (+ silu·mul) and down of a decode batch as ONE launch (w4_gemm_moe_em2_kernel).  `arrive` must be zero on entry;
 // the launch zeroes `arrive_next` (the caller alternates two counter arrays).  *took = 0 when the shapes do not fit the
 // merged form (the caller then runs the two expert-major launches).
+bool w4_gemm_moe_expert_major_pair_supports(const W4Device& gu, const W4Device& dn, int num_experts, int num_valid_pairs,
+                                            const MoeRouteLists* route) {
+    if (num_valid_pairs <= 0) return false;
+    const bool zp = gu.zp != nullptr;
+    if (zp != (dn.zp != nullptr) || dn.G < 2 || !gu.fused_gate_up || gu.n / 2 != dn.k || (gu.n / 2) % 8 != 0 || dn.n % 8 != 0 ||
+        num_valid_pairs > 1024 || num_experts > 65535 || (long)num_valid_pairs * (gu.n / 2) * 2 >= (1L << 31))
+        return false;
+    if (route && (route->T < 1 || route->T > 64 || route->Q < 1 || route->Q > 4 || num_valid_pairs > 512 ||
+                  !route->cand || !route->stats || !route->pub_expert_ids || !route->pub_expert_w))
+        return false;
+    return true;
+}
+
 int w4_gemm_moe_expert_major_pair(const W4Device& gu, const W4Device& dn, const __half* x, __half* h, __half* out,
                                   const int32_t* pair_expert_ids, int num_experts, int num_valid_pairs, int top_k,
-                                  unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream) {
+                                  unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream,
+                                  const MoeRouteLists* route) {
     *took = 0;
     if (num_valid_pairs <= 0) return 0;
     const bool zp = gu.zp != nullptr;
-    if (zp != (dn.zp != nullptr) || dn.G < 2 || !gu.fused_gate_up || gu.n / 2 != dn.k || (gu.n / 2) % 8 != 0 || dn.n % 8 != 0 ||
-        num_valid_pairs > 1024 || num_experts > 65535 || (long)num_valid_pairs * (gu.n / 2) * 2 >= (1L << 31) || !arrive || !arrive_next ||
-        !timeout)
+    if (!w4_gemm_moe_expert_major_pair_supports(gu, dn, num_experts, num_valid_pairs, route) || !arrive || !arrive_next || !timeout ||
+        (!route && !pair_expert_ids))
         return 0;
     W4Em2Args a{};
     a.gu_qw = gu.qw; a.gu_sc = gu.sc; a.gu_zp = gu.zp; a.gu_G = gu.G; a.gu_n64 = gu.n64;
@@ -2321,15 +2686,72 @@ int w4_gemm_moe_expert_major_pair(const W4Device& gu, const W4Device& dn, const 
     a.dn_qw = dn.qw; a.dn_sc = dn.sc; a.dn_zp = dn.zp; a.dn_G = dn.G; a.dn_n64 = dn.n64;
     a.dn_stride_qw = (long)dn.n64 * dn.G * 4 * 64 * 4; a.dn_stride_sc = (long)dn.n64 * dn.G * 16 * 4;
     a.x = x; a.h = h; a.out = out; a.pair_expert_ids = pair_expert_ids;
+    if (route) {
+        a.cand = route->cand; a.stats = route->stats; a.route_T = route->T; a.route_Q = route->Q; a.norm_topk = route->norm_topk;
+        a.pub_expert_ids = route->pub_expert_ids; a.pub_expert_w = route->pub_expert_w;
+    }
     a.P = num_valid_pairs; a.top_k = top_k; a.E = num_experts; a.K = gu.k; a.I = gu.n / 2; a.H = dn.n;
     a.arrive = arrive; a.arrive_next = arrive_next; a.timeout = timeout;
 #ifdef FERRUM_HIP_EXPERIMENTS
     a.tl = g_timeline;
 #endif
-    const dim3 grid((unsigned)((gu.n64 + dn.n64) * num_experts), 1, 1);
+    const dim3 grid((unsigned)((gu.n64 + dn.n64) * num_experts + (route ? (route->T + 15) / 16 : 0)), 1, 1);
     form_hit(FORM_MOE_EXPERT_MAJOR_PAIR);
-    if (zp) hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<true>), grid, dim3(64), 0, stream, a);
-    else hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<false>), grid, dim3(64), 0, stream, a);
+    if (route) {
+        if (zp) hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<true, true>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<false, true>), grid, dim3(64), 0, stream, a);
+    } else {
+        if (zp) hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<true, false>), grid, dim3(64), 0, stream, a);
+        else hipLaunchKernelGGL((w4_gemm_moe_em2_kernel<false, false>), grid, dim3(64), 0, stream, a);
+    }
+    FH_CHECK_LAUNCH();
+    *took = 1;
+    return 0;
+}
+
+// gate_up (+ silu·mul) and down of a small decode batch (≤ 64 pairs) as ONE block-major launch (w4_gemm_moe_bm2_kernel).
+// `arrive` (max_blocks counters, MOE_PAIR_COUNTER_STRIDE words apart) must be zero on entry; the launch zeroes `arrive_next`.
+// `route` hands the routing over as the router's per-part candidate lists (≤ 8 tokens) instead of pair ids.
+bool w4_gemm_moe_block_major_pair_supports(const W4Device& gu, const W4Device& dn, int num_experts, int num_valid_pairs, int max_blocks,
+                                           const MoeRouteLists* route) {
+    if (num_valid_pairs <= 0 || num_valid_pairs > 64 || max_blocks <= 0 || max_blocks > num_experts || num_experts > 512) return false;
+    if ((gu.zp != nullptr) != (dn.zp != nullptr) || !gu.fused_gate_up || gu.n / 2 != dn.k || (gu.n / 2) % 8 != 0 || dn.n % 8 != 0 ||
+        gu.G < 1 || gu.G > 16 || dn.G < 1 || dn.G > 16 || (long)num_valid_pairs * (gu.n / 2) * 2 >= (1L << 31))
+        return false;
+    if (route && (route->T < 1 || route->T > 8 || !(route->Q == 1 || route->Q == 2 || route->Q == 4) || !route->cand || !route->stats ||
+                  !route->pub_expert_ids || !route->pub_expert_w))
+        return false;
+    return true;
+}
+
+int w4_gemm_moe_block_major_pair(const W4Device& gu, const W4Device& dn, const __half* x, __half* h, __half* out,
+                                 const int32_t* pair_expert_ids, int num_experts, int num_valid_pairs, int max_blocks, int top_k,
+                                 unsigned* arrive, unsigned* arrive_next, unsigned* timeout, int* took, hipStream_t stream,
+                                 const MoeRouteLists* route) {
+    *took = 0;
+    if (num_valid_pairs <= 0) return 0;
+    if (!w4_gemm_moe_block_major_pair_supports(gu, dn, num_experts, num_valid_pairs, max_blocks, route) || !arrive || !arrive_next ||
+        !timeout || (!route && !pair_expert_ids))
+        return 0;
+    W4Bm2Args a{};
+    a.gu_qw = gu.qw; a.gu_sc = gu.sc; a.gu_zp = gu.zp; a.gu_G = gu.G; a.gu_n64 = gu.n64;
+    a.gu_stride_qw = (long)gu.n64 * gu.G * 4 * 64 * 4; a.gu_stride_sc = (long)gu.n64 * gu.G * 16 * 4;
+    a.dn_qw = dn.qw; a.dn_sc = dn.sc; a.dn_zp = dn.zp; a.dn_G = dn.G; a.dn_n64 = dn.n64;
+    a.dn_stride_qw = (long)dn.n64 * dn.G * 4 * 64 * 4; a.dn_stride_sc = (long)dn.n64 * dn.G * 16 * 4;
+    a.x = x; a.h = h; a.out = out; a.pair_expert_ids = pair_expert_ids;
+    if (route) {
+        a.cand = route->cand; a.stats = route->stats; a.route_T = route->T; a.route_Q = route->Q; a.norm_topk = route->norm_topk;
+        a.pub_expert_ids = route->pub_expert_ids; a.pub_expert_w = route->pub_expert_w;
+    }
+    a.P = num_valid_pairs; a.top_k = top_k; a.E = num_experts; a.K = gu.k; a.I = gu.n / 2; a.H = dn.n;
+    a.arrive = arrive; a.arrive_next = arrive_next; a.timeout = timeout;
+#ifdef FERRUM_HIP_EXPERIMENTS
+    a.tl = g_timeline;
+#endif
+    const dim3 grid((unsigned)(gu.n64 + dn.n64), (unsigned)max_blocks, 1);
+    form_hit(FORM_MOE_BLOCK_MAJOR_PAIR);
+    if (gu.zp) hipLaunchKernelGGL((w4_gemm_moe_bm2_kernel<true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((w4_gemm_moe_bm2_kernel<false>), grid, dim3(256), 0, stream, a);
     FH_CHECK_LAUNCH();
     *took = 1;
     return 0;

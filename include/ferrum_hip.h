@@ -175,6 +175,15 @@ int ferrum_hip_moe_gemm_phase_expert_major_pair_f16(FerrumHipGptq* gate_up_stack
                                                     const int32_t* expert_ids_per_pair, void* act_out, void* output, int prob_m,
                                                     int num_experts, int top_k, void* stream);
 
+/* The same pair of phases for a SMALL batch (prob_m ≤ 64 pairs: decode at c ≤ 8) as one block-major launch: (gate_up tiles +
+ * down tiles) × 16-row blocks of the align order, four waves per tile splitting K with the whole tile in flight, the down tiles
+ * of a block waiting in the launch for that block's gate_up tiles.  max_blocks ≥ the number of 16-row blocks the routing needs
+ * (≤ num_experts).  Outputs: the bits of ferrum_hip_moe_gemm_phase_inline_align_f16 ×2 for prob_m ≤ 16 (the same K split);
+ * within fp32 summation order of them beyond (those forms do not split K there). */
+int ferrum_hip_moe_gemm_phase_block_major_pair_f16(FerrumHipGptq* gate_up_stack, const FerrumHipGptq* down_stack, const void* input,
+                                                   const int32_t* expert_ids_per_pair, void* act_out, void* output, int prob_m,
+                                                   int num_experts, int top_k, int max_blocks, void* stream);
+
 /* Number of in-launch waits of the stack's merged launches that gave up so far (0 = every hand-off completed; a non-zero
  * count means the outputs of the affected call are invalid — the waits are bounded so that a missing producer never hangs). */
 int ferrum_hip_moe_pair_status(const FerrumHipGptq* gate_up_stack, unsigned* timeouts);

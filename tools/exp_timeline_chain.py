@@ -31,7 +31,7 @@ torch.cuda.synchronize()
 lib.ferrum_hip_debug_set_chain_timeline(None)
 t = tl.cpu().numpy().reshape(-1, 4)
 rh = (c + 15) // 16
-n_a, n_qkv, n_attn, n_o, n_b = c, (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // 64 * rh, c * 4
+n_a, n_qkv, n_attn, n_o, n_b = c, (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // 64 * rh, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
 tot = n_a + n_qkv + n_attn + n_o + n_b
 t = t[:tot]
 t0 = t[:, 0].min()
