@@ -31,7 +31,8 @@ torch.cuda.synchronize()
 lib.ferrum_hip_debug_set_chain_timeline(None)
 t = tl.cpu().numpy().reshape(-1, 4)
 rh = (c + 15) // 16
-n_a, n_qkv, n_attn, n_o, n_b = c, (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // 64 * rh, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
+FUSED = c <= 4 and os.environ.get('FERRUM_HIP_CHAIN_FUSE_TAIL', '1') != '0'
+n_a, n_qkv, n_attn, n_o, n_b = (0 if FUSED else c), (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // 64 * rh, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
 tot = n_a + n_qkv + n_attn + n_o + n_b
 t = t[:tot]
 t0 = t[:, 0].min()
@@ -40,6 +41,7 @@ q = lambda a: "min %6.2f  p50 %6.2f  max %6.2f" % (a.min(), np.percentile(a, 50)
 print(f"decode chain (last of {LAYERS} layers), c={c}: {tot} workgroups")
 o = 0
 for name, n in (("A    tail", n_a), ("qkv  gemm", n_qkv), ("attention", n_attn), ("o    gemm", n_o), ("B   route", n_b)):
+    if n == 0: continue
     u = us[o:o + n]
     u = u[u[:, 3] > u[:, 0]] if name.startswith("B") else u
     print(f"{name} ({n:3d} wgs): entry {q(u[:, 0])} | wait done {q(u[:, 1])} | work done {q(u[:, 2])} | exit {q(u[:, 3])}")
