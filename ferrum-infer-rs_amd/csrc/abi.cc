@@ -43,6 +43,7 @@ void reload_knobs() {
     k.decode_chain = env_int("FERRUM_HIP_DECODE_CHAIN", 1);
     k.moe_deferred_merge = env_int("FERRUM_HIP_MOE_DEFERRED_MERGE", 1);
     k.moe_bm2 = env_int("FERRUM_HIP_MOE_BM2", 0);
+    k.dense_chain = env_int("FERRUM_HIP_DENSE_CHAIN", 1);
     k.w4_tile_min_m = env_int("FERRUM_HIP_W4_TILE_MIN_M", 0);
     k.w4_tile_wgs = env_int("FERRUM_HIP_W4_TILE_WGS", 256);
     k.w4_ldsa = env_int("FERRUM_HIP_W4_LDSA", 1);
@@ -72,7 +73,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk", "gather_columns",
-    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "moe_block_major_pair"};
+    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "dense_chain", "moe_block_major_pair"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 

@@ -66,8 +66,9 @@ struct ChainGemm {
 struct ChainArgs {
     int T, H, nq, nkv;
     // role A: residual' = residual + Σ_k w_k·down_k; norm1 = rms_norm(residual')·ln_in   (absent for the first layer)
-    int has_a, top_k;
+    int has_a, top_k;              // has_a: 0 no tail, 1 MoE combine (down / comb_w / top_k), 2 dense (the down projection's split-K slabs)
     const __half* down; const float* comb_w; const __half* res_in; const __half* ln_in;
+    const float* a_slabs; int a_S; long a_slab_stride; int a_ld;
     float eps;
     __half* res_a;                // residual' — also what role B adds the o projection to
     __half* norm1;                // [T, H]
@@ -151,7 +152,19 @@ __device__ __forceinline__ void chain_role_a(const ChainArgs& p, int row, unsign
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const int i = threadIdx.x + c * 512;
-        if (i < nvec) {
+        if (i < nvec && p.has_a == 2) {
+            // dense model: the MLP's down projection arrives as S fp32 split-K slabs — summed in slab order and rounded like the
+            // fp16 op output (add_rmsnorm_route_kernel<true>, fused.hip), then the residual add
+            float o[8];
+            reduce_slabs8(p.a_slabs + (long)row * p.a_ld + i * 8, p.a_slab_stride, p.a_S, o);
+            half8 rv = *reinterpret_cast<const half8*>(p.res_in + (long)row * H + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + (float)(_Float16)o[j]);
+            store16_sc1(r_res, (int)(((long)row * H + i * 8) * 2), rv);
+            v[c] = rv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
+        } else if (i < nvec) {
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             float wk8[8];
             half8 d8[8];
@@ -541,8 +554,8 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
     }
     constexpr int U = 16;
     const int tiles = (num_experts + 15) >> 4;
-    const int tiles_q = tiles / Q;
-    const int ksplit = tiles_q >= 8 ? 1 : 8 / tiles_q;
+    const int tiles_q = num_experts > 0 ? tiles / Q : 0;              // (dense model: no router, Q = 1)
+    const int ksplit = (tiles_q >= 8 || tiles_q == 0) ? 1 : 8 / tiles_q;
     const int ksteps = H >> 5;
     half8 bw_pre[U];
     bool pre = false;
@@ -598,6 +611,7 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
             }
         }
     }
+    if (num_experts <= 0) { CH_TL(2); CH_TL(3); return; }           // dense model: add + norm only (norm2 / res_b_out written above)
     __syncthreads();
     const int a = lane >> 4, b = lane & 15;
     for (int u = wave; u < tiles_q * ksplit; u += 8) {
@@ -792,8 +806,12 @@ bool decode_chain_supports(const DecodeChainDesc& d) {
     if (d.o->G / 8 != 4) return false;              // (the instantiated forms: o_proj's K slice per wave is four groups)
     if (d.T < 1 || d.T > 32 || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
     if (d.H % 32 != 0 || d.H > 8192 || d.qkv->k != d.H || d.qkv->n != (d.nq + 2 * d.nkv) * 128 || d.o->k != d.nq * 128 || d.o->n != d.H) return false;
+    if (d.E <= 0) {       // dense model: role B is add + norm, role A sums the down projection's slabs
+        if (d.Q != 1 || (d.has_a && (!d.a_slabs || d.a_S < 1 || d.a_ld < d.H))) return false;
+        return (size_t)d.H * 2 + 64 * 4 <= (size_t)CH_SMEM;
+    }
     const int tiles = (d.E + 15) / 16;
-    if (d.E <= 0 || d.E > 0xfff0 || d.Q < 1 || d.Q > 4 || tiles % d.Q != 0 || tiles / d.Q > 8 || d.r_top_k < 1 || d.r_top_k > 8) return false;
+    if (d.E > 0xfff0 || d.Q < 1 || d.Q > 4 || tiles % d.Q != 0 || tiles / d.Q > 8 || d.r_top_k < 1 || d.r_top_k > 8) return false;
     if (d.has_a && (d.top_k < 1)) return false;
     // LDS of role B: the row + the part logits
     const int tiles_q = tiles / d.Q, ksplit = tiles_q >= 8 ? 1 : 8 / tiles_q;
@@ -805,7 +823,8 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     FH_REQUIRE(decode_chain_supports(d), "decode_chain: shapes not taken by the merged form");
     ChainArgs a{};
     a.T = d.T; a.H = d.H; a.nq = d.nq; a.nkv = d.nkv;
-    a.has_a = d.has_a ? 1 : 0; a.top_k = d.top_k; a.down = d.down; a.comb_w = d.comb_w; a.res_in = d.res_in; a.ln_in = d.ln_in;
+    a.has_a = d.has_a ? (d.E > 0 ? 1 : 2) : 0; a.top_k = d.top_k;
+    a.a_slabs = d.a_slabs; a.a_S = d.a_S; a.a_slab_stride = d.a_slab_stride; a.a_ld = d.a_ld; a.down = d.down; a.comb_w = d.comb_w; a.res_in = d.res_in; a.ln_in = d.ln_in;
     a.eps = d.eps; a.res_a = d.res_a; a.norm1 = d.norm1;
     a.qkv = ChainGemm{d.qkv->qw, d.qkv->sc, d.qkv->zp, d.qkv->G, d.qkv->n, d.qkv->k};
     a.qkv_out = d.qkv_out;

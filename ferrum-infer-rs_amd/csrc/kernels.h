@@ -233,6 +233,8 @@ struct DecodeChainDesc {
     bool has_a = false;          // the previous layer's tail runs as the first role (else norm1 / res_a come from an earlier launch)
     int top_k = 0;               // role A: expert rows per token
     const __half* down = nullptr; const float* comb_w = nullptr; const __half* res_in = nullptr; const __half* ln_in = nullptr;
+    // dense model (E == 0): the tail is residual + Σ_slabs of the MLP's down projection [a_S][rows][a_ld] fp32, then the norm
+    const float* a_slabs = nullptr; int a_S = 0; long a_slab_stride = 0; int a_ld = 0;
     float eps = 0.f;
     __half* res_a = nullptr;     // residual after the tail (role A's output, role B's input)
     __half* norm1 = nullptr;     // [T, H] input rows of the q|k|v projection

@@ -28,6 +28,7 @@ struct Knobs {
     // INT4 GEMMs (w4_gemm.hip)
     int moe_kw_pairs = 16;
     int decode_chain = 1;             // MoE decode at ≤ 32 rows: tail + q|k|v + attention + o_proj + route as ONE launch (0 = five launches)
+    int dense_chain = 1;              // dense models at 17–32 rows: the attention half of the layer as the chain launch too (0 = five launches)
     int moe_em2 = 1;                  // decode: gate_up → down as one expert-major launch (0 = two launches)
     int moe_bm2 = 0;                  // decode at ≤ 64 pairs: gate_up → down as one block-major launch — measured slower than the two launches (profiles/r03_moe_bm2_timeline.txt): off
     int moe_deferred_merge = 1;       // decode chain: the grouped GEMM's prologue merges the router's candidate lists (0 = role B does)
@@ -94,6 +95,7 @@ enum Form : int {
     FORM_MOE_EXPERT_MAJOR_PAIR, // gate_up → down in one expert-major launch (in-launch hand-off per expert)
     FORM_DECODE_CHAIN,          // the attention half of a MoE decode layer as one launch (chain.hip)
     FORM_MOE_DEFERRED_MERGE,    // the merged grouped GEMM took the routing as per-part candidate lists and merged them itself
+    FORM_DENSE_CHAIN,           // dense model: tail + q|k|v + attention + o_proj + add/norm as the one chain launch (chain.hip)
     FORM_MOE_BLOCK_MAJOR_PAIR,  // ≤ 64 pairs: gate_up → down in one block-major launch (in-launch hand-off per 16-row block)
     FORM_COUNT
 };

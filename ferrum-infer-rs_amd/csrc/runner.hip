@@ -783,6 +783,16 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
     } else {
         rc |= dev_alloc(&m->gate_up_out, T * 2 * c.intermediate);
         rc |= dev_alloc(&m->act_out, T * (size_t)c.intermediate);
+        // the one-launch attention half of the decode layer (chain.hip) for dense models: ping-pong residual, its two counter halves
+        // (layout as above without the per-expert part) and the give-up word
+        rc |= dev_alloc(&m->residual2, (size_t)64 * H);
+        m->arrive_half_words = (size_t)decode_chain_counter_words();
+        rc |= dev_alloc(&m->route_arrive, (size_t)64 + 2 * m->arrive_half_words + 4);
+        if (!rc) m->em2_arrive = m->route_arrive + 64;
+        if (!rc) {
+            FH_CHECK_HIP(hipHostMalloc((void**)&m->inlaunch_timeouts, 64, hipHostMallocDefault));
+            *m->inlaunch_timeouts = 0u;
+        }
     }
     if (rc) return rc;
     // workspace: split-K slabs (≤ 64 rows) and split-KV attention partials
@@ -1254,7 +1264,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         int Q = m->route_parts;
         const int tiles = (c.num_experts + 15) / 16;
         while (Q > 1 && (tiles % Q != 0 || Q > 8)) Q >>= 1;
-        d.Q = Q;
+        d.Q = c.num_experts > 0 ? Q : 1;
         d.cand = m->route_cand; d.stats = m->route_stats; d.route_arrive = m->route_arrive; d.ids = m->expert_ids; d.weights = m->expert_w;
         d.timeout = m->inlaunch_timeouts;
         return d;
@@ -1266,6 +1276,19 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         if (T * c.top_k > 1024 || c.top_k > 8 || T > 64) return false;
         return decode_chain_supports(chain_desc(li));
     };
+    // dense models at 17–32 rows: the same launch for the attention half (tail of the previous layer's MLP — its down slabs +
+    // residual + norm — q|k|v, attention, o_proj, add + norm), then gate_up slabs → gated activation → down slabs
+    bool pending_dense_tail = false;
+    int tail_S = 0, tail_rows_pad = 0, tail_n_pad = 0;
+    auto dense_chain_ok = [&](int li) {
+        const LayerWeights& L = m->layers[li];
+        if (c.num_experts > 0 || !knobs().decode_chain || !knobs().dense_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts || !m->residual2) return false;
+        if (!sh.all_single_token || !m->fuse_rope_attn || T <= 16 || T > 32 || m->taps_enabled || sandwich || c.tp_world > 1) return false;
+        if (!m->dense_slabs || !L.o.qw || !L.gate_up.qw || !L.down.qw || L.gate_up.perm || L.down.perm || L.qkv.perm || L.o.perm) return false;
+        DecodeChainDesc d = chain_desc(li);
+        d.has_a = false;
+        return decode_chain_supports(d);
+    };
     for (int li = 0; li < c.num_layers; li++) {
         LayerWeights& L = m->layers[li];
         const __half* dummy = L.input_ln;
@@ -1274,6 +1297,35 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         const int32_t* gu_perm = L.gate_up.perm;
         // MoE decode at ≤ 32 rows: [the previous layer's tail] + q|k|v + attention + o_proj + add/norm/route as ONE launch
         // (chain.hip), then the merged gate_up → down launch: two launches per layer instead of seven
+        if (dense_chain_ok(li)) {
+            DecodeChainDesc d = chain_desc(li);
+            d.has_a = pending_dense_tail;
+            d.a_slabs = m->workspace; d.a_S = tail_S; d.a_slab_stride = (long)tail_rows_pad * tail_n_pad; d.a_ld = tail_n_pad;
+            d.cnt = m->em2_arrive + (size_t)m->chain_parity * m->arrive_half_words;
+            d.cnt_next = m->em2_arrive + (size_t)(m->chain_parity ^ 1) * m->arrive_half_words;
+            RUN(decode_chain_f16(d, s));
+            m->chain_parity ^= 1;
+            pending_dense_tail = false;
+            form_hit(FORM_DENSE_CHAIN);
+            const int I = c.intermediate;
+            int S = 0, rows_pad = 0, n_pad = 0;
+            RUN(w4_gemm_dense_slabs_lds(L.gate_up, m->norm_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+            RUN(fused_gated_act_slabs_f16(m->workspace, S, (long)rows_pad * n_pad, n_pad, m->act_out, T, I, c.activation == 1, s));
+            S = 0;
+            RUN(w4_gemm_dense_slabs_lds(L.down, m->act_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+            if (li + 1 < c.num_layers && dense_chain_ok(li + 1)) {
+                pending_dense_tail = true;          // slabs + residual + next input norm: the first role of the next layer's launch
+                tail_S = S; tail_rows_pad = rows_pad; tail_n_pad = n_pad;
+            } else {
+                // (the residual of this layer sits in the ping-pong buffer: the stand-alone tail works on it in place, then it moves back)
+                RUN(fused_add_rms_norm_route_slabs_f16(m->residual2, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad,
+                                                       next_ln ? next_ln : L.input_ln, c.rms_eps, m->norm_out, nullptr, 0, 0, 0, nullptr, nullptr,
+                                                       nullptr, T, H, s, next_qkv_perm));
+                FH_CHECK_HIP(hipMemcpyAsync(m->residual, m->residual2, (size_t)T * H * sizeof(__half), hipMemcpyDeviceToDevice, s));
+                qkv_in_perm = next_ln && next_qkv_perm != nullptr;
+            }
+            continue;
+        }
         if (chain_ok(li)) {
             const int E = c.num_experts, K = c.top_k, P = T * K, sorted_max = P + E * 16;
             const int max_blocks = std::min(sorted_max / 16, P / 16 + std::min(P, E));

@@ -683,6 +683,73 @@ def test_asymmetric_and_act_order_expert_stacks_at_qwen3_dims(pkg, asym, desc_ac
         assert np.array_equal(g[s][free], fed[s + 1][free]), s
 
 
+# ── the same launch for the attention half of a DENSE layer (Llama-style: no q/k norm, no router) ─────────────────────────────
+# Three layers, so that the tail of a layer — the MLP's down projection as split-K slabs + residual + next input norm — runs as the
+# first role of the next layer's launch: oracle-followed rows, the five-launch layer on the same tokens, graph ≡ eager.
+@pytest.mark.parametrize("c", [32, 19])
+def test_dense_decode_chain_across_layers(pkg, c, forms, knobs):
+    from tests import modelgen
+    from oracle import oracle as O
+    tm = modelgen.TinyModel(False, layers=3, hidden=2048, nq=32, nkv=4, hd=128, inter=2048, vocab=2048, seed=53, max_seq_len=64,
+                            qk_norm=False, rope_theta=500000.0)
+    plen, steps = 5, 3
+    followed = sorted({0, c // 2, c - 1})
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    rng = np.random.default_rng(49)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    state = {}
+
+    def drive(chain, check):
+        knobs.set(DENSE_CHAIN=chain)
+        hm = tm.hip_model(pkg, kv_num_blocks=c * 2 + 4, max_seqs=c, max_tokens=max(c * plen, 64))
+        toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        cur = np.array(toks, np.uint32)
+        if check:
+            for oc, i in enumerate(followed):
+                cur[i] = check(f"prefill/{i}", om.forward(oc, prompts[i], 0), lg[i], toks[i])
+        else:
+            cur = state["fed"][0].copy()
+        fed, out = [cur.copy()], []
+        forms.reset()
+        for s in range(steps):
+            toks, lg = hm.unified_forward([(i, [int(cur[i])], plen + s, True) for i in range(c)], greedy=True, want_logits=True)
+            out.append((np.array(toks, np.uint32), lg.copy()))
+            cur = np.array(toks, np.uint32)
+            if check:
+                for oc, i in enumerate(followed):
+                    cur[i] = check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i])
+            else:
+                cur = state["fed"][s + 1].copy()
+            fed.append(cur.copy())
+        return out, fed, forms.hits(), hm
+
+    par = modelgen.Parity(f"dense-chain-c{c}", cos_min=0.999, rel_max=5e-2)
+    out1, fed, hits, hm1 = drive(1, lambda tag, ref, lg, tok: par.check(tag, ref, lg, tok, float("inf")))
+    state["fed"] = fed
+    assert hits.get("decode_chain", 0) == 3 * steps and hits.get("dense_chain", 0) == 3 * steps, hits
+    assert "attn_fused_qkv_wide" not in hits and "dense_slab_chain" not in hits, hits
+    O.set_threads(1)
+    par.finish(max_mismatches=1, max_route_ties=0)
+    graph_ids = hm1.decode_steps(list(range(c)), fed[-1], 4)                      # hipGraph loop from this state …
+    del hm1
+    _, _, _, hm2 = drive(1, None)                                                 # … ≡ single forwards of a second instance
+    cur = fed[-1]
+    for s in range(4):
+        toks, _ = hm2.unified_forward([(i, [int(cur[i])], plen + steps + s, True) for i in range(c)], greedy=True)
+        assert np.array_equal(np.array(toks, np.uint32), graph_ids[s]), s
+        cur = graph_ids[s]
+    del hm2
+    out0, _, hits0, hm0 = drive(0, None)                                          # the five-launch layer on the same tokens
+    assert "decode_chain" not in hits0 and hits0.get("dense_slab_chain", 0) == 3 * steps, hits0
+    for s, ((t1, l1), (t0, l0)) in enumerate(zip(out1, out0)):
+        err = np.abs(l1 - l0).max(axis=1)
+        assert float(err.max()) < 0.02 * float(np.abs(l0).max()), (s, float(err.max()))
+        srt = np.sort(l0, axis=1)
+        for r in np.nonzero(t1 != t0)[0]:
+            assert srt[r, -1] - srt[r, -2] <= 2 * err[r] + 1e-6, (s, int(r))
+
+
 @pytest.mark.parametrize("name", sorted(BENCH_DIMS))
 def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, forms):
     from tests import modelgen
@@ -721,7 +788,11 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
             cur[i] = par.check(f"step{s}/{i}", om.forward(oc, np.array([fed[-1][i]], np.uint32), plen + s), lg[i], toks[i], gap())
         fed.append(cur.copy())
     # decode at c = 32, kv ≈ 260: fused rope + attention with 8 waves, and the 17–32-row chains
-    forms.require(*(("decode_chain", "route_split", "moe_expert_major_pair") if moe else ("attn_fused_qkv_wide", "dense_slab_chain", "w4_slabs_lds")))
+    # (dense Llama-style layers of hidden ≤ 4096: the attention half is the chain launch too; Gemma's sandwich norms and the
+    # 8192-wide rows of Llama-3-70B — eight quant groups per wave of the chain's GEMM roles — keep the slab chain)
+    chain_dense = not moe and not act_order and tm.cfg["hidden"] <= 4096
+    forms.require(*(("decode_chain", "route_split", "moe_expert_major_pair") if moe else
+                    ("decode_chain", "dense_chain", "w4_slabs_lds") if chain_dense else ("attn_fused_qkv_wide", "dense_slab_chain", "w4_slabs_lds")))
     if act_order: forms.require("perm_producer", absent=("gather_columns",))     # decode of a desc_act pack: no gather launch at all
     O.set_threads(1)
     rep = par.finish(max_mismatches=1, max_route_ties=1 if moe else 0)   # 27 followed rows: exact ids, at most one excused row
