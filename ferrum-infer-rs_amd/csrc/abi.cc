@@ -60,6 +60,7 @@ void reload_knobs() {
     k.trace_launches = getenv("FERRUM_HIP_TRACE_LAUNCHES") != nullptr && k.no_graph;
     k.time_same_layer = getenv("FERRUM_HIP_TIME_SAME_LAYER") != nullptr;
     k.tp_oneshot = env_int("FERRUM_HIP_TP_ONESHOT", -1);
+    k.tp_fused_norm = env_int("FERRUM_HIP_TP_FUSED_NORM", 1);
     g_knobs = k;
 }
 namespace { struct KnobsInit { KnobsInit() { reload_knobs(); } } g_knobs_init; }
@@ -73,7 +74,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk", "gather_columns",
-    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "dense_chain", "moe_block_major_pair"};
+    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "dense_chain", "tp_allreduce_norm_fused", "moe_block_major_pair"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 

@@ -48,6 +48,7 @@ struct Knobs {
     bool no_graph = false;
     bool trace_launches = false;
     bool time_same_layer = false;
+    int tp_fused_norm = 1;            // tensor parallel, one-shot transport: all-reduce + residual add + norm as one launch (0 = two)
     int tp_oneshot = -1;              // -1 auto, 0 never, 1 always (tensor-parallel all-reduce form)
 };
 
@@ -96,6 +97,7 @@ enum Form : int {
     FORM_DECODE_CHAIN,          // the attention half of a MoE decode layer as one launch (chain.hip)
     FORM_MOE_DEFERRED_MERGE,    // the merged grouped GEMM took the routing as per-part candidate lists and merged them itself
     FORM_DENSE_CHAIN,           // dense model: tail + q|k|v + attention + o_proj + add/norm as the one chain launch (chain.hip)
+    FORM_TP_ALLREDUCE_NORM_FUSED, // tensor parallel: one-shot all-reduce + residual add + norm as one launch
     FORM_MOE_BLOCK_MAJOR_PAIR,  // ≤ 64 pairs: gate_up → down in one block-major launch (in-launch hand-off per 16-row block)
     FORM_COUNT
 };

@@ -251,6 +251,19 @@ int tp_all_reduce(FerrumHipModel* m, __half* buf, size_t count) {
     FH_REQUIRE(m->comm, "tensor parallel: no communicator (ferrum_hip_model_tp_init / ferrum_hip_model_set_comm)");
     return comm_all_reduce_f16(m->comm, buf, count, m->stream);
 }
+
+// residual += all_reduce(x); out = rms_norm(residual)·w (tp_decode.rs:350-372 + the layer's add + norm): ONE launch where the
+// one-shot transport carries the message, else the all-reduce and fused_add_rms_norm_f16 — the same bits either way.
+int tp_all_reduce_add_rms_norm(FerrumHipModel* m, __half* x, __half* residual, const __half* w, float eps, __half* out, int T, int H,
+                               hipStream_t s, const int32_t* out_perm) {
+    if (m->cfg.tp_world > 1 && !m->tp_loopback && m->comm && !out_perm) {
+        int fused = 0;
+        if (int rc = comm_all_reduce_add_rms_norm_f16(m->comm, x, residual, w, eps, out, T, H, &fused, s)) return rc;
+        if (fused) return 0;
+    }
+    if (int rc = tp_all_reduce(m, x, (size_t)T * H)) return rc;
+    return fused_add_rms_norm_f16(residual, x, w, eps, out, T, H, s, out_perm);
+}
 }  // namespace
 
 static void drop_graph(FerrumHipModel* m) {
@@ -1535,11 +1548,11 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 form_hit(FORM_DENSE_SLAB_CHAIN);
                 if (tp) {
                     RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
-                    RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                     if (sandwich) {
+                        RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                         RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
                     } else {
-                        RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
+                        RUN(tp_all_reduce_add_rms_norm(m, m->o_out, m->residual, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
                     }
                 } else {
                 if (L.o.perm) form_hit(FORM_PERM_PRODUCER);
@@ -1560,12 +1573,13 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 S = 0;
                 if (tp) {
                     RUN(dense_linear(m, L.down, m->act_out, m->mlp_out, T, s));
-                    RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
                     if (sandwich) {
+                        RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
                         RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
                     } else if (next_ln) {
-                        RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
+                        RUN(tp_all_reduce_add_rms_norm(m, m->mlp_out, m->residual, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
                     } else {
+                        RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
                         RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
                     }
                 } else {
@@ -1583,12 +1597,12 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 qkv_in_perm = next_qkv_perm != nullptr;
             } else {
             RUN(dense_linear(m, L.o, m->attn_out, m->o_out, T, s, attn_perm));
-            RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
             if (sandwich) {
+                RUN(tp_all_reduce(m, m->o_out, (size_t)T * H));
                 // Gemma 3 (llama_family.rs:3357-3421): residual += norm(o, post_attention_layernorm); pre-MLP norm
                 RUN(sandwich_add_rms_norm_f32(m->o_out, L.post_attn_ln, m->residual_f32, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
             } else {
-                RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
+                RUN(tp_all_reduce_add_rms_norm(m, m->o_out, m->residual, L.post_ln, c.rms_eps, m->norm_out, T, H, s, gu_perm));
             }
             RUN(dense_linear(m, L.gate_up, m->norm_out, m->gate_up_out, T, s, true));
             if (c.activation == 1) {
@@ -1597,13 +1611,14 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                 RUN(fused_silu_mul_split_f16(m->gate_up_out, m->act_out, T, I, s));
             }
             RUN(dense_linear(m, L.down, m->act_out, m->mlp_out, T, s));
-            RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
             if (sandwich) {
+                RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
                 // residual += norm(mlp_out, post_feedforward_layernorm); next layer's input norm rides along
                 RUN(sandwich_add_rms_norm_f32(m->mlp_out, L.post_ffn_ln, m->residual_f32, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
             } else if (next_ln) {
-                RUN(fused_add_rms_norm_f16(m->residual, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
+                RUN(tp_all_reduce_add_rms_norm(m, m->mlp_out, m->residual, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm));
             } else {
+                RUN(tp_all_reduce(m, m->mlp_out, (size_t)T * H));
                 RUN(add_inplace_f16(m->residual, m->mlp_out, (long)T * H, s));
             }
             qkv_in_perm = next_ln && next_qkv_perm != nullptr;

@@ -160,6 +160,135 @@ __global__ __launch_bounds__(256) void tp_oneshot_all_reduce_kernel(OneShotArgs 
     }
 }
 
+// One-shot all-reduce FOLDED INTO ITS CONSUMER (tp_decode.rs:350-372 runs all-reduce, then the residual add + norm of the layer,
+// as two launches): one 256-thread block per token row sends the row's partial, waits for the peers' flags with the norm weights
+// already requested, sums the `world` partials in rank order (fp32, one rounding — the all-reduce's output bits), adds the
+// residual, and normalises: residual' = residual + Σ_r x_r, out = rms_norm(residual')·w.  Same flags, parity, epoch and tickets
+// as the all-reduce above; same thread ↔ element mapping and reduction order as rms_norm_kernel<true, ·> (norm.hip), so the
+// result is the two launches' bit for bit.
+struct OneShotNormArgs {
+    OneShotArgs r;              // in = this rank's partial [rows, dim]; out unused
+    __half* residual;           // [rows, dim] in / out
+    const __half* w;            // [dim]
+    __half* norm_out;           // [rows, dim]
+    float eps;
+    int dim;
+};
+
+template <int CHUNKS>
+__global__ __launch_bounds__(256) void tp_oneshot_reduce_add_norm_kernel(OneShotNormArgs q) {
+    const OneShotArgs& a = q.r;
+    __shared__ float smem[4];
+    __shared__ int timed_out;
+    const int tid = threadIdx.x, nb = gridDim.x;
+    const long row = blockIdx.x;
+    const int dim = q.dim, nvec = dim >> 3;
+    const unsigned epoch = __hip_atomic_load(&a.state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int parity = (int)(epoch & 1u);
+    const unsigned token = epoch + 1u;
+    // stage 1: this row of my partial → my comm buffer (write-through, system scope)
+    {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.in + row * dim);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(a.peers[a.rank] + ONESHOT_FLAG_BYTES + (size_t)parity * a.parity_bytes) + row * (dim >> 2);
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++) {
+            const int i = tid + c * 256;
+            if (i < nvec) {
+                __hip_atomic_store(&dst[2 * i], src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&dst[2 * i + 1], src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+    // requested before the wait: the row's residual and norm weights
+    half8 rv[CHUNKS], wv[CHUNKS];
+#pragma unroll
+    for (int c = 0; c < CHUNKS; c++) {
+        const int i = tid + c * 256;
+        if (i < nvec) {
+            rv[c] = *reinterpret_cast<const half8*>(q.residual + row * dim + i * 8);
+            wv[c] = *reinterpret_cast<const half8*>(q.w + i * 8);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        timed_out = 0;
+        const unsigned t = __hip_atomic_fetch_add(&a.state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)nb - 1) {
+            __hip_atomic_store(&a.state[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int p = 0; p < a.world; p++)
+                __hip_atomic_store(oneshot_flag(a.peers[p], parity, a.rank), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    if (tid < a.world) {
+        const unsigned* f = oneshot_flag(a.peers[a.rank], parity, tid);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != token) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > ONESHOT_SPIN_TICKS) { timed_out = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    }
+    __syncthreads();
+    if (!timed_out) {
+        float ss = 0.f;
+        half8 v[CHUNKS];
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++) {
+            const int i = tid + c * 256;
+            if (i < nvec) {
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int p = 0; p < a.world; p++) {
+                    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(a.peers[p] + ONESHOT_FLAG_BYTES + (size_t)parity * a.parity_bytes) + row * (dim >> 2);
+                    const unsigned long long lo = __hip_atomic_load(&src[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const unsigned long long hi = __hip_atomic_load(&src[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    const half4 hl = __builtin_bit_cast(half4, lo), hh = __builtin_bit_cast(half4, hi);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { acc[j] += (float)hl[j]; acc[4 + j] += (float)hh[j]; }
+                }
+                half8 r = rv[c];
+#pragma unroll
+                for (int j = 0; j < 8; j++) r[j] = (_Float16)((float)r[j] + (float)(_Float16)acc[j]);     // (the all-reduce's fp16 output, then the add)
+                *reinterpret_cast<half8*>(q.residual + row * dim + i * 8) = r;
+                v[c] = r;
+#pragma unroll
+                for (int j = 0; j < 8; j++) ss += (float)r[j] * (float)r[j];
+            }
+        }
+        // block_reduce_sum_256 of norm.hip: wave sums, then the four partials in wave order
+        ss = wave_reduce_sum(ss);
+        if ((tid & 63) == 0) smem[tid >> 6] = ss;
+        __syncthreads();
+        const float total = smem[0] + smem[1] + smem[2] + smem[3];
+        const float inv = 1.0f / sqrtf(total / (float)dim + q.eps);
+#pragma unroll
+        for (int c = 0; c < CHUNKS; c++) {
+            const int i = tid + c * 256;
+            if (i < nvec) {
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = (_Float16)((float)v[c][j] * inv * (float)wv[c][j]);
+                *reinterpret_cast<half8*>(q.norm_out + row * dim + i * 8) = o;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (timed_out) {
+            __hip_atomic_fetch_add(&a.state[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (a.timeouts_host) __hip_atomic_fetch_add(a.timeouts_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const unsigned t = __hip_atomic_fetch_add(&a.state[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (unsigned)nb - 1) {
+            __hip_atomic_store(&a.state[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.state[0], epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // One-shot all-gather of a small record per rank (≤ 64 KB; the per-row argmax pairs of a vocabulary-parallel lm_head): the
 // same buffers, flags, parity and epoch as the all-reduce above (one block, so it is its own last arriver).
 __global__ __launch_bounds__(256) void tp_oneshot_all_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long bytes,
@@ -256,6 +385,26 @@ int comm_all_reduce_f16(FerrumHipComm* c, __half* buf, size_t count, hipStream_t
     const int rc = g_all_reduce(buf, buf, count, 6, 0, c->nccl, s);
     FH_REQUIRE(rc == 0, "ncclAllReduce failed: %d", rc);
     form_hit(FORM_TP_ALLREDUCE_RCCL);
+    return 0;
+}
+
+// residual += Σ_ranks x; norm_out = rms_norm(residual)·w — the all-reduce and its consumer as ONE launch where the one-shot
+// transport carries the message (rows ≤ 64, dim ≤ 8192); *fused = 0 otherwise (the caller then runs all-reduce + add + norm).
+int comm_all_reduce_add_rms_norm_f16(FerrumHipComm* c, const __half* x, __half* residual, const __half* w, float eps, __half* norm_out,
+                                     int rows, int dim, int* fused, hipStream_t s) {
+    *fused = 0;
+    if (!c || c->world <= 1 || rows <= 0) return 0;
+    if (!knobs().tp_fused_norm || rows > ONESHOT_MAX_BLOCKS || dim % 8 != 0 || dim > 8 * 256 * 4 || !comm_oneshot_fits(c, (size_t)rows * dim)) return 0;
+    OneShotNormArgs q{};
+    q.r = OneShotArgs{x, nullptr, (long)rows * dim, c->peers_dev, c->state, c->timeouts_host, (long)c->parity_bytes, c->world, c->rank};
+    q.residual = residual; q.w = w; q.norm_out = norm_out; q.eps = eps; q.dim = dim;
+    const int chunks = cdiv(dim / 8, 256);
+    if (chunks <= 1) hipLaunchKernelGGL((tp_oneshot_reduce_add_norm_kernel<1>), dim3(rows), dim3(256), 0, s, q);
+    else if (chunks <= 2) hipLaunchKernelGGL((tp_oneshot_reduce_add_norm_kernel<2>), dim3(rows), dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((tp_oneshot_reduce_add_norm_kernel<4>), dim3(rows), dim3(256), 0, s, q);
+    FH_CHECK_LAUNCH();
+    form_hit(FORM_TP_ALLREDUCE_NORM_FUSED);
+    *fused = 1;
     return 0;
 }
 
@@ -437,6 +586,14 @@ int ferrum_hip_all_reduce_f16(FerrumHipComm* c, void* buf, size_t count, void* s
     FH_REQUIRE(buf || count == 0, "all_reduce: null buffer");
     return comm_all_reduce_f16(c, (__half*)buf, count, as_stream(stream));
 }
+int ferrum_hip_all_reduce_add_rms_norm_f16(FerrumHipComm* c, const void* x, void* residual, const void* w, float eps, void* norm_out,
+                                           int rows, int dim, int* fused, void* stream) {
+    FH_REQUIRE(fused && (rows == 0 || (x && residual && w && norm_out)), "all_reduce_add_rms_norm: null argument");
+    return comm_all_reduce_add_rms_norm_f16(c, reinterpret_cast<const __half*>(x), reinterpret_cast<__half*>(residual),
+                                            reinterpret_cast<const __half*>(w), eps, reinterpret_cast<__half*>(norm_out), rows, dim, fused,
+                                            as_stream(stream));
+}
+
 // BackendCollective::all_gather / broadcast (capabilities.rs:95-108): RCCL ranks only.
 int ferrum_hip_all_gather_f16(FerrumHipComm* c, const void* local, void* global, size_t local_count, void* stream) {
     if (!c || c->world <= 1) {

@@ -202,6 +202,14 @@ class Comm:
         ptr = C.c_void_p(buf.data_ptr()) if hasattr(buf, "data_ptr") else buf
         _check(self.lib.ferrum_hip_all_reduce_f16(self.h, ptr, C.c_size_t(count), stream), "all_reduce")
 
+    def all_reduce_add_rms_norm(self, x, residual, w, eps, norm_out, rows, dim, stream):
+        """residual += all_reduce(x); norm_out = rms_norm(residual)·w as ONE launch (one-shot transport); False when not taken."""
+        fused = C.c_int(0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _check(self.lib.ferrum_hip_all_reduce_add_rms_norm_f16(self.h, p(x), p(residual), p(w), C.c_float(eps), p(norm_out), rows, dim,
+                                                               C.byref(fused), stream), "all_reduce_add_rms_norm")
+        return bool(fused.value)
+
     def destroy(self):
         if self.h:
             self.lib.ferrum_hip_comm_destroy(self.h)

@@ -612,6 +612,12 @@ int ferrum_hip_comm_destroy(FerrumHipComm* comm);
 int ferrum_hip_comm_world_size(const FerrumHipComm* comm);          /* BackendCollective::world_size (NULL comm: 1) */
 int ferrum_hip_comm_rank(const FerrumHipComm* comm);                /* BackendCollective::rank */
 int ferrum_hip_all_reduce_f16(FerrumHipComm* comm, void* buf, size_t count, void* stream);   /* ReduceOp::Sum, in place */
+/* The all-reduce folded into its consumer (cuda/tp_decode.rs:350-372 runs all_reduce, then the layer's residual add + norm):
+ * residual[rows, dim] += Σ_ranks x; norm_out = rms_norm(residual)·w, ONE launch where the one-shot transport carries the
+ * message (rows ≤ 64, dim ≤ 8192) — bit for bit ferrum_hip_all_reduce_f16 followed by ferrum_hip_fused_add_rms_norm_f16.
+ * *fused = 0: nothing was done (RCCL transport, message too large, …) and the caller runs the two calls. */
+int ferrum_hip_all_reduce_add_rms_norm_f16(FerrumHipComm* comm, const void* x, void* residual, const void* w, float eps,
+                                           void* norm_out, int rows, int dim, int* fused, void* stream);
 int ferrum_hip_all_gather_f16(FerrumHipComm* comm, const void* local, void* global, size_t local_count, void* stream);
 int ferrum_hip_broadcast_f16(FerrumHipComm* comm, void* buf, size_t count, int src_rank, void* stream);
 /* Runner side: an RCCL rank owned by the model, or a communicator of the caller's. */

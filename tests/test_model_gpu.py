@@ -1442,6 +1442,51 @@ def test_kv_admission_contract(pkg):
         hm.unified_forward([(2, [1], 5, True)])
 
 
+def test_tp2_one_shot_all_reduce_folded_into_add_norm(pkg, forms, knobs):
+    """Tensor-parallel decode of a Llama-style model (plain residual add + norm behind o_proj and down_proj, tp_decode.rs:350-372)
+    over the one-shot transport between two in-process ranks: the all-reduce and its add + norm consumer run as ONE launch
+    (tp_oneshot_reduce_add_norm_kernel).  Bit for bit the two-launch form (knob off), on both ranks, eager prefill and the
+    per-rank decode hipGraph; ids against the unsharded model."""
+    from tests import modelgen
+    tm = modelgen.TinyModel(False, layers=3, hidden=1024, nq=8, nkv=4, hd=128, inter=2048, vocab=2048, seed=57, max_seq_len=64,
+                            qk_norm=False, rope_theta=500000.0)
+    world, c, plen, steps = 2, 18, 4, 6
+    mk = dict(kv_num_blocks=c + 4, max_seqs=c, max_tokens=c * plen)
+    rng = np.random.default_rng(58)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    ids = list(range(c))
+
+    def drive(_r, m):
+        toks, lg = m.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        return np.array(toks), lg.copy(), m.decode_steps(ids, toks, steps)
+
+    ref = drive(0, tm.hip_model(pkg, **mk))
+    runs = {}
+    for fused in (1, 0):
+        knobs.set(TP_FUSED_NORM=fused, TP_ONESHOT=1)
+        ranks = _tp_rank_models(pkg, tm, world, **mk)
+        comms = pkg.Comm.local_group(world, 4 << 20)
+        for m, cm in zip(ranks, comms):
+            m.set_comm(cm)
+        forms.reset()
+        runs[fused] = _run_ranks(ranks, drive)
+        h = forms.require("tp_allreduce_oneshot", "graph_replay", absent=("tp_allreduce_rccl", "tp_allreduce_loopback"))
+        assert (h.get("tp_allreduce_norm_fused", 0) > 0) == bool(fused), h
+        for cm in comms:
+            st = cm.oneshot_status()
+            assert st["timeouts"] == 0 and st["epoch"] > 0, st
+        del ranks
+    for r in range(world):
+        for a_, b_ in zip(runs[1][r], runs[0][r]):
+            assert np.array_equal(a_, b_), r                     # one launch ≡ all-reduce + add + norm, bit for bit
+        for a_, b_ in zip(runs[1][0], runs[1][r]):
+            assert np.array_equal(a_, b_), r                     # ranks agree bit for bit
+    for i in range(c):
+        assert modelgen.cosine(ref[1][i], runs[1][0][1][i]) > 0.9999
+    same = sum(int(np.array_equal(ref[2][:, i], runs[1][0][2][:, i]) and ref[0][i] == runs[1][0][0][i]) for i in range(c))
+    assert same >= c - 1, same
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_multi_process_tensor_parallel_rehearsal_over_hipipc(pkg, world):
     """The multi-process tensor-parallel path end to end on ONE GPU (tools/tp_rehearsal.py under torch.distributed.run, gloo
@@ -1468,6 +1513,9 @@ def test_multi_process_tensor_parallel_rehearsal_over_hipipc(pkg, world):
     line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["world"] == world and d["all_reduce"]["bit_exact"] and d["all_reduce"]["timeouts"] == 0
+    # the all-reduce folded into the residual add + norm: one launch ≡ the two, bit for bit, and it is what the decode graph ran
+    assert d["all_reduce"]["fused_norm_bit_exact"] and d["all_reduce"]["fused_norm_calls"] == 6
+    assert d["forms"].get("tp_allreduce_norm_fused", 0) > 0, d["forms"]
     tp = d["tp_decode"]
     assert tp["tp"] == world and tp["ranks_agree_on_ids"] and tp["oneshot_timeouts"] == 0 and tp["oneshot_epochs"] > 0, tp
     assert tp["per_rank_shapes"]["num_kv_heads"] == 8 // world and tp["tok_s"] > 0

@@ -69,9 +69,27 @@ def main():
             got = t.cpu().numpy()
             assert np.array_equal(got.view(np.uint16), ref.view(np.uint16)), (rank, it, n, float(np.max(np.abs(got.astype(np.float32) - ref.astype(np.float32)))))
             calls += 1
+        # 1b. the all-reduce folded into its consumer (residual add + norm): one launch ≡ all_reduce → fused_add_rms_norm, bit for bit
+        fused_calls = 0
+        for it, (rows, dim) in enumerate([(1, 1024), (20, 4096), (32, 8192), (64, 5376), (7, 2048), (32, 4096)]):
+            x = torch.from_numpy((rng.standard_normal((rows, dim)) * (1 + rank)).astype(np.float16)).cuda()
+            g = np.random.default_rng(7000 + it)                  # residual and weights: the same on every rank
+            res0 = torch.from_numpy(g.standard_normal((rows, dim)).astype(np.float16)).cuda()
+            w = torch.from_numpy((1 + 0.1 * g.standard_normal(dim)).astype(np.float16)).cuda()
+            res_a, out_a = res0.clone(), torch.empty_like(res0)
+            took = comm.all_reduce_add_rms_norm(x, res_a, w, 1e-6, out_a, rows, dim, ctx.stream)
+            assert took, (rows, dim)
+            xr, res_b, out_b = x.clone(), res0.clone(), torch.empty_like(res0)
+            comm.all_reduce(xr, rows * dim, ctx.stream)
+            B.fused_add_rms_norm(ctx, res_b, xr, w, 1e-6, out_b, rows, dim)
+            ctx.sync()
+            assert torch.equal(res_a, res_b) and torch.equal(out_a, out_b), (rank, rows, dim)
+            fused_calls += 1
+            calls += 2
     st = comm.oneshot_status()
     assert st["timeouts"] == 0 and st["epoch"] == calls, st
-    out["all_reduce"] = {"calls": calls, "epoch": st["epoch"], "timeouts": st["timeouts"], "bit_exact": True}
+    out["all_reduce"] = {"calls": calls, "epoch": st["epoch"], "timeouts": st["timeouts"], "bit_exact": True,
+                         "fused_norm_calls": fused_calls, "fused_norm_bit_exact": True}
     comm.destroy()
     dist.barrier()
 
@@ -80,6 +98,13 @@ def main():
                                c=int(os.environ.get("FERRUM_REHEARSAL_C", "20")), PL=48, steps=8, warm=2, chunk=96,
                                try_oneshot=False, transport="oneshot", layers=int(os.environ.get("FERRUM_REHEARSAL_LAYERS", "3")))
     out["tp_decode"] = res
+    lib = pkg.load_library()
+    import ctypes as C
+    lib.ferrum_hip_debug_form_name.restype = C.c_char_p
+    nforms = lib.ferrum_hip_debug_form_count()
+    arr = (C.c_uint64 * nforms)()
+    lib.ferrum_hip_debug_form_hits(arr, nforms)
+    out["forms"] = {lib.ferrum_hip_debug_form_name(i).decode(): int(arr[i]) for i in range(nforms) if arr[i]}
     # 3. the MoE model as one expert-parallel group (experts sharded, partial MoE outputs all-reduced)
     if 128 % world == 0:
         out["ep_decode"] = bench.tp_decode_case(pkg, torch, dist, "qwen3-30b-a3b", world, rank, c=16, PL=48, steps=8, warm=2, chunk=96,
