@@ -551,7 +551,7 @@ def main():
                 us, blocks = model.time_kernel("moe_pair", c, kv_end, reps=3)
                 b = moe_gemm_bytes(cfg, blocks, c, "moe_gate_up") + moe_gemm_bytes(cfg, blocks, c, "moe_down")
                 kernels["moe_pair"] = {"avg_us": round(us, 2), "expert_blocks": blocks, "bytes": b, "gbs": round(b / us / 1e3, 1)}
-                dom, dom_name = kernels["moe_pair"], "w4_gemm_moe_em2_kernel<false, true> (MoE gate_up + silu*mul -> down INT4 grouped GEMMs, one expert-major launch)"
+                dom, dom_name = kernels["moe_pair"], "w4_gemm_moe_em2_kernel<false, false> (MoE gate_up + silu*mul -> down INT4 grouped GEMMs, one expert-major launch)"
                 traffic_file = "pmc_traffic_moe_pair.json"
             except Exception as e:       # batches that do not take the merged form (c < 32): the two-launch kernels above stand
                 kernels["moe_pair"] = {"unavailable": str(e)[:120]}

@@ -16,3 +16,24 @@ for mode in ("graph", "eager"):
     b = hm.decode_steps(list(range(8)), a[-1], 300)     # second run: graph reuse with a different kv bucket
     outs.append(np.concatenate([a, b]))
 print("graph == eager over 600 steps:", np.array_equal(outs[0], outs[1]), outs[0].shape)
+
+# the merged launches (decode chain + one-launch MoE pair) at Qwen3-30B-A3B dims, three layers, c = 32 and c = 3: two fresh
+# instances per mode sample the same 96 ids per row, graph ≡ eager — in-launch hand-offs leave no run-to-run freedom
+import bench
+for c in (32, 3):
+    cfg = dict(bench.QWEN3_30B_A3B)
+    cfg["vocab"] = 4096
+    runs = []
+    for mode in ("graph", "graph", "eager"):
+        if mode == "eager": os.environ["FERRUM_HIP_NO_GRAPH"] = "1"
+        else: os.environ.pop("FERRUM_HIP_NO_GRAPH", None)
+        model = bench.build_model(pkg, cfg, c, 64 + 128, c * 64, 1234, layers=3)
+        r2 = np.random.default_rng(77)
+        pr = [r2.integers(256, 4096, size=64).astype(np.uint32) for _ in range(c)]
+        first = bench.prefill(model, pr, 0, c * 64)
+        a = model.decode_steps(list(range(c)), np.array(first, np.uint32), 48)
+        b = model.decode_steps(list(range(c)), a[-1], 48)
+        runs.append(np.concatenate([a, b]))
+        del model
+    print(f"merged launches, c={c}: repeat identical {np.array_equal(runs[0], runs[1])}, graph == eager {np.array_equal(runs[0], runs[2])}", runs[0].shape)
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
