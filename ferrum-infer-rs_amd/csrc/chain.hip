@@ -51,7 +51,8 @@ constexpr int CH_QKV_SLOT = 56, CH_QKV_R = 4;                           // q|k|v
 constexpr int CH_MAX_KVH = 16;
 constexpr int CH_SLOTS = CH_QKV_SLOT + CH_QKV_R * CH_MAX_KVH;
 constexpr int CH_GRAN = 10;              // granules per (token, router part): 8 candidates + max + Σexp
-constexpr int CH_GRAN_WORDS = 32 * 4 * CH_GRAN * 2;      // T ≤ 32 tokens × Q ≤ 4 parts, 8-byte granules
+constexpr int CH_MAX_T = 64;
+constexpr int CH_GRAN_WORDS = CH_MAX_T * 4 * CH_GRAN * 2;      // T ≤ 64 tokens × Q ≤ 4 parts, 8-byte granules
 constexpr int CH_SMEM = 8 * 16 * (128 + 4) * 4 + 2 * 8 * 16 * 4 + 16 * 128 * 2 + 2 * 128 * 2;     // the attention role's arena: 73,216 B
 
 constexpr int CH_QKV_NST = 2, CH_O_NST = 1;     // 64-column supertiles per workgroup: one head (128 columns) for q|k|v, 64 columns for o_proj; 16 rows each
@@ -800,11 +801,11 @@ int decode_chain_counter_words() { return CH_SLOTS * CH_STRIDE + CH_GRAN_WORDS; 
 bool decode_chain_supports(const DecodeChainDesc& d) {
     const auto gemm_ok = [](const W4Device& w) {
         return w.qw && !w.zp && !w.perm && !w.bias && !w.f16t && w.G % 8 == 0 && (w.G / 8 == 2 || w.G / 8 == 4) && w.n % 128 == 0 &&
-               (long)32 * std::max(w.n, w.k) * 2 < (1L << 31);
+               (long)CH_MAX_T * std::max(w.n, w.k) * 2 < (1L << 31);
     };
     if (!d.qkv || !d.o || !gemm_ok(*d.qkv) || !gemm_ok(*d.o)) return false;
     if (d.o->G / 8 != 4) return false;              // (the instantiated forms: o_proj's K slice per wave is four groups)
-    if (d.T < 1 || d.T > 32 || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
+    if (d.T < 1 || d.T > CH_MAX_T || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
     if (d.H % 32 != 0 || d.H > 8192 || d.qkv->k != d.H || d.qkv->n != (d.nq + 2 * d.nkv) * 128 || d.o->k != d.nq * 128 || d.o->n != d.H) return false;
     if (d.E <= 0) {       // dense model: role B is add + norm, role A sums the down projection's slabs
         if (d.Q != 1 || (d.has_a && (!d.a_slabs || d.a_S < 1 || d.a_ld < d.H))) return false;

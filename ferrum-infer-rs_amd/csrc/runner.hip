@@ -1284,7 +1284,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     };
     auto chain_ok = [&](int li) {
         if (c.num_experts <= 0 || !knobs().decode_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts) return false;
-        if (!sh.all_single_token || !m->fuse_rope_attn || T > 32 || m->taps_enabled || sandwich) return false;
+        if (!sh.all_single_token || !m->fuse_rope_attn || T > knobs().chain_max_rows || m->taps_enabled || sandwich) return false;
         if (c.tp_world > 1 && c.expert_parallel != 2) return false;             // (tensor-parallel attention: an all-reduce sits behind o_proj)
         if (T * c.top_k > 1024 || c.top_k > 8 || T > 64) return false;
         return decode_chain_supports(chain_desc(li));
