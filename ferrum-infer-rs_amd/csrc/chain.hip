@@ -70,6 +70,7 @@ struct ChainArgs {
     int has_a, top_k;              // has_a: 0 no tail, 1 MoE combine (down / comb_w / top_k), 2 dense (the down projection's split-K slabs)
     const __half* down; const float* comb_w; const __half* res_in; const __half* ln_in;
     const float* a_slabs; int a_S; long a_slab_stride; int a_ld;
+    const __half* a_x;              // has_a == 3: the MLP output as fp16 rows [T, H]
     float eps;
     __half* res_a;                // residual' — also what role B adds the o projection to
     __half* norm1;                // [T, H]
@@ -153,7 +154,17 @@ __device__ __forceinline__ void chain_role_a(const ChainArgs& p, int row, unsign
 #pragma unroll
     for (int c = 0; c < CH; c++) {
         const int i = threadIdx.x + c * 512;
-        if (i < nvec && p.has_a == 2) {
+        if (i < nvec && p.has_a == 3) {
+            // dense model, the MLP's output as fp16 rows (≤ 16 or > 32 rows: no slabs): residual add, as fused_add_rms_norm
+            const half8 xv = *reinterpret_cast<const half8*>(p.a_x + (long)row * H + i * 8);
+            half8 rv = *reinterpret_cast<const half8*>(p.res_in + (long)row * H + i * 8);
+#pragma unroll
+            for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + (float)xv[j]);
+            store16_sc1(r_res, (int)(((long)row * H + i * 8) * 2), rv);
+            v[c] = rv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)rv[j] * (float)rv[j];
+        } else if (i < nvec && p.has_a == 2) {
             // dense model: the MLP's down projection arrives as S fp32 split-K slabs — summed in slab order and rounded like the
             // fp16 op output (add_rmsnorm_route_kernel<true>, fused.hip), then the residual add
             float o[8];
@@ -807,8 +818,8 @@ bool decode_chain_supports(const DecodeChainDesc& d) {
     if (d.o->G / 8 != 4) return false;              // (the instantiated forms: o_proj's K slice per wave is four groups)
     if (d.T < 1 || d.T > CH_MAX_T || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
     if (d.H % 32 != 0 || d.H > 8192 || d.qkv->k != d.H || d.qkv->n != (d.nq + 2 * d.nkv) * 128 || d.o->k != d.nq * 128 || d.o->n != d.H) return false;
-    if (d.E <= 0) {       // dense model: role B is add + norm, role A sums the down projection's slabs
-        if (d.Q != 1 || (d.has_a && (!d.a_slabs || d.a_S < 1 || d.a_ld < d.H))) return false;
+    if (d.E <= 0) {       // dense model: role B is add + norm, role A sums the down projection's slabs (or adds its fp16 rows)
+        if (d.Q != 1 || (d.has_a && !d.a_x && (!d.a_slabs || d.a_S < 1 || d.a_ld < d.H))) return false;
         return (size_t)d.H * 2 + 64 * 4 <= (size_t)CH_SMEM;
     }
     const int tiles = (d.E + 15) / 16;
@@ -824,7 +835,8 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     FH_REQUIRE(decode_chain_supports(d), "decode_chain: shapes not taken by the merged form");
     ChainArgs a{};
     a.T = d.T; a.H = d.H; a.nq = d.nq; a.nkv = d.nkv;
-    a.has_a = d.has_a ? (d.E > 0 ? 1 : 2) : 0; a.top_k = d.top_k;
+    a.has_a = d.has_a ? (d.E > 0 ? 1 : (d.a_x ? 3 : 2)) : 0; a.top_k = d.top_k;
+    a.a_x = d.a_x;
     a.a_slabs = d.a_slabs; a.a_S = d.a_S; a.a_slab_stride = d.a_slab_stride; a.a_ld = d.a_ld; a.down = d.down; a.comb_w = d.comb_w; a.res_in = d.res_in; a.ln_in = d.ln_in;
     a.eps = d.eps; a.res_a = d.res_a; a.norm1 = d.norm1;
     a.qkv = ChainGemm{d.qkv->qw, d.qkv->sc, d.qkv->zp, d.qkv->G, d.qkv->n, d.qkv->k};

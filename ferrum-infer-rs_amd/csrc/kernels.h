@@ -235,6 +235,7 @@ struct DecodeChainDesc {
     const __half* down = nullptr; const float* comb_w = nullptr; const __half* res_in = nullptr; const __half* ln_in = nullptr;
     // dense model (E == 0): the tail is residual + Σ_slabs of the MLP's down projection [a_S][rows][a_ld] fp32, then the norm
     const float* a_slabs = nullptr; int a_S = 0; long a_slab_stride = 0; int a_ld = 0;
+    const __half* a_x = nullptr;  // … or, without slabs, the MLP output as fp16 rows [T, H]
     float eps = 0.f;
     __half* res_a = nullptr;     // residual after the tail (role A's output, role B's input)
     __half* norm1 = nullptr;     // [T, H] input rows of the q|k|v projection

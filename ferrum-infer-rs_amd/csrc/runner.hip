@@ -1296,8 +1296,9 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     auto dense_chain_ok = [&](int li) {
         const LayerWeights& L = m->layers[li];
         if (c.num_experts > 0 || !knobs().decode_chain || !knobs().dense_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts || !m->residual2) return false;
-        if (!sh.all_single_token || !m->fuse_rope_attn || T <= 16 || T > 32 || m->taps_enabled || sandwich || c.tp_world > 1) return false;
-        if (!m->dense_slabs || !L.o.qw || !L.gate_up.qw || !L.down.qw || L.gate_up.perm || L.down.perm || L.qkv.perm || L.o.perm) return false;
+        if (!sh.all_single_token || !m->fuse_rope_attn || T > knobs().chain_max_rows || m->taps_enabled || sandwich || c.tp_world > 1) return false;
+        if (!L.o.qw || !L.gate_up.qw || !L.down.qw || L.gate_up.perm || L.down.perm || L.qkv.perm || L.o.perm) return false;
+        if (L.qkv.bias || L.o.bias) return false;
         DecodeChainDesc d = chain_desc(li);
         d.has_a = false;
         return decode_chain_supports(d);
@@ -1314,6 +1315,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             DecodeChainDesc d = chain_desc(li);
             d.has_a = pending_dense_tail;
             d.a_slabs = m->workspace; d.a_S = tail_S; d.a_slab_stride = (long)tail_rows_pad * tail_n_pad; d.a_ld = tail_n_pad;
+            d.a_x = tail_S == 0 ? m->mlp_out : nullptr;
             d.cnt = m->em2_arrive + (size_t)m->chain_parity * m->arrive_half_words;
             d.cnt_next = m->em2_arrive + (size_t)(m->chain_parity ^ 1) * m->arrive_half_words;
             RUN(decode_chain_f16(d, s));
@@ -1322,13 +1324,26 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
             form_hit(FORM_DENSE_CHAIN);
             const int I = c.intermediate;
             int S = 0, rows_pad = 0, n_pad = 0;
-            RUN(w4_gemm_dense_slabs_lds(L.gate_up, m->norm_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
-            RUN(fused_gated_act_slabs_f16(m->workspace, S, (long)rows_pad * n_pad, n_pad, m->act_out, T, I, c.activation == 1, s));
-            S = 0;
-            RUN(w4_gemm_dense_slabs_lds(L.down, m->act_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+            const bool slabs = m->dense_slabs && T > 16 && T <= 32;      // 17–32 rows: split-K slabs summed by their consumers
+            if (slabs) {
+                RUN(w4_gemm_dense_slabs_lds(L.gate_up, m->norm_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+                RUN(fused_gated_act_slabs_f16(m->workspace, S, (long)rows_pad * n_pad, n_pad, m->act_out, T, I, c.activation == 1, s));
+                S = 0;
+                RUN(w4_gemm_dense_slabs_lds(L.down, m->act_out, m->workspace, m->workspace_bytes, T, &S, &rows_pad, &n_pad, s));
+            } else {
+                RUN(dense_linear(m, L.gate_up, m->norm_out, m->gate_up_out, T, s, true));
+                if (c.activation == 1) { RUN(fused_gelu_tanh_mul_split_f16(m->gate_up_out, m->act_out, T, I, s)); }
+                else { RUN(fused_silu_mul_split_f16(m->gate_up_out, m->act_out, T, I, s)); }
+                RUN(dense_linear(m, L.down, m->act_out, m->mlp_out, T, s));
+            }
             if (li + 1 < c.num_layers && dense_chain_ok(li + 1)) {
-                pending_dense_tail = true;          // slabs + residual + next input norm: the first role of the next layer's launch
+                pending_dense_tail = true;          // MLP output + residual + next input norm: the first role of the next layer's launch
                 tail_S = S; tail_rows_pad = rows_pad; tail_n_pad = n_pad;
+            } else if (!slabs) {
+                if (next_ln) { RUN(fused_add_rms_norm_f16(m->residual2, m->mlp_out, next_ln, c.rms_eps, m->norm_out, T, H, s, next_qkv_perm)); }
+                else { RUN(add_inplace_f16(m->residual2, m->mlp_out, (long)T * H, s)); }
+                FH_CHECK_HIP(hipMemcpyAsync(m->residual, m->residual2, (size_t)T * H * sizeof(__half), hipMemcpyDeviceToDevice, s));
+                qkv_in_perm = next_ln && next_qkv_perm != nullptr;
             } else {
                 // (the residual of this layer sits in the ping-pong buffer: the stand-alone tail works on it in place, then it moves back)
                 RUN(fused_add_rms_norm_route_slabs_f16(m->residual2, nullptr, m->workspace, S, (long)rows_pad * n_pad, n_pad,

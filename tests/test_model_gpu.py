@@ -686,7 +686,7 @@ def test_asymmetric_and_act_order_expert_stacks_at_qwen3_dims(pkg, asym, desc_ac
 # ── the same launch for the attention half of a DENSE layer (Llama-style: no q/k norm, no router) ─────────────────────────────
 # Three layers, so that the tail of a layer — the MLP's down projection as split-K slabs + residual + next input norm — runs as the
 # first role of the next layer's launch: oracle-followed rows, the five-launch layer on the same tokens, graph ≡ eager.
-@pytest.mark.parametrize("c", [32, 19])
+@pytest.mark.parametrize("c", [48, 32, 19, 9, 2])
 def test_dense_decode_chain_across_layers(pkg, c, forms, knobs):
     from tests import modelgen
     from oracle import oracle as O
@@ -728,7 +728,7 @@ def test_dense_decode_chain_across_layers(pkg, c, forms, knobs):
     out1, fed, hits, hm1 = drive(1, lambda tag, ref, lg, tok: par.check(tag, ref, lg, tok, float("inf")))
     state["fed"] = fed
     assert hits.get("decode_chain", 0) == 3 * steps and hits.get("dense_chain", 0) == 3 * steps, hits
-    assert "attn_fused_qkv_wide" not in hits and "dense_slab_chain" not in hits, hits
+    assert "attn_fused_qkv_wide" not in hits and "attn_fused_qkv_narrow" not in hits and "dense_slab_chain" not in hits, hits
     O.set_threads(1)
     par.finish(max_mismatches=1, max_route_ties=0)
     graph_ids = hm1.decode_steps(list(range(c)), fed[-1], 4)                      # hipGraph loop from this state …
@@ -741,7 +741,7 @@ def test_dense_decode_chain_across_layers(pkg, c, forms, knobs):
         cur = graph_ids[s]
     del hm2
     out0, _, hits0, hm0 = drive(0, None)                                          # the five-launch layer on the same tokens
-    assert "decode_chain" not in hits0 and hits0.get("dense_slab_chain", 0) == 3 * steps, hits0
+    assert "decode_chain" not in hits0 and (hits0.get("dense_slab_chain", 0) == 3 * steps or not 16 < c <= 32), hits0
     for s, ((t1, l1), (t0, l0)) in enumerate(zip(out1, out0)):
         err = np.abs(l1 - l0).max(axis=1)
         assert float(err.max()) < 0.02 * float(np.abs(l0).max()), (s, float(err.max()))
