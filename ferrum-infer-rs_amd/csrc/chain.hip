@@ -51,7 +51,7 @@ constexpr int CH_QKV_SLOT = 56, CH_QKV_R = 4;                           // q|k|v
 constexpr int CH_MAX_KVH = 16;
 constexpr int CH_SLOTS = CH_QKV_SLOT + CH_QKV_R * CH_MAX_KVH;
 constexpr int CH_GRAN = 10;              // granules per (token, router part): 8 candidates + max + Σexp
-constexpr int CH_MAX_T = 64;
+constexpr int CH_MAX_T = 128;
 constexpr int CH_GRAN_WORDS = CH_MAX_T * 4 * CH_GRAN * 2;      // T ≤ 64 tokens × Q ≤ 4 parts, 8-byte granules
 constexpr int CH_SMEM = 8 * 16 * (128 + 4) * 4 + 2 * 8 * 16 * 4 + 16 * 128 * 2 + 2 * 128 * 2;     // the attention role's arena: 73,216 B
 

@@ -774,7 +774,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         rc |= dev_alloc(&m->sorted_ids, sorted_max);
         rc |= dev_alloc(&m->block_ids, sorted_max / 16 + 1);
         rc |= dev_alloc(&m->total_post_pad, (size_t)4);
-        rc |= dev_alloc(&m->residual2, (size_t)64 * H);
+        rc |= dev_alloc(&m->residual2, (size_t)128 * H);
         rc |= dev_alloc(&m->route_cand, (size_t)512 * 8);     // [T ≤ 64][Q ≤ 8][8]
         rc |= dev_alloc(&m->route_stats, (size_t)512 * 2);
         // [64] arrival counters of the split route kernel (zeroed here; the kernel re-arms them) + [2][E] per-expert counters of the
@@ -798,7 +798,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
         rc |= dev_alloc(&m->act_out, T * (size_t)c.intermediate);
         // the one-launch attention half of the decode layer (chain.hip) for dense models: ping-pong residual, its two counter halves
         // (layout as above without the per-expert part) and the give-up word
-        rc |= dev_alloc(&m->residual2, (size_t)64 * H);
+        rc |= dev_alloc(&m->residual2, (size_t)128 * H);
         m->arrive_half_words = (size_t)decode_chain_counter_words();
         rc |= dev_alloc(&m->route_arrive, (size_t)64 + 2 * m->arrive_half_words + 4);
         if (!rc) m->em2_arrive = m->route_arrive + 64;
@@ -1286,7 +1286,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         if (c.num_experts <= 0 || !knobs().decode_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts) return false;
         if (!sh.all_single_token || !m->fuse_rope_attn || T > knobs().chain_max_rows || m->taps_enabled || sandwich) return false;
         if (c.tp_world > 1 && c.expert_parallel != 2) return false;             // (tensor-parallel attention: an all-reduce sits behind o_proj)
-        if (T * c.top_k > 1024 || c.top_k > 8 || T > 64) return false;
+        if (T * c.top_k > 1024 || c.top_k > 8 || T > 128) return false;
         return decode_chain_supports(chain_desc(li));
     };
     // dense models at 17–32 rows: the same launch for the attention half (tail of the previous layer's MLP — its down slabs +
@@ -1296,7 +1296,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
     auto dense_chain_ok = [&](int li) {
         const LayerWeights& L = m->layers[li];
         if (c.num_experts > 0 || !knobs().decode_chain || !knobs().dense_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts || !m->residual2) return false;
-        if (!sh.all_single_token || !m->fuse_rope_attn || T > knobs().chain_max_rows || m->taps_enabled || sandwich || c.tp_world > 1) return false;
+        if (!sh.all_single_token || !m->fuse_rope_attn || T > std::min(64, knobs().chain_max_rows) || m->taps_enabled || sandwich || c.tp_world > 1) return false;      // (beyond 64 rows the 64-row GEMM tiles win: Llama-3.1-8B c=96 5.56 vs 5.61 ms)
         if (!L.o.qw || !L.gate_up.qw || !L.down.qw || L.gate_up.perm || L.down.perm || L.qkv.perm || L.o.perm) return false;
         if (L.qkv.bias || L.o.bias) return false;
         DecodeChainDesc d = chain_desc(li);

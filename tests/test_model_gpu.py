@@ -553,7 +553,7 @@ def _chain_model():
     return _CHAIN_TM["tm"]
 
 
-@pytest.mark.parametrize("c", [64, 47, 32, 20, 9, 7, 4, 1])
+@pytest.mark.parametrize("c", [100, 64, 47, 32, 20, 9, 7, 4, 1])
 def test_decode_chain_and_merged_moe_launch_across_layers(pkg, c, forms, knobs):
     from tests import modelgen
     from oracle import oracle as O
