@@ -99,7 +99,10 @@ struct FerrumHipModel {
                                                       // un-overlapped prologue / epilogue cost more than the schedule gains (§3)
     int moe_tile32_min_pairs_per_expert = 8;  // … from which (below the 64-row threshold) they use 32-row LDS tiles
     int attn_flash_min_rows = 512;            // query rows (tokens × GQA group) per prompt from which attention takes the LDS-shared K/V form
-    int moe_em_min_pairs_per_expert = 2;      // decode (P ≤ 1024): average pairs per expert from which the grouped GEMMs run expert-major (0 = never)
+    // decode (P ≤ 1024): average pairs per expert, in eighths, from which the grouped GEMMs run expert-major (0 = never).  The
+    // one-launch gate_up → down pair moved the break-even down from 2 pairs per expert: c=20 4.08 → 3.84 ms per step, c=24 4.21 →
+    // 3.92, c=28 4.38 → 3.99 (c=16, one pair per expert: 3.62 vs 3.64 — the block-major launches keep it)
+    int moe_em_min_pairs_x8 = 9;
     bool dense_slabs = true;              // dense MLP block at 17–32 rows: slab GEMMs reduced by their consumers
     int o_slabs = 8;                      // split-K slabs of the o projection on the decode path (0 = direct)
     // expert parallelism (cfg.expert_parallel, tp_world > 1): this rank owns experts [ep_e0, ep_e0 + ep_E) of num_experts

@@ -374,7 +374,8 @@ int ferrum_hip_model_create(FerrumHipModel** model, const FerrumHipModelConfig* 
     if (const char* e = getenv("FERRUM_HIP_DENSE_SLABS")) m->dense_slabs = atoi(e) != 0;
     if (const char* e = getenv("FERRUM_HIP_ROUTE_GEMM_TOKENS")) m->route_gemm_min_tokens = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE_PAIRS")) m->moe_tile_min_pairs_per_expert = std::max(1, atoi(e));
-    if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_per_expert = std::max(0, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS")) m->moe_em_min_pairs_x8 = 8 * std::max(0, atoi(e));
+    if (const char* e = getenv("FERRUM_HIP_MOE_EM_PAIRS_X8")) m->moe_em_min_pairs_x8 = std::max(0, atoi(e));
     if (knobs().attn_flash_min_rows_set) m->attn_flash_min_rows = std::max(1, (int)knobs().attn_flash_min_rows);   // as the launcher reads it
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE96_PAIRS")) m->moe_tile96_min_pairs_per_expert = std::max(1, atoi(e));
     if (const char* e = getenv("FERRUM_HIP_MOE_TILE128_PAIRS")) m->moe_tile128_min_pairs_per_expert = std::max(1, atoi(e));
@@ -1069,7 +1070,7 @@ static int moe_down_input(FerrumHipModel* m, LayerWeights& L, int P, hipStream_t
 // `route` (decode chain with a deferred merge): the routing arrives as per-part candidate lists; only forms that merge them in
 // their own prologue may run (moe_deferred_merge_ok decides that BEFORE the chain launch).
 static bool moe_pair_form(const FerrumHipModel* m, const LayerWeights& L, int P) {
-    return m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * m->cfg.num_experts && knobs().moe_em2 &&
+    return m->moe_em_min_pairs_x8 > 0 && 8L * P >= (long)m->moe_em_min_pairs_x8 * m->cfg.num_experts && knobs().moe_em2 &&
            m->em2_arrive && !m->em2_failed && !L.exp_down.perm;
 }
 static bool moe_deferred_merge_ok(const FerrumHipModel* m, const LayerWeights& L, int T, int Q) {
@@ -1095,7 +1096,7 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
     const __half *gx = nullptr, *hx = nullptr;
     if (int rc = moe_gate_up_input(m, L, P / K, s, &gx)) return rc;
     // (the expert-major threshold compares pairs per expert: P pairs over num_experts, whatever share of them is local)
-    if (m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts) {
+    if (m->moe_em_min_pairs_x8 > 0 && 8L * P >= (long)m->moe_em_min_pairs_x8 * c.num_experts) {
         if (moe_pair_form(m, L, P)) {
             // one launch: down tiles wait for their expert's gate_up tiles inside it (w4_gemm_moe_em2_kernel)
             unsigned* cur = m->em2_arrive + (size_t)m->em2_parity * m->arrive_half_words;
@@ -1968,7 +1969,7 @@ int ferrum_hip_model_time_kernel(FerrumHipModel* m, int which, int n_seqs, int m
     FH_REQUIRE(T <= c.max_tokens, "time_kernel: %d rows > max_tokens %d", T, c.max_tokens);
     const int max_blocks = E > 0 ? std::min((P + E * 16) / 16, P / 16 + std::min(P, E)) : 0;
     int launches = 0, rc = 0;
-    const bool em = E > 0 && m->moe_em_min_pairs_per_expert > 0 && P >= m->moe_em_min_pairs_per_expert * c.num_experts;   // as moe_decode_gemms
+    const bool em = E > 0 && m->moe_em_min_pairs_x8 > 0 && 8L * P >= (long)m->moe_em_min_pairs_x8 * c.num_experts;   // as moe_decode_gemms
     auto one = [&](int li) -> int {
         LayerWeights& L = m->layers[li];
         switch (which) {
