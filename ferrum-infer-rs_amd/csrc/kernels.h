@@ -84,7 +84,8 @@ int w4_gemm_moe_block_major_pair(const W4Device& gu, const W4Device& dn, const _
                                  const MoeRouteLists* route = nullptr);
 int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
                              int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
-                             int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream);
+                             int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream,
+                             bool few_pairs_per_expert = false);
 int w4_gemm_moe_merge_route(const W4Device& w, const __half* x, __half* out, const RouteCand* cand, const float* stats,
                             int tokens, int Q, int top_k, int norm_topk, int num_experts, int max_blocks, int fused_silu,
                             int32_t* pub_expert_ids, float* pub_expert_w, int32_t* pub_sorted, int32_t* pub_block_ids,

@@ -1130,8 +1130,9 @@ static int moe_decode_gemms(FerrumHipModel* m, LayerWeights& L, int P, int max_b
         if (int rc = moe_down_input(m, L, P, s, &hx)) return rc;
         return w4_gemm_moe(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
     }
+    // (the router picks K distinct experts per token: with ≤ 16 tokens no expert holds more than 16 pairs — the ballot align)
     if (int rc = w4_gemm_moe_inline_align(L.exp_gate_up, gx, m->moe_act, ids, E, P, max_blocks, K, 1,
-                                          m->sorted_ids, m->block_ids, m->total_post_pad, s)) return rc;
+                                          m->sorted_ids, m->block_ids, m->total_post_pad, s, P / K <= 16 && !c.expert_parallel)) return rc;
     if (int rc = moe_down_input(m, L, P, s, &hx)) return rc;
     return w4_gemm_moe(L.exp_down, hx, m->moe_down, m->sorted_ids, m->block_ids, m->total_post_pad, P, max_blocks, 1, 0, s);
 }

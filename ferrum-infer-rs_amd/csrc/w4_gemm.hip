@@ -154,6 +154,7 @@ struct W4Args {
     const int32_t* block_ids;
     const int32_t* total_post_pad;
     int top_k;            // input row = id / top_k
+    int few_pairs_per_expert;   // the caller's promise that no expert holds more than 16 of the pairs (≤ 16 tokens, distinct experts per token)
     int rows_pad;         // slab row count
     int n_pad;            // slab column count (= n64·64)
     // inline align (decode-sized batches): raw per-pair expert ids instead of the three arrays above
@@ -369,10 +370,10 @@ __device__ __forceinline__ bool inline_align_block(const int* s_ids, int P, int 
     return true;
 }
 
-// The align for a handful of tokens routed from candidate lists (P ≤ 64 pairs, E ≤ 128 experts, every expert at most once per
-// token and T ≤ 16 tokens — so one 16-row block per active expert): no histogram, no scan.  The active experts are two 64-bit
-// ballots' worth of presence bits; block rb is the rb-th set bit; its rows are the lanes holding that expert, compacted in
-// ascending pair order — the arrays moe_align_block_size would produce.  One wave, ≈ 0.3 µs instead of inline_align_block's ≈ 1.5.
+// The align for a few tokens (P ≤ 128 pairs, E ≤ 128 experts, every expert at most once per token and T ≤ 16 tokens — so one
+// 16-row block per active expert): no histogram, no scan.  The active experts are two 64-bit words of presence bits; block rb
+// is the rb-th set bit; its rows are the pairs holding that expert, compacted in ascending pair order — the arrays
+// moe_align_block_size would produce.  One wave, two pairs per lane; ≈ 0.3 µs instead of inline_align_block's ≈ 1.5.
 template <bool ONE_WAVE = false>
 __device__ __forceinline__ bool align_block_few_pairs(const int* s_ids, int P, int rb, unsigned* s_bits, int* s_rows, int* expert_out,
                                                       int* total_blocks_out) {
@@ -380,8 +381,9 @@ __device__ __forceinline__ bool align_block_few_pairs(const int* s_ids, int P, i
     if (lane < 4) s_bits[lane] = 0u;
     if (lane < 16) s_rows[lane] = P;      // sentinel
     lds_sync<ONE_WAVE>();
-    const int e = lane < P ? s_ids[lane] : -1;
-    if (e >= 0 && e < 128) atomicOr(&s_bits[e >> 5], 1u << (e & 31));
+    const int e0 = lane < P ? s_ids[lane] : -1, e1 = 64 + lane < P ? s_ids[64 + lane] : -1;
+    if (e0 >= 0 && e0 < 128) atomicOr(&s_bits[e0 >> 5], 1u << (e0 & 31));
+    if (e1 >= 0 && e1 < 128) atomicOr(&s_bits[e1 >> 5], 1u << (e1 & 31));
     lds_sync<ONE_WAVE>();
     const unsigned long long lo = ((unsigned long long)s_bits[1] << 32) | s_bits[0], hi = ((unsigned long long)s_bits[3] << 32) | s_bits[2];
     const int n_lo = __popcll(lo), total = n_lo + __popcll(hi);
@@ -392,9 +394,10 @@ __device__ __forceinline__ bool align_block_few_pairs(const int* s_ids, int P, i
     const int want = rb < n_lo ? rb : rb - n_lo;
     const bool hit = ((w >> lane) & 1ull) && __popcll(w & ((1ull << lane) - 1ull)) == want;
     const int e_star = (__ffsll((long long)__ballot(hit)) - 1) + (rb < n_lo ? 0 : 64);
-    const bool mine = e == e_star;
-    const unsigned long long bal = __ballot(mine);
-    if (mine) s_rows[__popcll(bal & ((1ull << lane) - 1ull)) & 15] = lane;
+    const bool m0 = e0 == e_star, m1 = e1 == e_star;
+    const unsigned long long b0 = __ballot(m0), b1 = __ballot(m1);
+    if (m0) s_rows[__popcll(b0 & ((1ull << lane) - 1ull)) & 15] = lane;
+    if (m1) s_rows[(__popcll(b0) + __popcll(b1 & ((1ull << lane) - 1ull))) & 15] = 64 + lane;
     lds_sync<ONE_WAVE>();
     *expert_out = e_star;
     return true;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(MODE == 0 ? 256 : 64 * KW) void w4_gemm_kernel(W4Ar
                 __syncthreads();
             }
             int total_blocks;
-            if (p.cand && p.route_T <= 8 && p.M <= 64 && p.num_experts <= 128) {
+            if (((p.cand && p.route_T <= 8) || p.few_pairs_per_expert) && p.M <= (KW == 1 ? 128 : 64) && p.num_experts <= 128) {
                 if (!align_block_few_pairs(s_ids, p.M, rb, reinterpret_cast<unsigned*>(s_cnt), s_rows, &e, &total_blocks)) return;
             } else if (!inline_align_block(s_ids, p.M, p.num_experts, rb, s_cnt, s_rows, &e, &total_blocks)) return;
             id = s_rows[b];
@@ -2602,7 +2605,8 @@ int w4_gemm_dense(const W4Device& w, const __half* x, __half* out, int m, float*
 // out row = pair id, in row = pair id / top_k (vLLM marlin_moe convention, ops.cu:942).
 int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, const int32_t* pair_expert_ids,
                              int num_experts, int num_valid_pairs, int max_blocks, int top_k, int fused_silu,
-                             int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream) {
+                             int32_t* pub_sorted, int32_t* pub_block_ids, int32_t* pub_total, hipStream_t stream,
+                             bool few_pairs_per_expert) {
     if (num_valid_pairs <= 0 || max_blocks <= 0) return 0;
     FH_REQUIRE(num_valid_pairs <= 1024 && num_experts <= 512, "inline align: pairs=%d experts=%d out of range", num_valid_pairs, num_experts);
     W4Args a{};
@@ -2615,6 +2619,7 @@ int w4_gemm_moe_inline_align(const W4Device& w, const __half* x, __half* out, co
     a.pair_expert_ids = pair_expert_ids; a.num_experts = num_experts;
     a.pub_sorted_token_ids = pub_sorted; a.pub_block_ids = pub_block_ids; a.pub_total_post_pad = pub_total;
     a.top_k = top_k;
+    a.few_pairs_per_expert = few_pairs_per_expert ? 1 : 0;
     dim3 grid(w.n64, max_blocks, 1);
     form_hit(FORM_MOE_INLINE_ALIGN);
     if (fused_silu) return launch_w4<2>(a, 1, w.zp != nullptr, grid, stream);
