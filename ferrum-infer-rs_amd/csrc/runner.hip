@@ -1078,9 +1078,10 @@ static bool moe_deferred_merge_ok(const FerrumHipModel* m, const LayerWeights& L
     if (!mode || m->cfg.expert_parallel || Q < 2 || Q > 4 || m->cfg.top_k > 8) return false;
     const int P = T * m->cfg.top_k;
     // few pairs (block-major grid): every workgroup runs the full merge + align on a few hundred bytes of lists
-    // (T ≤ 4: c = 1 1.99 → 1.88 ms per step, c = 2 2.16 → 2.03, c = 4 ±0; at c = 8 the four merge passes in each of the ≈ 1500
-    // one-wave workgroups cost the gate_up launch more than role B's merge costs the chain: 2.89 → 3.03)
-    if (T <= 4 && P <= 64 && !moe_pair_form(m, L, P)) return true;
+    // (only where the gate_up launch is the K-split form — ≤ 16 pairs, c ≤ 2: c = 1 1.99 → 1.88 ms per step, c = 2 2.16 → 2.03.
+    // In the one-wave-per-tile form every one of the ≈ 770 workgroups at c = 4 pays the merge: its launch 13.5 → 17.3 µs against
+    // 2.9 µs saved in the chain; at c = 8 2.89 → 3.03 ms per step)
+    if (P <= std::min(knobs().moe_kw_pairs, 64) && T <= 4 && !moe_pair_form(m, L, P)) return true;
     // expert-major merged launch: each tile only checks its own expert against the lists; measured at c = 32 the ≈ 8 KiB of lists
     // read by all 7168 workgroups cost the launch what role B's merge cost the chain (47.4 → 50.3 µs vs ≈ −3 µs): off unless asked for
     if (mode < 2) return false;
