@@ -3070,14 +3070,16 @@ int f16t_repack(const __half* w_rowmajor, __half* out_tiled, int n, int k, hipSt
 }
 size_t f16t_elems(int n, int k) { return (size_t)cdiv(n, 16) * 16 * k; }
 
-template <int MT, typename OutT>
+// J = 16-column tiles per wave: 2, or 4 for two row tiles against a wide N (the lm_head at 17–32 rows: with 2 the activation
+// fragments a wave re-reads from L2 are as many bytes as the weights it streams from HBM)
+template <int MT, typename OutT, int J = 2>
 __global__ __launch_bounds__(256) void f16t_gemm_kernel(const __half* __restrict__ x, const __half* __restrict__ wt,
                                                         OutT* __restrict__ out, float* __restrict__ partial, int M, int N,
                                                         int K, int S, int rows_pad, int n_pad) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int ntile2 = blockIdx.x * 4 + wave;       // pair of 16-column tiles
-    const int n0 = ntile2 * 32;
+    const int ntile2 = blockIdx.x * 4 + wave;       // group of J 16-column tiles
+    const int n0 = ntile2 * 16 * J;
     if (n0 >= N) return;
     const int rb = blockIdx.y, z = blockIdx.z;
     const int ksteps = K >> 5;
@@ -3089,25 +3091,25 @@ __global__ __launch_bounds__(256) void f16t_gemm_kernel(const __half* __restrict
         int r = rb * 16 * MT + mt * 16 + b;
         xrow[mt] = x + (long)(r < M ? r : M - 1) * K + 8 * a;
     }
-    const __half* wtile[2];
+    const __half* wtile[J];
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-        int t = ntile2 * 2 + j;
+    for (int j = 0; j < J; j++) {
+        int t = ntile2 * J + j;
         wtile[j] = wt + ((long)(t < tiles ? t : tiles - 1) * ksteps * 64 + lane) * 8;
     }
-    float4v acc[MT][2];
+    float4v acc[MT][J];
 #pragma unroll
     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[mt][j] = (float4v){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < J; j++) acc[mt][j] = (float4v){0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
     int s = s0;
     for (; s + U <= s1; s += U) {
-        half8 bw[U][2], ax[U][MT];
+        half8 bw[U][J], ax[U][MT];
 #pragma unroll
         for (int u = 0; u < U; u++) {
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < J; j++)
                 bw[u][j] = __builtin_nontemporal_load(reinterpret_cast<const half8*>(wtile[j] + (long)(s + u) * 512));
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) ax[u][mt] = *reinterpret_cast<const half8*>(xrow[mt] + (s + u) * 32);
@@ -3115,14 +3117,14 @@ __global__ __launch_bounds__(256) void f16t_gemm_kernel(const __half* __restrict
 #pragma unroll
         for (int u = 0; u < U; u++)
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < J; j++)
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
                     acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[u][mt], bw[u][j], acc[mt][j], 0, 0, 0);
     }
     for (; s < s1; s++) {
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < J; j++) {
             half8 bwv = *reinterpret_cast<const half8*>(wtile[j] + (long)s * 512);
 #pragma unroll
             for (int mt = 0; mt < MT; mt++) {
@@ -3137,7 +3139,7 @@ __global__ __launch_bounds__(256) void f16t_gemm_kernel(const __half* __restrict
         for (int r = 0; r < 4; r++) {
             int row = rb * 16 * MT + mt * 16 + 4 * a + r;
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
+            for (int j = 0; j < J; j++) {
                 int col = n0 + j * 16 + b;
                 if (S > 1) {
                     partial[((long)z * rows_pad + row) * n_pad + col] = acc[mt][j][r];
@@ -3162,6 +3164,12 @@ static int f16t_gemm_impl(const __half* x, const __half* wt, OutT* out, int m, i
     while (tasks * S < 2048 && S * 2 <= ksteps / 8) S *= 2;
     int rows_pad = row_blocks * 16 * mt, n_pad = ntile2 * 32;
     if (S > 1 && (size_t)S * rows_pad * n_pad * sizeof(float) > workspace_bytes) S = 1;
+    if (mt == 2 && S == 1 && n >= 32768 && n % 64 == 0) {       // wide N at 17–32 rows (the lm_head): 64 columns per wave
+        hipLaunchKernelGGL((f16t_gemm_kernel<2, OutT, 4>), dim3(cdiv(cdiv(n, 64), 4), row_blocks, 1), dim3(256), 0, stream, x, wt, out, workspace, m,
+                           n, k, 1, rows_pad, n_pad);
+        FH_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid(cdiv(ntile2, 4), row_blocks, S);
     if (mt == 1) hipLaunchKernelGGL((f16t_gemm_kernel<1, OutT>), grid, dim3(256), 0, stream, x, wt, out, workspace, m, n, k, S, rows_pad, n_pad);
     else if (mt == 2) hipLaunchKernelGGL((f16t_gemm_kernel<2, OutT>), grid, dim3(256), 0, stream, x, wt, out, workspace, m, n, k, S, rows_pad, n_pad);

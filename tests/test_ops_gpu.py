@@ -265,7 +265,8 @@ def test_gptq_linearity(env):
 
 # ── dense fp16 GEMM (router / lm_head) ───────────────────────────────────────
 @pytest.mark.parametrize("m,n,k,f32out", [(1, 128, 2048, True), (32, 128, 2048, True), (5, 1511, 1024, True),
-                                          (33, 96, 256, False), (64, 2048, 512, False)])
+                                          (33, 96, 256, False), (64, 2048, 512, False),
+                                          (20, 32768 + 128, 256, True), (32, 32768 + 64, 128, False)])   # the wide-N form of 17–32 rows (lm_head): 64 columns per wave
 def test_dense_gemm(env, m, n, k, f32out):
     pkg, B, ctx, O, torch = env
     rng = np.random.default_rng(m * n + k)
