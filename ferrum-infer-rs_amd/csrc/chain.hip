@@ -55,7 +55,7 @@ constexpr int CH_MAX_T = 128;
 constexpr int CH_GRAN_WORDS = CH_MAX_T * 4 * CH_GRAN * 2;      // T ≤ 64 tokens × Q ≤ 4 parts, 8-byte granules
 constexpr int CH_SMEM = 8 * 16 * (128 + 4) * 4 + 2 * 8 * 16 * 4 + 16 * 128 * 2 + 2 * 128 * 2;     // the attention role's arena: 73,216 B
 
-constexpr int CH_QKV_NST = 2, CH_O_NST = 1;     // 64-column supertiles per workgroup: one head (128 columns) for q|k|v, 64 columns for o_proj; 16 rows each
+constexpr int CH_QKV_NST = 1, CH_O_NST = 1;     // 64-column supertiles per workgroup: one head (128 columns) for q|k|v, 64 columns for o_proj; 16 rows each
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -388,7 +388,7 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     // norm weights and the RoPE row of this position do not depend on the projection either
     __builtin_amdgcn_sched_barrier(0);
     // the q|k|v columns of this kv head: G + 2 heads, each one workgroup per 16-row block of the projection role
-    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * ((p.T + 15) >> 4)), p.timeout);
+    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (2 / CH_QKV_NST) * ((p.T + 15) >> 4)), p.timeout);
     CH_TL(1);
     half8 qf[KS];
     {
@@ -781,10 +781,10 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     wg -= n_a;
     if (wg < n_qkv) {
         // a column block is one head: its arrival counts for that head's kv head
-        const int head = wg / RH, G = p.nq / p.nkv;
+        const int cb = wg / RH, head = cb * CH_QKV_NST / 2, G = p.nq / p.nkv;     // (a head is two 64-column supertiles)
         const int kvh = head < p.nq ? head / G : (head < p.nq + p.nkv ? head - p.nq : head - p.nq - p.nkv);
         const ChainEdge e{p.has_a ? p.cnt + CH_NORM_SLOT * CH_STRIDE : nullptr, CH_NORM_SH, CH_NORM_R, (unsigned)p.T};
-        chain_role_gemm<CH_QKV_NST, GPW_QKV, HAS_ZP>(p.qkv, head, wg % RH, p.norm1, p.qkv_out, p.T, e,
+        chain_role_gemm<CH_QKV_NST, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
                                                      p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
         return;
     }
