@@ -66,6 +66,7 @@ struct ChainGemm {
 
 struct ChainArgs {
     int T, H, nq, nkv;
+    int qkv_half;                 // q|k|v in 32-column blocks (one 16-row block only: few rows, every CU gets a block)
     // role A: residual' = residual + Σ_k w_k·down_k; norm1 = rms_norm(residual')·ln_in   (absent for the first layer)
     int has_a, top_k;              // has_a: 0 no tail, 1 MoE combine (down / comb_w / top_k), 2 dense (the down projection's split-K slabs)
     const __half* down; const float* comb_w; const __half* res_in; const __half* ln_in;
@@ -239,26 +240,30 @@ __device__ __forceinline__ void chain_role_a(const ChainArgs& p, int row, unsign
 // split over workgroups (16 each) rather than the columns made narrower (32 rows × 4096: 8.0 µs behind the wait).
 struct ChainEdge { unsigned* base; int shards, reps; unsigned total; };      // base == nullptr: nothing to wait for
 
-template <int NST, int GPW, bool HAS_ZP>
+// NTL = 16-column tiles of the 64-column supertile a workgroup takes (NST = 1): 4, or 2 — a 32-column block `cb` = supertile cb / 2,
+// half cb % 2: half the weight bytes per workgroup, twice the workgroups (the stage is as long as its slowest workgroup's fetch).
+template <int NST, int GPW, bool HAS_ZP, int NTL = 4>
 __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int rb, const __half* x_in, __half* out, int T,
                                                 const ChainEdge& wait, unsigned* sig_base, int sig_shard, int sig_reps,
                                                 unsigned* timeout, unsigned char* smem, const ChainArgs& p) {
-    constexpr int V = NST * 16, CPR = NST * 8;                       // accumulator floats per lane; 16-byte chunks per output row
+    static_assert(NTL == 4 || (NTL == 2 && NST == 1), "half supertiles only for single-supertile blocks");
+    constexpr int V = NST * NTL * 4, CPR = NST * NTL * 2;                       // accumulator floats per lane; 16-byte chunks per output row
     float* red = reinterpret_cast<float*>(smem);                     // [8][V][64]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
     CH_TL(0);
     const int g0 = wave * GPW;                                        // G = 8·GPW (checked by the launcher)
-    u32x4 wq[GPW][NST][4];
+    const int nt0 = NTL == 2 ? (cb & 1) * 2 : 0;                      // first tile of the block inside its supertile
+    u32x4 wq[GPW][NST][NTL];
     uint2 scv[GPW][NST], zpv[GPW][NST];
 #pragma unroll
     for (int i = 0; i < GPW; i++)
 #pragma unroll
         for (int s = 0; s < NST; s++) {
-            const long st = (long)cb * NST + s;
+            const long st = NTL == 2 ? (long)(cb >> 1) : (long)cb * NST + s;
             const u32x4* qw_lane = reinterpret_cast<const u32x4*>(w.qw) + (st * w.G * 4) * 64 + lane;
 #pragma unroll
-            for (int nt = 0; nt < 4; nt++) wq[i][s][nt] = __builtin_nontemporal_load(qw_lane + ((long)(g0 + i) * 4 + nt) * 64);
+            for (int nt = 0; nt < NTL; nt++) wq[i][s][nt] = __builtin_nontemporal_load(qw_lane + ((long)(g0 + i) * 4 + nt0 + nt) * 64);
             scv[i][s] = (reinterpret_cast<const uint2*>(w.sc) + (st * w.G) * 16 + b)[(long)(g0 + i) * 16];
             if (HAS_ZP) zpv[i][s] = (reinterpret_cast<const uint2*>(w.zp) + (st * w.G) * 16 + b)[(long)(g0 + i) * 16];
         }
@@ -273,11 +278,11 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
 #pragma unroll
         for (int s = 0; s < 4; s++) af[buf][0][s] = load16_sc1(r_x, xoff + (g * 128 + 32 * s) * 2);
     };
-    float4v acc[NST][1][4];
+    float4v acc[NST][1][NTL];
 #pragma unroll
     for (int s = 0; s < NST; s++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++) acc[s][0][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NTL; nt++) acc[s][0][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
     issue_a(0, g0);
     if (GPW > 1) issue_a(1, g0 + 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -287,7 +292,7 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
         for (int s = 0; s < NST; s++) {
             const unsigned long long sb = ((unsigned long long)scv[i][s].y << 32) | scv[i][s].x;
             const unsigned long long zb = HAS_ZP ? (((unsigned long long)zpv[i][s].y << 32) | zpv[i][s].x) : 0ull;
-            w4_consume_group<1, 4, HAS_ZP, false>(wq[i][s], sb, zb, 0, af[i & 1], acc[s]);
+            w4_consume_group<1, NTL, HAS_ZP, false>(wq[i][s], sb, zb, nt0, af[i & 1], acc[s]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (i + 2 < GPW) issue_a(i & 1, g0 + i + 2);
@@ -297,9 +302,9 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
 #pragma unroll
     for (int s = 0; s < NST; s++)
 #pragma unroll
-        for (int nt = 0; nt < 4; nt++)
+        for (int nt = 0; nt < NTL; nt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) red[((wave * V) + (s * 4 + nt) * 4 + r) * 64 + lane] = acc[s][0][nt][r];
+            for (int r = 0; r < 4; r++) red[((wave * V) + (s * NTL + nt) * 4 + r) * 64 + lane] = acc[s][0][nt][r];
     __syncthreads();
     // thread → (row, 8 consecutive columns): one 16-byte write-through store
     if (threadIdx.x < 16 * CPR) {
@@ -322,7 +327,7 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
         const int r_out = rb * 16 + row;
         if (r_out < T) {
             const __amdgpu_buffer_rsrc_t r_o = chain_rsrc(out, (long)T * w.N * 2);
-            store16_sc1(r_o, (r_out * w.N + cb * 64 * NST + c8) * 2, o);
+            store16_sc1(r_o, (r_out * w.N + cb * 16 * NTL * NST + c8) * 2, o);
         }
     }
     CH_TL(2);
@@ -388,7 +393,7 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     // norm weights and the RoPE row of this position do not depend on the projection either
     __builtin_amdgcn_sched_barrier(0);
     // the q|k|v columns of this kv head: G + 2 heads, each one workgroup per 16-row block of the projection role
-    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (2 / CH_QKV_NST) * ((p.T + 15) >> 4)), p.timeout);
+    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (p.qkv_half ? 4 : 2 / CH_QKV_NST) * ((p.T + 15) >> 4)), p.timeout);
     CH_TL(1);
     half8 qf[KS];
     {
@@ -771,7 +776,8 @@ template <int GPW_QKV, int GPW_O, bool HAS_ZP>
 __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
-    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / (64 * CH_QKV_NST) * RH, n_attn = p.T * p.nkv, n_o = p.o.N / (64 * CH_O_NST) * RH;
+    const int QB = p.qkv_half ? 32 : 64 * CH_QKV_NST;               // q|k|v block width
+    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv, n_o = p.o.N / (64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
         if (threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;
@@ -781,11 +787,15 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     wg -= n_a;
     if (wg < n_qkv) {
         // a column block is one head: its arrival counts for that head's kv head
-        const int cb = wg / RH, head = cb * CH_QKV_NST / 2, G = p.nq / p.nkv;     // (a head is two 64-column supertiles)
+        const int cb = wg / RH, head = cb * QB / 128, G = p.nq / p.nkv;           // (a head is 128 columns)
         const int kvh = head < p.nq ? head / G : (head < p.nq + p.nkv ? head - p.nq : head - p.nq - p.nkv);
         const ChainEdge e{p.has_a ? p.cnt + CH_NORM_SLOT * CH_STRIDE : nullptr, CH_NORM_SH, CH_NORM_R, (unsigned)p.T};
-        chain_role_gemm<CH_QKV_NST, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
-                                                     p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
+        if (p.qkv_half)
+            chain_role_gemm<1, GPW_QKV, HAS_ZP, 2>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
+                                                   p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
+        else
+            chain_role_gemm<CH_QKV_NST, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
+                                                         p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
         return;
     }
     wg -= n_qkv;
@@ -856,7 +866,8 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     a.tl = g_chain_timeline;
 #endif
     const int rh = (d.T + 15) / 16;
-    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (64 * CH_QKV_NST) * rh + d.T * d.nkv + d.o->n / (64 * CH_O_NST) * rh + d.T * d.Q;
+    a.qkv_half = (knobs().chain_qkv_half && d.T <= 16) ? 1 : 0;
+    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv + d.o->n / (64 * CH_O_NST) * rh + d.T * d.Q;
     form_hit(FORM_DECODE_CHAIN);
     if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
