@@ -67,6 +67,7 @@ struct ChainGemm {
 struct ChainArgs {
     int T, H, nq, nkv;
     int qkv_half;                 // q|k|v in 32-column blocks (one 16-row block only: few rows, every CU gets a block)
+    int o_half;                   // o_proj likewise
     // role A: residual' = residual + Σ_k w_k·down_k; norm1 = rms_norm(residual')·ln_in   (absent for the first layer)
     int has_a, top_k;              // has_a: 0 no tail, 1 MoE combine (down / comb_w / top_k), 2 dense (the down projection's split-K slabs)
     const __half* down; const float* comb_w; const __half* res_in; const __half* ln_in;
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
     const int QB = p.qkv_half ? 32 : 64 * CH_QKV_NST;               // q|k|v block width
-    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv, n_o = p.o.N / (64 * CH_O_NST) * RH;
+    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv, n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
         if (threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;
@@ -803,8 +804,12 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     wg -= n_attn;
     if (wg < n_o) {
         const ChainEdge e{p.cnt + CH_ATTN_SLOT * CH_STRIDE, CH_ATTN_SH, CH_ATTN_R, (unsigned)n_attn};
-        chain_role_gemm<CH_O_NST, GPW_O, HAS_ZP>(p.o, wg / RH, wg % RH, p.attn_out, p.o_out, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
+        if (p.o_half)
+            chain_role_gemm<1, GPW_O, HAS_ZP, 2>(p.o, wg / RH, wg % RH, p.attn_out, p.o_out, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
                                                  wg % CH_O_SH, CH_O_R, p.timeout, smem, p);
+        else
+            chain_role_gemm<CH_O_NST, GPW_O, HAS_ZP>(p.o, wg / RH, wg % RH, p.attn_out, p.o_out, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
+                                                     wg % CH_O_SH, CH_O_R, p.timeout, smem, p);
         return;
     }
     wg -= n_o;
@@ -867,7 +872,9 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
 #endif
     const int rh = (d.T + 15) / 16;
     a.qkv_half = (knobs().chain_qkv_half && d.T <= 16) ? 1 : 0;
-    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv + d.o->n / (64 * CH_O_NST) * rh + d.T * d.Q;
+    // (narrow o_proj only: 2048 columns → 64 blocks; Llama-3.1-8B's 4096 columns are 64 blocks of 64 already: c=8 1.908 → 1.930 ms with 32)
+    a.o_half = (knobs().chain_o_half && d.T <= 16 && d.o->n <= 2048) ? 1 : 0;
+    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
     form_hit(FORM_DECODE_CHAIN);
     if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
