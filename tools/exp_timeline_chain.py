@@ -31,8 +31,9 @@ torch.cuda.synchronize()
 lib.ferrum_hip_debug_set_chain_timeline(None)
 t = tl.cpu().numpy().reshape(-1, 4)
 rh = (c + 15) // 16
-FUSED = c <= 4 and os.environ.get('FERRUM_HIP_CHAIN_FUSE_TAIL', '1') != '0'
-n_a, n_qkv, n_attn, n_o, n_b = (0 if FUSED else c), (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // 64 * rh, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
+half = c <= 16                                   # ≤ 16 rows: 32-column blocks in the GEMM roles
+qkv_cols = (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * 128
+n_a, n_qkv, n_attn, n_o, n_b = c, qkv_cols // (32 if half else 64) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // (32 if half else 64) * rh, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
 tot = n_a + n_qkv + n_attn + n_o + n_b
 t = t[:tot]
 t0 = t[:, 0].min()
