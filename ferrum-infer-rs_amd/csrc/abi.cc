@@ -44,6 +44,7 @@ void reload_knobs() {
     k.moe_deferred_merge = env_int("FERRUM_HIP_MOE_DEFERRED_MERGE", 1);
     k.moe_bm2 = env_int("FERRUM_HIP_MOE_BM2", 0);
     k.dense_chain = env_int("FERRUM_HIP_DENSE_CHAIN", 1);
+    k.chain_max_keys = env_int("FERRUM_HIP_CHAIN_MAX_KEYS", 2048);
     k.chain_o_half = env_int("FERRUM_HIP_CHAIN_O_HALF", 1);
     k.chain_qkv_half = env_int("FERRUM_HIP_CHAIN_QKV_HALF", 1);
     k.sandwich_wide = env_int("FERRUM_HIP_SANDWICH_WIDE", 1);

@@ -32,6 +32,7 @@ struct Knobs {
     int sandwich_wide = 1;            // sandwich add + norms of ≤ 64 rows: 1024 threads per row, loads ahead of the reductions (0 = 256 threads)
     int chain_qkv_half = 1;           // decode chain at ≤ 16 rows: q|k|v in 32-column blocks (0 = 64)
     int chain_o_half = 1;             // … and o_proj
+    int chain_max_keys = 2048;        // decode chain only up to this many keys per attention workgroup (× T·nkv / 128)
     int dense_chain = 1;              // dense models at 17–32 rows: the attention half of the layer as the chain launch too (0 = five launches)
     int moe_em2 = 1;                  // decode: gate_up → down as one expert-major launch (0 = two launches)
     int moe_bm2 = 0;                  // decode at ≤ 64 pairs: gate_up → down as one block-major launch — measured slower than the two launches (profiles/r03_moe_bm2_timeline.txt): off

@@ -1285,11 +1285,21 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         d.timeout = m->inlaunch_timeouts;
         return d;
     };
+    // The chain's attention role is one workgroup per (sequence, kv head) with no KV split: beyond ≈ 2048 keys per workgroup (more
+    // where T·nkv workgroups already cover the chip twice) the stand-alone split-KV attention wins — c=4 at kv 4096: 3.89 ms per
+    // step in the chain, 3.16 without; c=1: 3.31 vs 2.63; c=32 at kv 2048: 5.02 vs 5.37 the other way
+    auto chain_kv_ok = [&](int li) {
+        const int pattern = c.sliding_window_pattern;
+        const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
+        const int window = pattern == 0 ? c.sliding_window : (is_global ? 0 : c.sliding_window);
+        const long keys = window > 0 ? std::min<long>(sh.max_kv_len, window) : sh.max_kv_len;
+        return keys <= (long)knobs().chain_max_keys * std::max<long>(1, (long)T * nkv / 128);
+    };
     auto chain_ok = [&](int li) {
         if (c.num_experts <= 0 || !knobs().decode_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts) return false;
         if (!sh.all_single_token || !m->fuse_rope_attn || T > knobs().chain_max_rows || m->taps_enabled || sandwich) return false;
         if (c.tp_world > 1 && c.expert_parallel != 2) return false;             // (tensor-parallel attention: an all-reduce sits behind o_proj)
-        if (T * c.top_k > 1024 || c.top_k > 8 || T > 128) return false;
+        if (T * c.top_k > 1024 || c.top_k > 8 || T > 128 || !chain_kv_ok(li)) return false;
         return decode_chain_supports(chain_desc(li));
     };
     // dense models at 17–32 rows: the same launch for the attention half (tail of the previous layer's MLP — its down slabs +
@@ -1301,7 +1311,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         if (c.num_experts > 0 || !knobs().decode_chain || !knobs().dense_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts || !m->residual2) return false;
         if (!sh.all_single_token || !m->fuse_rope_attn || T > std::min(64, knobs().chain_max_rows) || m->taps_enabled || sandwich || c.tp_world > 1) return false;      // (beyond 64 rows the 64-row GEMM tiles win: Llama-3.1-8B c=96 5.56 vs 5.61 ms)
         if (!L.o.qw || !L.gate_up.qw || !L.down.qw || L.gate_up.perm || L.down.perm || L.qkv.perm || L.o.perm) return false;
-        if (L.qkv.bias || L.o.bias) return false;
+        if (L.qkv.bias || L.o.bias || !chain_kv_ok(li)) return false;
         DecodeChainDesc d = chain_desc(li);
         d.has_a = false;
         return decode_chain_supports(d);

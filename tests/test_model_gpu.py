@@ -683,6 +683,33 @@ def test_asymmetric_and_act_order_expert_stacks_at_qwen3_dims(pkg, asym, desc_ac
         assert np.array_equal(g[s][free], fed[s + 1][free]), s
 
 
+def test_decode_chain_yields_to_split_kv_attention_beyond_its_key_limit(pkg, forms, knobs):
+    """The chain's attention role is one workgroup per (sequence, kv head) without a KV split; beyond `chain_max_keys` keys per
+    workgroup (2048 by default, 256 here) the layer goes back to its stand-alone launches with split-KV attention.  The hipGraph
+    decode loop re-captures at the kv bucket where that happens; ids equal the eager loop's across the switch."""
+    from tests import modelgen
+    kw = dict(BENCH_DIMS["qwen3-30b-a3b"])
+    tm = modelgen.TinyModel(kw.pop("moe"), layers=2, vocab=2048, seed=49, max_seq_len=320, **kw)
+    c, plen = 4, 250
+    rng = np.random.default_rng(61)
+    prompts = [rng.integers(0, 2048, size=plen).astype(np.uint32) for _ in range(c)]
+    runs = []
+    for graph in (1, 0):
+        knobs.set(CHAIN_MAX_KEYS=256, NO_GRAPH=None if graph else 1)
+        hm = tm.hip_model(pkg, kv_num_blocks=c * 20, max_seqs=c, max_tokens=c * plen)
+        toks, _ = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+        forms.reset()
+        a = hm.decode_steps(list(range(c)), np.array(toks, np.uint32), 4)          # kv 250 … 254: bucket 256, the chain
+        below = forms.hits()
+        forms.reset()
+        b = hm.decode_steps(list(range(c)), a[-1], 8)                              # kv 254 … 262: bucket 512, beyond the limit
+        above = forms.hits()
+        assert below.get("decode_chain", 0) > 0 and "decode_chain" not in above, (below, above)
+        runs.append(np.concatenate([a, b]))
+        del hm
+    assert np.array_equal(runs[0], runs[1])
+
+
 # ── the same launch for the attention half of a DENSE layer (Llama-style: no q/k norm, no router) ─────────────────────────────
 # Three layers, so that the tail of a layer — the MLP's down projection as split-K slabs + residual + next input norm — runs as the
 # first role of the next layer's launch: oracle-followed rows, the five-launch layer on the same tokens, graph ≡ eager.
