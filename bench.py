@@ -104,6 +104,14 @@ def prefill(model, prompts, first_id, chunk_tokens, ttft_ms=None):
     out = []
     per = max(1, chunk_tokens // len(prompts[0]))
     t0 = time.perf_counter()
+    if len(prompts[0]) > chunk_tokens:                                  # long prompts: one sequence at a time, chunk_tokens per forward
+        for i, p in enumerate(prompts):
+            for o in range(0, len(p), chunk_tokens):
+                last = o + chunk_tokens >= len(p)
+                toks, _ = model.unified_forward([(first_id + i, p[o:o + chunk_tokens], o, last)], greedy=True)
+            out.append(int(toks[0]))
+            if ttft_ms is not None: ttft_ms.append((time.perf_counter() - t0) * 1e3)
+        return np.array(out, np.uint32)
     for i in range(0, len(prompts), per):
         items = [(first_id + i + j, p, 0, True) for j, p in enumerate(prompts[i:i + per])]
         toks, _ = model.unified_forward(items, greedy=True)        # returns after the tokens are on the host

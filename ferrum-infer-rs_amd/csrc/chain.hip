@@ -51,6 +51,7 @@ constexpr int CH_QKV_SLOT = 56, CH_QKV_R = 4;                           // q|k|v
 constexpr int CH_MAX_KVH = 16;
 constexpr int CH_SLOTS = CH_QKV_SLOT + CH_QKV_R * CH_MAX_KVH;
 constexpr int CH_GRAN = 10;              // granules per (token, router part): 8 candidates + max + Σexp
+constexpr int CH_MAX_SPLITS = 16;          // KV ranges per (sequence, kv head) in the attention role
 constexpr int CH_MAX_T = 128;
 constexpr int CH_GRAN_WORDS = CH_MAX_T * 4 * CH_GRAN * 2;      // T ≤ 64 tokens × Q ≤ 4 parts, 8-byte granules
 constexpr int CH_SMEM = 8 * 16 * (128 + 4) * 4 + 2 * 8 * 16 * 4 + 16 * 128 * 2 + 2 * 128 * 2;     // the attention role's arena: 73,216 B
@@ -66,6 +67,9 @@ struct ChainGemm {
 
 struct ChainArgs {
     int T, H, nq, nkv;
+    int attn_splits;              // KV ranges per (sequence, kv head): > 1 → partial states meet by ticket, the last arriver merges them
+    float* attn_partial;          // [T·nkv][splits][16 rows][HD + 4] fp32 (m, l in the pad)
+    unsigned* attn_tickets;       // [T·nkv] self-resetting
     int qkv_half;                 // q|k|v in 32-column blocks (one 16-row block only: few rows, every CU gets a block)
     int o_half;                   // o_proj likewise
     // role A: residual' = residual + Σ_k w_k·down_k; norm1 = rms_norm(residual')·ln_in   (absent for the first layer)
@@ -346,7 +350,8 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     __half* lds_kv = lds_q + 16 * HD;                                 // [2][HD]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int seq = wg % p.T, kvh = wg / p.T;
+    const int NS = p.attn_splits, split = wg % NS, unit = wg / NS;     // the splits of a (sequence, kv head) are neighbours
+    const int seq = unit % p.T, kvh = unit / p.T;
     CH_TL(0);
     const int G = p.nq / p.nkv;
     const int pos0 = (int)p.kv_lens[seq] - 1;
@@ -355,8 +360,11 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     const int win_lo = p.sliding_window > 0 ? max(0, row_pos + 1 - p.sliding_window) : 0;
     const int kv_end = pos0 + 1;
     const int kv_begin = p.sliding_window > 0 ? max(0, pos0 + 1 - p.sliding_window) : 0;
-    const int my_lo = (kv_begin / KV_BLOCK) / 2;
-    const int my_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;          // exclusive
+    const int all_lo = (kv_begin / KV_BLOCK) / 2;
+    const int all_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;         // exclusive: block pairs of the whole context
+    // this split's share of the pairs (the last split owns the pair with the new token: it patches and writes its K / V)
+    const int my_lo = all_lo + (int)((long)(all_hi - all_lo) * split / NS);
+    const int my_hi = all_lo + (int)((long)(all_hi - all_lo) * (split + 1) / NS);
     const int first = my_lo + wave;
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
     const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
@@ -426,7 +434,7 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
 #pragma unroll
         for (int s = 0; s < KS; s++) qf[s] = *reinterpret_cast<const half8*>(lds_q + b * HD + 32 * s + 8 * a);
         // the new token's K (wave 0) and V (wave 1) go to the cache (read by later launches only)
-        if (wave < 2) {
+        if (wave < 2 && split == NS - 1) {
             const long phys = p.block_tables[(long)seq * p.max_blocks + last_blk];
             const long toff = (phys * p.nkv + kvh) * kv_tile_elems(HD);
             for (int d = lane; d < HD; d += 64) {
@@ -538,8 +546,57 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
         for (int w = 0; w < NW; w++) acc += lds_o[(w * 16 + row) * OSTRIDE + d] * fw[w];
         ov[i] = acc;
     }
+    float Lm = L, Mm = M;
+    if (NS > 1) {
+        // several KV ranges per (sequence, kv head): every split leaves its state (m, l, unnormalised o) write-through and takes a
+        // ticket; the LAST to arrive reads all of them back (sc1) and merges them in split order — whoever it is, the same bits
+        static_assert(DPT == 4, "one 16-byte piece per thread");
+        constexpr int PST = HD + 4;
+        float* mine = p.attn_partial + ((long)unit * NS + split) * 16 * PST + row * PST;
+        const __amdgpu_buffer_rsrc_t pr_ = chain_rsrc(p.attn_partial, (long)p.T * p.nkv * NS * 16 * PST * 4);
+        const int my_off = (int)((mine - p.attn_partial) * 4);
+        if (row < G) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (float4v){ov[0], ov[1], ov[2], ov[3]}), pr_, my_off + dl * 16, 0, 16);
+            if (dl == 0) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (float4v){M, L, 0.f, 0.f}), pr_, my_off + HD * 4, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* s_tk = reinterpret_cast<int*>(lds_m);                     // (the merge above is done with lds_m)
+        if (threadIdx.x == 0) *s_tk = (int)__hip_atomic_fetch_add(p.attn_tickets + unit, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*s_tk != NS - 1) { CH_TL(2); CH_TL(3); return; }           // not the last: the merge (and the signal) is someone else's
+        if (threadIdx.x == 0) __hip_atomic_store(p.attn_tickets + unit, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (row < G) {
+            const int base = (int)(((long)unit * NS * 16 * PST + row * PST) * 4);
+            float ms[CH_MAX_SPLITS], ls[CH_MAX_SPLITS];
+            Mm = -INFINITY;
+#pragma unroll
+            for (int sp = 0; sp < CH_MAX_SPLITS; sp++) {
+                if (sp < NS) {
+                    const float4v ml = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(pr_, base + sp * 16 * PST * 4 + HD * 4, 0, 16));
+                    ms[sp] = ml[0]; ls[sp] = ml[1];
+                    Mm = fmaxf(Mm, ms[sp]);
+                }
+            }
+            const float Msafe = Mm == -INFINITY ? 0.f : Mm;
+            Lm = 0.f;
+#pragma unroll
+            for (int i = 0; i < DPT; i++) ov[i] = 0.f;
+#pragma unroll
+            for (int sp = 0; sp < CH_MAX_SPLITS; sp++) {
+                if (sp < NS) {
+                    const float4v os = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(pr_, base + sp * 16 * PST * 4 + dl * 16, 0, 16));
+                    const float f = __expf(ms[sp] - Msafe);
+                    Lm += ls[sp] * f;
+#pragma unroll
+                    for (int i = 0; i < DPT; i++) ov[i] += os[i] * f;
+                }
+            }
+        }
+    }
     if (row < G) {
-        const float inv = L > 0.f ? 1.0f / L : 0.f;
+        const float inv = Lm > 0.f ? 1.0f / Lm : 0.f;
         union { _Float16 h[4]; unsigned long long u; } o;
 #pragma unroll
         for (int i = 0; i < DPT; i++) o.h[i] = (_Float16)(ov[i] * inv);
@@ -547,7 +604,7 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), o.u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // 8-byte sc1 store
     }
     CH_TL(2);
-    chain_signal(p.cnt + CH_ATTN_SLOT * CH_STRIDE, wg % CH_ATTN_SH, CH_ATTN_R);
+    chain_signal(p.cnt + CH_ATTN_SLOT * CH_STRIDE, unit % CH_ATTN_SH, CH_ATTN_R);
     CH_TL(3);
 }
 
@@ -778,7 +835,7 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
     const int QB = p.qkv_half ? 32 : 64 * CH_QKV_NST;               // q|k|v block width
-    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv, n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
+    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * p.attn_splits, n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
         if (threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;
@@ -803,7 +860,7 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     if (wg < n_attn) { chain_role_attn(p, wg, smem); return; }
     wg -= n_attn;
     if (wg < n_o) {
-        const ChainEdge e{p.cnt + CH_ATTN_SLOT * CH_STRIDE, CH_ATTN_SH, CH_ATTN_R, (unsigned)n_attn};
+        const ChainEdge e{p.cnt + CH_ATTN_SLOT * CH_STRIDE, CH_ATTN_SH, CH_ATTN_R, (unsigned)(p.T * p.nkv)};      // (one arrival per (sequence, kv head): its last split's)
         if (p.o_half)
             chain_role_gemm<1, GPW_O, HAS_ZP, 2>(p.o, wg / RH, wg % RH, p.attn_out, p.o_out, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
                                                  wg % CH_O_SH, CH_O_R, p.timeout, smem, p);
@@ -831,6 +888,7 @@ bool decode_chain_supports(const DecodeChainDesc& d) {
     };
     if (!d.qkv || !d.o || !gemm_ok(*d.qkv) || !gemm_ok(*d.o)) return false;
     if (d.o->G / 8 != 4) return false;              // (the instantiated forms: o_proj's K slice per wave is four groups)
+    if (d.attn_splits > CH_MAX_SPLITS || (d.attn_splits > 1 && (!d.attn_partial || !d.attn_tickets))) return false;
     if (d.T < 1 || d.T > CH_MAX_T || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
     if (d.H % 32 != 0 || d.H > 8192 || d.qkv->k != d.H || d.qkv->n != (d.nq + 2 * d.nkv) * 128 || d.o->k != d.nq * 128 || d.o->n != d.H) return false;
     if (d.E <= 0) {       // dense model: role B is add + norm, role A sums the down projection's slabs (or adds its fp16 rows)
@@ -871,11 +929,13 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     a.tl = g_chain_timeline;
 #endif
     const int rh = (d.T + 15) / 16;
+    a.attn_splits = std::max(1, d.attn_splits); a.attn_partial = d.attn_partial; a.attn_tickets = d.attn_tickets;
     a.qkv_half = (knobs().chain_qkv_half && d.T <= 16) ? 1 : 0;
     // (narrow o_proj only: 2048 columns → 64 blocks; Llama-3.1-8B's 4096 columns are 64 blocks of 64 already: c=8 1.908 → 1.930 ms with 32)
     a.o_half = (knobs().chain_o_half && d.T <= 16 && d.o->n <= 2048) ? 1 : 0;
-    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
+    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv * a.attn_splits + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
     form_hit(FORM_DECODE_CHAIN);
+    if (a.attn_splits > 1) form_hit(FORM_CHAIN_ATTN_KV_SPLITS);
     if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     FH_CHECK_LAUNCH();

@@ -229,6 +229,7 @@ int fused_add_rms_norm_route_parts_f16(const __half* residual_in, __half* residu
 // ── the attention half of a MoE decode layer as one launch (chain.hip) ───────────────────────────────────────────────
 // [combine + add + norm of the previous layer's tail] → q|k|v → QK-norm / RoPE / KV write / attention → o_proj →
 // add + norm + router + top-k, as roles of one grid with in-launch hand-offs.  Buffers as the stand-alone kernels use them.
+constexpr int CHAIN_MAX_ATTN_WGS = 1024;      // (sequence, kv head, KV split) workgroups whose states the split buffer holds
 struct DecodeChainDesc {
     int T = 0, H = 0, nq = 0, nkv = 0, head_dim = 0;
     bool has_a = false;          // the previous layer's tail runs as the first role (else norm1 / res_a come from an earlier launch)
@@ -250,6 +251,9 @@ struct DecodeChainDesc {
     int E = 0, r_top_k = 0, Q = 0, norm_topk = 0;
     bool defer_merge = false;    // role B stops at the per-part candidate lists (cand / stats); the grouped GEMM that follows merges them
     RouteCand* cand = nullptr; float* stats = nullptr; unsigned* route_arrive = nullptr; int32_t* ids = nullptr; float* weights = nullptr;
+    int attn_splits = 1;           // KV ranges per (sequence, kv head) in the attention role (≤ 16); > 1 needs the two buffers below
+    float* attn_partial = nullptr; // [T·nkv·attn_splits][16][head_dim + 4] fp32
+    unsigned* attn_tickets = nullptr;   // [T·nkv] zeroed words (self-resetting)
     unsigned* cnt = nullptr;       // decode_chain_counter_words() words, zero on entry
     unsigned* cnt_next = nullptr;  // the other half of the double buffer: zeroed by this launch
     unsigned* timeout = nullptr;   // host-visible word, bumped by a bounded wait that gave up

@@ -32,7 +32,9 @@ struct Knobs {
     int sandwich_wide = 1;            // sandwich add + norms of ≤ 64 rows: 1024 threads per row, loads ahead of the reductions (0 = 256 threads)
     int chain_qkv_half = 1;           // decode chain at ≤ 16 rows: q|k|v in 32-column blocks (0 = 64)
     int chain_o_half = 1;             // … and o_proj
-    int chain_max_keys = 2048;        // decode chain only up to this many keys per attention workgroup (× T·nkv / 128)
+    int chain_split_keys = 256;       // decode chain attention: target keys per KV range (≤ 16 ranges per (sequence, kv head), see runner.hip); 0 = never split
+    int chain_attn_splits = 0;        // > 0: that many KV ranges whatever the context (experiments)
+    int chain_max_keys = 4096;        // decode chain only up to this many keys per attention workgroup (× T·nkv / 128)
     int dense_chain = 1;              // dense models at 17–32 rows: the attention half of the layer as the chain launch too (0 = five launches)
     int moe_em2 = 1;                  // decode: gate_up → down as one expert-major launch (0 = two launches)
     int moe_bm2 = 0;                  // decode at ≤ 64 pairs: gate_up → down as one block-major launch — measured slower than the two launches (profiles/r03_moe_bm2_timeline.txt): off
@@ -104,6 +106,7 @@ enum Form : int {
     FORM_DENSE_CHAIN,           // dense model: tail + q|k|v + attention + o_proj + add/norm as the one chain launch (chain.hip)
     FORM_TP_ALLREDUCE_NORM_FUSED, // tensor parallel: one-shot all-reduce + residual add + norm as one launch
     FORM_MOE_BLOCK_MAJOR_PAIR,  // ≤ 64 pairs: gate_up → down in one block-major launch (in-launch hand-off per 16-row block)
+    FORM_CHAIN_ATTN_KV_SPLITS,  // decode chain with several KV ranges per (sequence, kv head) in its attention role (ticket merge)
     FORM_COUNT
 };
 

@@ -399,7 +399,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->moe_gather_x, (void*)m->moe_gather_h, (void*)m->router_logits,
                     (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
-                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2,
+                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2, (void*)m->chain_attn_partial, (void*)m->chain_attn_tickets,
                     (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
                     (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch, (void*)m->greedy_opts_dev, (void*)m->tp_tmp,
                     (void*)m->expert_ids_local, (void*)m->ones, m->vp_pairs, m->vp_gathered})
@@ -807,6 +807,10 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
             FH_CHECK_HIP(hipHostMalloc((void**)&m->inlaunch_timeouts, 64, hipHostMallocDefault));
             *m->inlaunch_timeouts = 0u;
         }
+    }
+    if (!rc && m->em2_arrive && c.head_dim == 128) {
+        rc |= dev_alloc(&m->chain_attn_partial, (size_t)CHAIN_MAX_ATTN_WGS * 16 * (c.head_dim + 4));
+        rc |= dev_alloc(&m->chain_attn_tickets, (size_t)4096);
     }
     if (rc) return rc;
     // workspace: split-K slabs (≤ 64 rows) and split-KV attention partials
@@ -1283,17 +1287,31 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         d.Q = c.num_experts > 0 ? Q : 1;
         d.cand = m->route_cand; d.stats = m->route_stats; d.route_arrive = m->route_arrive; d.ids = m->expert_ids; d.weights = m->expert_w;
         d.timeout = m->inlaunch_timeouts;
+        // KV ranges per (sequence, kv head) in the attention role: ≈ chain_split_keys (256) keys each while the role stays within
+        // W workgroups — W = 32 … 256 growing with the (sequence, kv head) count: the chain holds one workgroup per CU, and ranges
+        // beyond that push the o_proj / router roles (which prefetch their weights while they wait) out of residence — but never
+        // more than ≈ 1024 keys per range while 256 workgroups allow (profiles/r03_chain_kv_splits.txt: c × context × ranges)
+        const long keys = d.sliding_window > 0 ? std::min<long>(sh.max_kv_len, d.sliding_window) : sh.max_kv_len;
+        const long units = (long)T * nkv, sk = std::max(1, knobs().chain_split_keys);
+        const long cap_w = std::min<long>(256, std::max<long>(4 * units, std::min<long>(8 * units, 64)));
+        long ns_l = std::min<long>({16, std::max<long>(1, cap_w / units), (keys + sk - 1) / sk});
+        ns_l = std::max<long>(ns_l, std::min<long>({16, std::max<long>(1, 256 / units), (keys + 4 * sk - 1) / (4 * sk)}));
+        int ns = keys <= 2 * sk ? 1 : (int)std::max<long>(1, ns_l);        // (≤ 512 keys: one range — c=4 at 256+: 2.31 vs 2.36 ms split in two)
+        if (knobs().chain_attn_splits > 0) ns = std::min(16, knobs().chain_attn_splits);
+        while (ns > 1 && units * ns > CHAIN_MAX_ATTN_WGS) ns--;
+        if (!m->chain_attn_partial || units > 4096 || knobs().chain_split_keys <= 0) ns = 1;
+        d.attn_splits = ns; d.attn_partial = m->chain_attn_partial; d.attn_tickets = m->chain_attn_tickets;
         return d;
     };
-    // The chain's attention role is one workgroup per (sequence, kv head) with no KV split: beyond ≈ 2048 keys per workgroup (more
-    // where T·nkv workgroups already cover the chip twice) the stand-alone split-KV attention wins — c=4 at kv 4096: 3.89 ms per
-    // step in the chain, 3.16 without; c=1: 3.31 vs 2.63; c=32 at kv 2048: 5.02 vs 5.37 the other way
+    // The chain stays the layer's form while one attention workgroup has ≤ chain_max_keys (4096) keys to stream (more where T·nkv
+    // workgroups already cover the chip twice); with its KV ranges it beat the stand-alone split-KV launches at every point measured
+    // (c=1 at 32 k keys: 3.06 vs 3.52 ms per step; c=4 at 16 k: 3.62 vs 3.96; c=32 at 8 k: 7.85 vs 8.24) — beyond that is unmeasured
     auto chain_kv_ok = [&](int li) {
         const int pattern = c.sliding_window_pattern;
         const bool is_global = pattern == 0 || (li + 1) % pattern == 0;
         const int window = pattern == 0 ? c.sliding_window : (is_global ? 0 : c.sliding_window);
         const long keys = window > 0 ? std::min<long>(sh.max_kv_len, window) : sh.max_kv_len;
-        return keys <= (long)knobs().chain_max_keys * std::max<long>(1, (long)T * nkv / 128);
+        return keys <= (long)knobs().chain_max_keys * chain_desc(li).attn_splits * std::max<long>(1, (long)T * nkv / 128);
     };
     auto chain_ok = [&](int li) {
         if (c.num_experts <= 0 || !knobs().decode_chain || m->em2_failed || !m->em2_arrive || !m->inlaunch_timeouts) return false;

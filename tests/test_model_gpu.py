@@ -710,6 +710,76 @@ def test_decode_chain_yields_to_split_kv_attention_beyond_its_key_limit(pkg, for
     assert np.array_equal(runs[0], runs[1])
 
 
+def test_decode_chain_attention_kv_splits(pkg, forms, knobs):
+    """Long contexts inside the chain: the attention role takes several KV ranges per (sequence, kv head) — ≈ `chain_split_keys`
+    keys each (256 by default within a workgroup budget, runner.hip; 16 and 5 ranges forced here), every range's workgroup leaving its (m, l, o) state write-through and taking
+    a ticket, the last to arrive merging all of them in range order.  Ragged contexts (one shorter than the number of ranges:
+    empty ranges), oracle-followed rows, the unsplit chain and the stand-alone launches on the same tokens, graph ≡ eager."""
+    from tests import modelgen
+    from oracle import oracle as O
+    kw = dict(BENCH_DIMS["qwen3-30b-a3b"])
+    tm = modelgen.TinyModel(kw.pop("moe"), layers=2, vocab=2048, seed=57, max_seq_len=320, **kw)
+    lens = [300, 5, 129, 250, 37, 64]
+    c, steps = len(lens), 3
+    followed = [0, 1, 2]
+    rng = np.random.default_rng(67)
+    prompts = [rng.integers(0, 2048, size=n).astype(np.uint32) for n in lens]
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    par = modelgen.Parity("decode-chain-kv-splits", cos_min=0.999, rel_max=5e-2)
+    outs, ids = {}, {}
+    fed = None
+    for mode in ("split", "split5", "unsplit", "launches"):
+        split = mode.startswith("split")
+        knobs.set(CHAIN_ATTN_SPLITS=(16 if mode == "split" else 5) if split else None, CHAIN_SPLIT_KEYS=None if split else 0,
+                  CHAIN_MAX_KEYS=1 << 20, DECODE_CHAIN=0 if mode == "launches" else 1, MOE_EM2=0 if mode == "launches" else 1)
+        hm = tm.hip_model(pkg, kv_num_blocks=c * 22, max_seqs=c, max_tokens=sum(lens))
+        toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        cur = np.array(toks, np.uint32)
+        if fed is None:
+            for i in followed: cur[i] = par.check(f"prefill/{i}", om.forward(i, prompts[i], 0), lg[i], toks[i], om.last_route_gap_rel())
+            feds = [cur.copy()]
+        else:
+            cur = fed[0].copy()
+        forms.reset()
+        out = []
+        for s in range(steps):
+            toks, lg = hm.unified_forward([(i, [int(cur[i])], lens[i] + s, True) for i in range(c)], greedy=True, want_logits=True)
+            out.append((np.array(toks, np.uint32), lg.copy()))
+            cur = np.array(toks, np.uint32)
+            if fed is None:
+                for i in followed:
+                    cur[i] = par.check(f"step{s}/{i}", om.forward(i, np.array([feds[-1][i]], np.uint32), lens[i] + s), lg[i], toks[i], om.last_route_gap_rel())
+                feds.append(cur.copy())
+            else:
+                cur = fed[s + 1].copy()
+        hits = forms.hits()
+        if fed is None: fed = feds
+        assert (hits.get("decode_chain", 0) == 2 * steps) == (mode != "launches"), (mode, hits)
+        assert (hits.get("chain_attn_kv_splits", 0) == 2 * steps) == split, (mode, hits)
+        outs[mode] = out
+        if mode == "split":
+            ids["graph"] = hm.decode_steps(list(range(c)), fed[-1], 4)
+            del hm
+            knobs.set(NO_GRAPH=1)
+            hm = tm.hip_model(pkg, kv_num_blocks=c * 22, max_seqs=c, max_tokens=sum(lens))
+            hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True)
+            for s in range(steps): hm.unified_forward([(i, [int(fed[s][i])], lens[i] + s, True) for i in range(c)], greedy=True)
+            ids["eager"] = hm.decode_steps(list(range(c)), fed[-1], 4)
+            knobs.set(NO_GRAPH=None)
+        del hm
+    O.set_threads(1)
+    par.finish(max_mismatches=1, max_route_ties=1)
+    assert np.array_equal(ids["graph"], ids["eager"])
+    for mine, other in (("split", "unsplit"), ("split", "launches"), ("split5", "unsplit")):
+        for s, ((t1, l1), (t0, l0)) in enumerate(zip(outs[mine], outs[other])):
+            err = np.abs(l1 - l0).max(axis=1)
+            assert float(err.max()) < 0.02 * float(np.abs(l0).max()), (other, s, float(err.max()))
+            srt = np.sort(l0, axis=1)
+            for r in np.nonzero(t1 != t0)[0]:
+                assert srt[r, -1] - srt[r, -2] <= 2 * err[r] + 1e-6, (other, s, int(r))
+
+
 # ── the same launch for the attention half of a DENSE layer (Llama-style: no q/k norm, no router) ─────────────────────────────
 # Three layers, so that the tail of a layer — the MLP's down projection as split-K slabs + residual + next input norm — runs as the
 # first role of the next layer's launch: oracle-followed rows, the five-launch layer on the same tokens, graph ≡ eager.
