@@ -67,9 +67,6 @@ struct ChainGemm {
 
 struct ChainArgs {
     int T, H, nq, nkv;
-    int attn_splits;              // KV ranges per (sequence, kv head): > 1 → partial states meet by ticket, the last arriver merges them
-    float* attn_partial;          // [T·nkv][splits][16 rows][HD + 4] fp32 (m, l in the pad)
-    unsigned* attn_tickets;       // [T·nkv] self-resetting
     int qkv_half;                 // q|k|v in 32-column blocks (one 16-row block only: few rows, every CU gets a block)
     int o_half;                   // o_proj likewise
     // role A: residual' = residual + Σ_k w_k·down_k; norm1 = rms_norm(residual')·ln_in   (absent for the first layer)
@@ -99,6 +96,10 @@ struct ChainArgs {
 #ifdef FERRUM_HIP_EXPERIMENTS
     unsigned long long* tl;       // development: per-workgroup wall-clock stamps (tools/exp_timeline_chain.py)
 #endif
+    // (behind everything else: the one-range kernel's argument layout is the one it was tuned with)
+    int attn_splits;              // KV ranges per (sequence, kv head): > 1 → partial states meet by ticket, the last arriver merges them
+    float* attn_partial;          // [T·nkv][splits][16 rows][HD + 4] fp32 (m, l in the pad)
+    unsigned* attn_tickets;       // [T·nkv] self-resetting
 };
 #ifdef FERRUM_HIP_EXPERIMENTS
 unsigned long long* g_chain_timeline = nullptr;
@@ -341,6 +342,7 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
 }
 
 // ── attention role: paged_attn_kernel<128, true, 8> (decode, one new token per sequence) ────────────────────────────────
+template <bool KVS>
 __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsigned char* smem) {
     constexpr int HD = 128, NW = CH_W, DT = HD / 16, KS = HD / 32, OSTRIDE = HD + 4;
     float* lds_o = reinterpret_cast<float*>(smem);                    // [NW·16][OSTRIDE]
@@ -350,7 +352,10 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     __half* lds_kv = lds_q + 16 * HD;                                 // [2][HD]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
-    const int NS = p.attn_splits, split = wg % NS, unit = wg / NS;     // the splits of a (sequence, kv head) are neighbours
+    // (the ranges of a (sequence, kv head) are neighbours; one range: no divisions on the way to the first K/V request — the role's
+    // later workgroups enter when the q|k|v blocks leave their CUs, with the projection already done)
+    const int NS = KVS ? p.attn_splits : 1;                          // (a kernel of its own: the one-range form stays as lean as it was)
+    const int unit = NS == 1 ? wg : (int)((unsigned)wg / (unsigned)NS), split = NS == 1 ? 0 : wg - unit * NS;
     const int seq = unit % p.T, kvh = unit / p.T;
     CH_TL(0);
     const int G = p.nq / p.nkv;
@@ -363,8 +368,9 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     const int all_lo = (kv_begin / KV_BLOCK) / 2;
     const int all_hi = (cdiv_dev(kv_end, KV_BLOCK) + 1) / 2;         // exclusive: block pairs of the whole context
     // this split's share of the pairs (the last split owns the pair with the new token: it patches and writes its K / V)
-    const int my_lo = all_lo + (int)((long)(all_hi - all_lo) * split / NS);
-    const int my_hi = all_lo + (int)((long)(all_hi - all_lo) * (split + 1) / NS);
+    const unsigned np_all = (unsigned)max(0, all_hi - all_lo);       // (≤ 2^16 pairs × ≤ 16 ranges: 32-bit)
+    const int my_lo = NS == 1 ? all_lo : all_lo + (int)(np_all * (unsigned)split / (unsigned)NS);
+    const int my_hi = NS == 1 ? all_hi : all_lo + (int)(np_all * (unsigned)(split + 1) / (unsigned)NS);
     const int first = my_lo + wave;
     const int nblocks = cdiv_dev(kv_end, KV_BLOCK);
     const int32_t* bt = p.block_tables + (long)seq * p.max_blocks;
@@ -830,12 +836,12 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
     CH_TL(3);
 }
 
-template <int GPW_QKV, int GPW_O, bool HAS_ZP>
+template <int GPW_QKV, int GPW_O, bool HAS_ZP, bool KVS = false>
 __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
     const int QB = p.qkv_half ? 32 : 64 * CH_QKV_NST;               // q|k|v block width
-    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * p.attn_splits, n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
+    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * (KVS ? p.attn_splits : 1), n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
         if (threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;
@@ -857,7 +863,7 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
         return;
     }
     wg -= n_qkv;
-    if (wg < n_attn) { chain_role_attn(p, wg, smem); return; }
+    if (wg < n_attn) { chain_role_attn<KVS>(p, wg, smem); return; }
     wg -= n_attn;
     if (wg < n_o) {
         const ChainEdge e{p.cnt + CH_ATTN_SLOT * CH_STRIDE, CH_ATTN_SH, CH_ATTN_R, (unsigned)(p.T * p.nkv)};      // (one arrival per (sequence, kv head): its last split's)
@@ -936,7 +942,10 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv * a.attn_splits + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
     form_hit(FORM_DECODE_CHAIN);
     if (a.attn_splits > 1) form_hit(FORM_CHAIN_ATTN_KV_SPLITS);
-    if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
+    if (a.attn_splits > 1) {
+        if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false, true>), dim3(blocks), dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false, true>), dim3(blocks), dim3(512), 0, stream, a);
+    } else if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     FH_CHECK_LAUNCH();
     return 0;
