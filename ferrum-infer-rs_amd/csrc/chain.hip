@@ -96,6 +96,7 @@ struct ChainArgs {
 #ifdef FERRUM_HIP_EXPERIMENTS
     unsigned long long* tl;       // development: per-workgroup wall-clock stamps (tools/exp_timeline_chain.py)
 #endif
+    int qkv_wide;                 // q|k|v in 128-column blocks (one head per workgroup)
     // (behind everything else: the one-range kernel's argument layout is the one it was tuned with)
     int attn_splits;              // KV ranges per (sequence, kv head): > 1 → partial states meet by ticket, the last arriver merges them
     float* attn_partial;          // [T·nkv][splits][16 rows][HD + 4] fp32 (m, l in the pad)
@@ -408,7 +409,7 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     // norm weights and the RoPE row of this position do not depend on the projection either
     __builtin_amdgcn_sched_barrier(0);
     // the q|k|v columns of this kv head: G + 2 heads, each one workgroup per 16-row block of the projection role
-    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (p.qkv_half ? 4 : 2 / CH_QKV_NST) * ((p.T + 15) >> 4)), p.timeout);
+    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (p.qkv_half ? 4 : (p.qkv_wide ? 1 : 2)) * ((p.T + 15) >> 4)), p.timeout);
     CH_TL(1);
     half8 qf[KS];
     {
@@ -840,7 +841,7 @@ template <int GPW_QKV, int GPW_O, bool HAS_ZP, bool KVS = false>
 __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
-    const int QB = p.qkv_half ? 32 : 64 * CH_QKV_NST;               // q|k|v block width
+    const int QB = p.qkv_half ? 32 : (p.qkv_wide ? 128 : 64);       // q|k|v block width
     const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * (KVS ? p.attn_splits : 1), n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
@@ -857,7 +858,13 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
         if (p.qkv_half)
             chain_role_gemm<1, GPW_QKV, HAS_ZP, 2>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
                                                    p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
-        else
+        else if (GPW_QKV == 2 && p.qkv_wide) {
+            // one head (128 columns) per workgroup: half as many workgroups of twice the bytes — taken where the narrow blocks and the
+            // attention role together exceed the workgroups the chip holds at once and the wide ones do not (decode_chain_f16)
+            if constexpr (GPW_QKV == 2)
+                chain_role_gemm<2, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
+                                                    p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
+        } else
             chain_role_gemm<CH_QKV_NST, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
                                                          p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
         return;
@@ -939,9 +946,19 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     a.qkv_half = (knobs().chain_qkv_half && d.T <= 16) ? 1 : 0;
     // (narrow o_proj only: 2048 columns → 64 blocks; Llama-3.1-8B's 4096 columns are 64 blocks of 64 already: c=8 1.908 → 1.930 ms with 32)
     a.o_half = (knobs().chain_o_half && d.T <= 16 && d.o->n <= 2048) ? 1 : 0;
-    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : 64 * CH_QKV_NST) * rh + d.T * d.nkv * a.attn_splits + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
+    // 128-column q|k|v blocks (hidden 2048 only: the two-group weight ring): where the 64-column blocks + the attention role do not fit
+    // the chip's resident workgroups, the role's last workgroups enter behind the projection (≈ 2.7 µs of K/V round trips on the
+    // critical path, profiles/r03_decode_chain_timeline.txt) — c=32 4.025 → 3.995 ms per step, c=64 4.83 → 4.69; c=20–24 (where they fit) 3 % slower
+    a.qkv_wide = 0;
+    if (!a.qkv_half && d.qkv->G / 8 == 2) {
+        const int wide = knobs().chain_qkv_wide;
+        const int n64 = d.qkv->n / 64 * rh, n_at = d.T * d.nkv * a.attn_splits;
+        a.qkv_wide = wide >= 0 ? (wide > 0) : (n64 + n_at > knobs().chain_slots);
+    }
+    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : (a.qkv_wide ? 128 : 64)) * rh + d.T * d.nkv * a.attn_splits + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
     form_hit(FORM_DECODE_CHAIN);
     if (a.attn_splits > 1) form_hit(FORM_CHAIN_ATTN_KV_SPLITS);
+    if (a.qkv_wide) form_hit(FORM_CHAIN_QKV_WIDE);
     if (a.attn_splits > 1) {
         if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false, true>), dim3(blocks), dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false, true>), dim3(blocks), dim3(512), 0, stream, a);

@@ -603,6 +603,9 @@ def test_decode_chain_and_merged_moe_launch_across_layers(pkg, c, forms, knobs):
     out1, fed, hits, hm1 = drive(1, lambda tag, ref, lg, tok: par.check(tag, ref, lg, tok, gap()))
     drive.fed = fed
     assert hits.get("decode_chain", 0) == 3 * steps, hits             # one chain launch per layer and step
+    # 128-column q|k|v blocks exactly where the 64-column ones + the attention role exceed the 256 resident workgroups
+    wide = c > 16 and 80 * ((c + 15) // 16) + 4 * c > 256
+    assert hits.get("chain_qkv_wide", 0) == (3 * steps if wide else 0), hits
     if 8 * c * 8 >= 9 * 128: assert hits.get("moe_expert_major_pair", 0) == 3 * steps, hits      # (from 1.125 pairs per expert: c ≥ 18)
     # ≤ 2 tokens (the K-split gate_up form): role B stops at the per-part candidate lists; the gate_up launch's prologue merges them (under nothing the
     # chain waits for)
