@@ -47,6 +47,7 @@ void reload_knobs() {
     k.chain_max_keys = env_int("FERRUM_HIP_CHAIN_MAX_KEYS", 4096);
     k.chain_split_keys = env_int("FERRUM_HIP_CHAIN_SPLIT_KEYS", 256);
     k.chain_attn_splits = env_int("FERRUM_HIP_CHAIN_ATTN_SPLITS", 0);
+    k.route_gemm_topk = env_int("FERRUM_HIP_ROUTE_GEMM_TOPK", 1);
     k.chain_qkv_wide = env_int("FERRUM_HIP_CHAIN_QKV_WIDE", -1);
     k.chain_slots = env_int("FERRUM_HIP_CHAIN_SLOTS", 256);
     k.chain_o_half = env_int("FERRUM_HIP_CHAIN_O_HALF", 1);
@@ -83,7 +84,7 @@ static const char* const g_form_names[FORM_COUNT] = {
     "moe_expert_major", "moe_inline_align", "moe_block16", "moe_tile64", "moe_tile32", "moe_tile_big", "moe_merge_route", "route_split",
     "route_fused", "route_gemm", "dense_slab_chain", "graph_capture", "graph_replay", "tp_allreduce_rccl",
     "tp_allreduce_loopback", "tp_allreduce_oneshot", "f16_dense_linear", "w4_fused_tail", "attn_resident", "w4_big", "w4_ldsk", "gather_columns",
-    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "dense_chain", "tp_allreduce_norm_fused", "moe_block_major_pair", "chain_attn_kv_splits", "chain_qkv_wide"};
+    "perm_producer", "moe_expert_major_pair", "decode_chain", "moe_deferred_merge", "dense_chain", "tp_allreduce_norm_fused", "moe_block_major_pair", "chain_attn_kv_splits", "chain_qkv_wide", "route_gemm_topk"};
 const char* form_name(int f) { return f >= 0 && f < FORM_COUNT ? g_form_names[f] : nullptr; }
 }  // namespace fh
 

@@ -181,6 +181,10 @@ size_t paged_attention_workspace_bytes(int total_q_tokens, int num_heads, int he
 // ── MoE routing (moe.hip) ────────────────────────────────────────────────────
 int moe_route_topk_softmax_f16(const __half* logits, int32_t* expert_ids, float* expert_weights, int tokens,
                                int num_experts, int top_k, int norm_topk_prob, hipStream_t s);
+// prefill router in one launch (E = 128): logits on the matrix cores, softmax + top-k in the same workgroup (moe.hip)
+bool moe_route_gemm_topk_supports(int num_experts, int hidden, int top_k);
+int moe_route_gemm_topk_f16(const __half* x, const __half* router_f16t, int32_t* expert_ids, float* expert_weights, int tokens,
+                            int num_experts, int hidden, int top_k, int norm_topk_prob, hipStream_t s);
 int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* expert_weights, int tokens,
                                int num_experts, int top_k, int norm_topk_prob, hipStream_t s);
 int moe_align_block_size(const int32_t* expert_ids, int32_t* sorted_token_ids, int32_t* block_ids,

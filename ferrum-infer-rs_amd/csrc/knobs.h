@@ -35,6 +35,7 @@ struct Knobs {
     int chain_split_keys = 256;       // decode chain attention: target keys per KV range (≤ 16 ranges per (sequence, kv head), see runner.hip); 0 = never split
     int chain_qkv_wide = -1;          // decode chain q|k|v blocks of 128 columns: -1 = where the 64-column blocks + attention exceed chain_slots
     int chain_slots = 256;            // workgroups of the chain kernel the chip holds at once (one per CU)
+    int route_gemm_topk = 1;          // prefill router GEMM + top-k as one launch (E = 128)
     int chain_attn_splits = 0;        // > 0: that many KV ranges whatever the context (experiments)
     int chain_max_keys = 4096;        // decode chain only up to this many keys per attention workgroup (× T·nkv / 128)
     int dense_chain = 1;              // dense models at 17–32 rows: the attention half of the layer as the chain launch too (0 = five launches)
@@ -110,6 +111,7 @@ enum Form : int {
     FORM_MOE_BLOCK_MAJOR_PAIR,  // ≤ 64 pairs: gate_up → down in one block-major launch (in-launch hand-off per 16-row block)
     FORM_CHAIN_ATTN_KV_SPLITS,  // decode chain with several KV ranges per (sequence, kv head) in its attention role (ticket merge)
     FORM_CHAIN_QKV_WIDE,        // decode chain with 128-column q|k|v blocks (the narrow ones + attention exceed the resident workgroups)
+    FORM_ROUTE_GEMM_TOPK,       // prefill router: logits (MFMA) + softmax + top-k in one launch (moe_route_gemm_topk_kernel)
     FORM_COUNT
 };
 

@@ -96,6 +96,148 @@ int moe_route_topk_softmax_f32(const float* logits, int32_t* expert_ids, float* 
     return 0;
 }
 
+// ── prefill router in ONE launch: logits = x · Wrᵀ on the matrix cores, then softmax + top-k, 32 tokens per workgroup ──────────
+// Replaces f16t GEMM (split-K 4) → reduce → one-wave-per-token top-k (27 + 7 + 16 µs per layer at 8192 tokens): the logits never
+// leave the CU.  E = 128 (eight 16-expert tiles of the f16t layout, w4_gemm.hip), K split over the four waves (each wave: 32
+// tokens × 128 experts × K/4), partial sums meet in LDS in wave order; then 16 lanes per token (8 experts each, e = l + 16·i), four
+// tokens per wave pass: f32 softmax over all experts, k argmax-mask passes (strict > within a lane's ascending experts, ties →
+// lower id across lanes), renormalised by the selected sum — router.rs:113-195 / moe_router.cu:32 as moe_route_kernel above.
+constexpr int RG_TOK = 32, RG_LD = 132;
+template <int CTRL>
+__device__ __forceinline__ void rg_argmax_step(float& best, int& idx) {      // (larger value, then smaller index): a total order, any pairing
+    const float ob = dpp_move<CTRL>(best);
+    const int oi = __builtin_amdgcn_update_dpp(0, idx, CTRL, 0xF, 0xF, true);
+    if (ob > best || (ob == best && oi < idx)) { best = ob; idx = oi; }
+}
+__global__ __launch_bounds__(256) void moe_route_gemm_topk_kernel(const __half* __restrict__ x, const __half* __restrict__ wt,
+                                                                   int32_t* __restrict__ ids, float* __restrict__ weights, int T,
+                                                                   int K, int top_k, int norm_topk_prob) {
+    extern __shared__ __attribute__((aligned(16))) float rg_lds[];     // [4][32][RG_LD] partials; the logits replace wave 0's
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int a = lane >> 4, b = lane & 15;
+    const int t0 = blockIdx.x * RG_TOK;
+    const int ksteps = K >> 5, s0 = ksteps * wave / 4, s1 = ksteps * (wave + 1) / 4;
+    const __half* xrow[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+        const int r = t0 + mt * 16 + b;
+        xrow[mt] = x + (long)(r < T ? r : T - 1) * K + 8 * a;
+    }
+    const __half* wl = wt + (long)lane * 8;
+    float4v acc[2][8];
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++) acc[mt][nt] = (float4v){0.f, 0.f, 0.f, 0.f};
+    // two k-steps per ring slot, two slots: 2–4 k-steps (20–40 KiB per wave, the router from L2) in flight
+    half8 bw[2][2][8], ax[2][2][2];
+    auto issue = [&](int buf, int s) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int su = s + u < s1 ? s + u : s1 - 1;
+#pragma unroll
+            for (int mt = 0; mt < 2; mt++) ax[buf][u][mt] = *reinterpret_cast<const half8*>(xrow[mt] + su * 32);
+#pragma unroll
+            for (int nt = 0; nt < 8; nt++) bw[buf][u][nt] = *reinterpret_cast<const half8*>(wl + ((long)nt * ksteps + su) * 512);
+        }
+    };
+    auto consume = [&](int buf, int s) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (s + u < s1) {
+#pragma unroll
+                for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+                    for (int mt = 0; mt < 2; mt++)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ax[buf][u][mt], bw[buf][u][nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    };
+    if (s0 < s1) issue(0, s0);
+    for (int s = s0; s < s1; s += 4) {
+        if (s + 2 < s1) issue(1, s + 2);
+        consume(0, s);
+        if (s + 4 < s1) issue(0, s + 4);
+        if (s + 2 < s1) consume(1, s + 2);
+    }
+    float* part = rg_lds + (long)wave * RG_TOK * RG_LD;
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+        for (int nt = 0; nt < 8; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) part[(mt * 16 + 4 * a + r) * RG_LD + nt * 16 + b] = acc[mt][nt][r];
+    __syncthreads();
+    float* logit = rg_lds;                 // (in place of wave 0's partials: every thread reads its own 16 sums' inputs first)
+    {
+        const int tok = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            float v = rg_lds[tok * RG_LD + c0 + j];
+#pragma unroll
+            for (int w = 1; w < 4; w++) v += rg_lds[(w * RG_TOK + tok) * RG_LD + c0 + j];
+            logit[tok * RG_LD + c0 + j] = v;
+        }
+    }
+    __syncthreads();
+    const int grp = lane >> 4, l16 = lane & 15;
+    for (int pass = 0; pass < 2; pass++) {
+        const int tl = wave * 8 + pass * 4 + grp, tok = t0 + tl;
+        float v[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v[i] = logit[tl * RG_LD + l16 + 16 * i]; mx = fmaxf(mx, v[i]); }
+        // (reductions inside the token's 16-lane row by DPP — quad permutes, row_half_mirror, row_mirror — not ds_bpermute)
+        mx = fmaxf(mx, dpp_move<0xB1>(mx)); mx = fmaxf(mx, dpp_move<0x4E>(mx)); mx = fmaxf(mx, dpp_move<0x141>(mx)); mx = fmaxf(mx, dpp_move<0x140>(mx));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v[i] = expf(v[i] - mx); sum += v[i]; }
+        sum += dpp_move<0xB1>(sum); sum += dpp_move<0x4E>(sum); sum += dpp_move<0x141>(sum); sum += dpp_move<0x140>(sum);
+        const float inv_sum = 1.0f / sum;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] *= inv_sum;
+        float sel_sum = 0.f, my_w = 0.f;
+        int my_id = 0;
+        for (int k = 0; k < top_k; k++) {
+            float best = -INFINITY;
+            int best_idx = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (v[i] > best) { best = v[i]; best_idx = l16 + 16 * i; }
+            rg_argmax_step<0xB1>(best, best_idx); rg_argmax_step<0x4E>(best, best_idx);
+            rg_argmax_step<0x141>(best, best_idx); rg_argmax_step<0x140>(best, best_idx);
+            if (best_idx == 0x7fffffff) best_idx = 0;
+            sel_sum += best;
+            if (l16 == k) { my_w = best; my_id = best_idx; }
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (l16 + 16 * i == best_idx) v[i] = -INFINITY;
+        }
+        if (l16 < top_k && tok < T) {
+            float w = my_w;
+            if (norm_topk_prob) w = sel_sum > 0.f ? w * (1.0f / sel_sum) : 1.0f / (float)top_k;
+            ids[(long)tok * top_k + l16] = my_id;
+            weights[(long)tok * top_k + l16] = w;
+        }
+    }
+}
+
+bool moe_route_gemm_topk_supports(int num_experts, int hidden, int top_k) {
+    return num_experts == 128 && hidden % 128 == 0 && top_k >= 1 && top_k <= 16;
+}
+int moe_route_gemm_topk_f16(const __half* x, const __half* router_f16t, int32_t* expert_ids, float* expert_weights, int tokens,
+                            int num_experts, int hidden, int top_k, int norm_topk_prob, hipStream_t s) {
+    if (tokens <= 0) return 0;
+    FH_REQUIRE(moe_route_gemm_topk_supports(num_experts, hidden, top_k), "route gemm+top-k: E=%d H=%d k=%d unsupported", num_experts, hidden, top_k);
+    const size_t lds = (size_t)4 * RG_TOK * RG_LD * sizeof(float);
+    static bool attr = false;
+    if (!attr) { FH_CHECK_HIP(hipFuncSetAttribute((const void*)moe_route_gemm_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    hipLaunchKernelGGL(moe_route_gemm_topk_kernel, dim3(cdiv(tokens, RG_TOK)), dim3(256), lds, s, x, router_f16t, expert_ids, expert_weights,
+                       tokens, hidden, top_k, norm_topk_prob);
+    FH_CHECK_LAUNCH();
+    return 0;
+}
+
 // One workgroup per expert: histogram of every pair (LDS atomics, order-free) → prefixes →
 // ordered compaction of this expert's pair ids (ballot prefix keeps ascending pair id).  Three outputs share the walk:
 //   MODE 0  moe_align_block_size_pair_ids (capabilities.rs:449): sorted_token_ids holds pair ids p = token·top_k + slot

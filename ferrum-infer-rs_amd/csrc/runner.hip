@@ -1566,8 +1566,14 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
                     // prefill: one workgroup per token would pull the whole router (E·H·2 B) from L2 per token (2048 tokens:
                     // 1 GB, 95 µs) — run the router as a GEMM over all tokens instead, then the top-k kernel
                     RUN(fused_add_rms_norm_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, T, H, s));
-                    RUN(f16t_gemm_f32out(m->norm_out, L.router, m->router_logits, T, E, H, m->workspace, m->workspace_bytes, s));
-                    RUN(moe_route_topk_softmax_f32(m->router_logits, m->expert_ids, m->expert_w, T, E, K, c.norm_topk_prob, s));
+                    if (knobs().route_gemm_topk && !m->taps_enabled && moe_route_gemm_topk_supports(E, H, K)) {
+                        // … and the top-k in the same workgroups: the logits stay on the CU (8192 tokens: 27 + 7 + 16 µs → one launch)
+                        form_hit(FORM_ROUTE_GEMM_TOPK);
+                        RUN(moe_route_gemm_topk_f16(m->norm_out, L.router, m->expert_ids, m->expert_w, T, E, H, K, c.norm_topk_prob, s));
+                    } else {
+                        RUN(f16t_gemm_f32out(m->norm_out, L.router, m->router_logits, T, E, H, m->workspace, m->workspace_bytes, s));
+                        RUN(moe_route_topk_softmax_f32(m->router_logits, m->expert_ids, m->expert_w, T, E, K, c.norm_topk_prob, s));
+                    }
                 } else {
                     // residual += o; post-attention norm; router logits; top-k — one launch (fused.hip B)
                     RUN(fused_add_rms_norm_route_f16(m->residual, m->o_out, L.post_ln, c.rms_eps, m->norm_out, L.router, E, K,

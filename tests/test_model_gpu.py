@@ -850,6 +850,44 @@ def test_dense_decode_chain_across_layers(pkg, c, forms, knobs):
             assert srt[r, -1] - srt[r, -2] <= 2 * err[r] + 1e-6, (s, int(r))
 
 
+def test_prefill_router_gemm_and_top_k_in_one_launch(pkg, forms, knobs):
+    """Prefill of ≥ 512 tokens on a 128-expert model: router logits on the matrix cores + softmax + top-k in ONE launch
+    (`moe_route_gemm_topk_kernel`) against the three launches it replaces (f16t GEMM with split-K → reduce → one wave per token):
+    the K split and the order of the partial sums are the same, the softmax denominator is summed over a different lane layout —
+    logits of the sampled rows within fp16 noise, ids equal unless a near-tie; ragged prompts (a tail block of < 32 tokens), and an
+    oracle-followed row."""
+    from tests import modelgen
+    from oracle import oracle as O
+    kw = dict(BENCH_DIMS["qwen3-30b-a3b"])
+    tm = modelgen.TinyModel(kw.pop("moe"), layers=2, vocab=2048, seed=71, max_seq_len=320, **kw)
+    lens = [300, 257, 129, 13]                      # 699 tokens: 21 full 32-token blocks + 27
+    rng = np.random.default_rng(73)
+    prompts = [rng.integers(0, 2048, size=n).astype(np.uint32) for n in lens]
+    outs = {}
+    for mode in (1, 0):
+        knobs.set(ROUTE_GEMM_TOPK=mode)
+        hm = tm.hip_model(pkg, kv_num_blocks=len(lens) * 22, max_seqs=len(lens), max_tokens=sum(lens))
+        forms.reset()
+        toks, lg = hm.unified_forward([(i, p, 0, True) for i, p in enumerate(prompts)], greedy=True, want_logits=True)
+        hits = forms.hits()
+        assert hits.get("route_gemm", 0) == 2 and hits.get("route_gemm_topk", 0) == (2 if mode else 0), hits
+        outs[mode] = (np.array(toks, np.uint32), lg.copy())
+        del hm
+    (t1, l1), (t0, l0) = outs[1], outs[0]
+    err = np.abs(l1 - l0).max(axis=1)
+    assert float(err.max()) < 0.02 * float(np.abs(l0).max()), float(err.max())
+    srt = np.sort(l0, axis=1)
+    for r in np.nonzero(t1 != t0)[0]:
+        assert srt[r, -1] - srt[r, -2] <= 2 * err[r] + 1e-6, int(r)
+    O.set_threads(ORACLE_THREADS)
+    om = tm.oracle_model()
+    par = modelgen.Parity("prefill-router-one-launch", cos_min=0.999, rel_max=5e-2)
+    for oc, i in enumerate((2, 3)):
+        par.check(f"prefill/{i}", om.forward(oc, prompts[i], 0), l1[i], t1[i], om.last_route_gap_rel())
+    O.set_threads(1)
+    par.finish(max_mismatches=0, max_route_ties=1)
+
+
 @pytest.mark.parametrize("name", sorted(BENCH_DIMS))
 def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, forms):
     from tests import modelgen
@@ -867,7 +905,7 @@ def test_bench_workload_at_real_dims_prefill_8192_then_decode_c32(pkg, name, for
     # the forms the 8192-token prefill is meant to take: 96- / 256-row GEMM tiles with the scale folded into the fp16 B operand,
     # resident-K/V attention (256-token prompts: the whole context in one LDS image), and for the MoE model the router GEMM +
     # 96-pair grouped tiles through the same tall-tile kernel
-    h = forms.require("w4_big", "attn_resident", *(("route_gemm", "moe_tile_big") if moe else ()))
+    h = forms.require("w4_big", "attn_resident", *(("route_gemm", "route_gemm_topk", "moe_tile_big") if moe else ()))
     act_order = name == "gemma3-27b"
     if act_order:      # a desc_act pack: every norm / gated activation writes its row permuted; ONE gather launch per layer is left
         forms.require("perm_producer")                                        # (o_proj behind the prefill attention forms)
