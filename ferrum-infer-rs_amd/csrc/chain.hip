@@ -343,7 +343,7 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
 }
 
 // ── attention role: paged_attn_kernel<128, true, 8> (decode, one new token per sequence) ────────────────────────────────
-template <bool KVS>
+template <bool KVS, bool WIDE>
 __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsigned char* smem) {
     constexpr int HD = 128, NW = CH_W, DT = HD / 16, KS = HD / 32, OSTRIDE = HD + 4;
     float* lds_o = reinterpret_cast<float*>(smem);                    // [NW·16][OSTRIDE]
@@ -409,7 +409,7 @@ __device__ __forceinline__ void chain_role_attn(const ChainArgs& p, int wg, unsi
     // norm weights and the RoPE row of this position do not depend on the projection either
     __builtin_amdgcn_sched_barrier(0);
     // the q|k|v columns of this kv head: G + 2 heads, each one workgroup per 16-row block of the projection role
-    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (p.qkv_half ? 4 : (p.qkv_wide ? 1 : 2)) * ((p.T + 15) >> 4)), p.timeout);
+    chain_wait(p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 1, CH_QKV_R, (unsigned)((G + 2) * (WIDE ? 1 : (p.qkv_half ? 4 : 2)) * ((p.T + 15) >> 4)), p.timeout);
     CH_TL(1);
     half8 qf[KS];
     {
@@ -837,11 +837,14 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
     CH_TL(3);
 }
 
-template <int GPW_QKV, int GPW_O, bool HAS_ZP, bool KVS = false>
+// KVS / WIDE are kernels of their own, not branches: the one-range, 64-column kernel keeps the instruction layout it was tuned
+// with (with either compiled in as a runtime branch it lost ≈ 1 % at every batch size — roles entering late have their first
+// instructions on the critical path)
+template <int GPW_QKV, int GPW_O, bool HAS_ZP, bool KVS = false, bool WIDE = false>
 __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
-    const int QB = p.qkv_half ? 32 : (p.qkv_wide ? 128 : 64);       // q|k|v block width
+    const int QB = WIDE ? 128 : (p.qkv_half ? 32 : 64);             // q|k|v block width
     const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * (KVS ? p.attn_splits : 1), n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
@@ -855,22 +858,21 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
         const int cb = wg / RH, head = cb * QB / 128, G = p.nq / p.nkv;           // (a head is 128 columns)
         const int kvh = head < p.nq ? head / G : (head < p.nq + p.nkv ? head - p.nq : head - p.nq - p.nkv);
         const ChainEdge e{p.has_a ? p.cnt + CH_NORM_SLOT * CH_STRIDE : nullptr, CH_NORM_SH, CH_NORM_R, (unsigned)p.T};
-        if (p.qkv_half)
+        if constexpr (WIDE) {
+            // one head (128 columns) per workgroup: half as many workgroups of twice the bytes — taken where the narrow blocks and the
+            // attention role together exceed the workgroups the chip holds at once (decode_chain_f16)
+            chain_role_gemm<2, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
+                                                p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
+        } else if (p.qkv_half)
             chain_role_gemm<1, GPW_QKV, HAS_ZP, 2>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
                                                    p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
-        else if (GPW_QKV == 2 && p.qkv_wide) {
-            // one head (128 columns) per workgroup: half as many workgroups of twice the bytes — taken where the narrow blocks and the
-            // attention role together exceed the workgroups the chip holds at once and the wide ones do not (decode_chain_f16)
-            if constexpr (GPW_QKV == 2)
-                chain_role_gemm<2, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
-                                                    p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
-        } else
+        else
             chain_role_gemm<CH_QKV_NST, GPW_QKV, HAS_ZP>(p.qkv, cb, wg % RH, p.norm1, p.qkv_out, p.T, e,
                                                          p.cnt + (CH_QKV_SLOT + kvh * CH_QKV_R) * CH_STRIDE, 0, CH_QKV_R, p.timeout, smem, p);
         return;
     }
     wg -= n_qkv;
-    if (wg < n_attn) { chain_role_attn<KVS>(p, wg, smem); return; }
+    if (wg < n_attn) { chain_role_attn<KVS, WIDE>(p, wg, smem); return; }
     wg -= n_attn;
     if (wg < n_o) {
         const ChainEdge e{p.cnt + CH_ATTN_SLOT * CH_STRIDE, CH_ATTN_SH, CH_ATTN_R, (unsigned)(p.T * p.nkv)};      // (one arrival per (sequence, kv head): its last split's)
@@ -950,7 +952,7 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     // the chip's resident workgroups, the role's last workgroups enter behind the projection (≈ 2.7 µs of K/V round trips on the
     // critical path, profiles/r03_decode_chain_timeline.txt) — c=32 4.025 → 3.995 ms per step, c=64 4.83 → 4.69; c=20–24 (where they fit) 3 % slower
     a.qkv_wide = 0;
-    if (!a.qkv_half && d.qkv->G / 8 == 2) {
+    if (!a.qkv_half && d.qkv->G / 8 == 2 && a.attn_splits == 1) {
         const int wide = knobs().chain_qkv_wide;
         const int n64 = d.qkv->n / 64 * rh, n_at = d.T * d.nkv * a.attn_splits;
         a.qkv_wide = wide >= 0 ? (wide > 0) : (n64 + n_at > knobs().chain_slots);
@@ -962,7 +964,8 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     if (a.attn_splits > 1) {
         if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false, true>), dim3(blocks), dim3(512), 0, stream, a);
         else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false, true>), dim3(blocks), dim3(512), 0, stream, a);
-    } else if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
+    } else if (a.qkv_wide) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false, false, true>), dim3(blocks), dim3(512), 0, stream, a);
+    else if (d.qkv->G / 8 == 2) hipLaunchKernelGGL((decode_chain_kernel<2, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     else hipLaunchKernelGGL((decode_chain_kernel<4, 4, false>), dim3(blocks), dim3(512), 0, stream, a);
     FH_CHECK_LAUNCH();
     return 0;
