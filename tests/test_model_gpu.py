@@ -713,7 +713,8 @@ def test_decode_chain_yields_to_split_kv_attention_beyond_its_key_limit(pkg, for
     assert np.array_equal(runs[0], runs[1])
 
 
-def test_decode_chain_attention_kv_splits(pkg, forms, knobs):
+@pytest.mark.parametrize("window", [0, 150])
+def test_decode_chain_attention_kv_splits(pkg, forms, knobs, window):
     """Long contexts inside the chain: the attention role takes several KV ranges per (sequence, kv head) — ≈ `chain_split_keys`
     keys each (256 by default within a workgroup budget, runner.hip; 16 and 5 ranges forced here), every range's workgroup leaving its (m, l, o) state write-through and taking
     a ticket, the last to arrive merging all of them in range order.  Ragged contexts (one shorter than the number of ranges:
@@ -721,7 +722,8 @@ def test_decode_chain_attention_kv_splits(pkg, forms, knobs):
     from tests import modelgen
     from oracle import oracle as O
     kw = dict(BENCH_DIMS["qwen3-30b-a3b"])
-    tm = modelgen.TinyModel(kw.pop("moe"), layers=2, vocab=2048, seed=57, max_seq_len=320, **kw)
+    # (window: a uniform sliding window — the ranges then divide the window's block pairs, most of the 16 are empty)
+    tm = modelgen.TinyModel(kw.pop("moe"), layers=2, vocab=2048, seed=57, max_seq_len=320, sliding_window=window, **kw)
     lens = [300, 5, 129, 250, 37, 64]
     c, steps = len(lens), 3
     followed = [0, 1, 2]
@@ -729,7 +731,7 @@ def test_decode_chain_attention_kv_splits(pkg, forms, knobs):
     prompts = [rng.integers(0, 2048, size=n).astype(np.uint32) for n in lens]
     O.set_threads(ORACLE_THREADS)
     om = tm.oracle_model()
-    par = modelgen.Parity("decode-chain-kv-splits", cos_min=0.999, rel_max=5e-2)
+    par = modelgen.Parity(f"decode-chain-kv-splits-w{window}", cos_min=0.999, rel_max=5e-2)
     outs, ids = {}, {}
     fed = None
     for mode in ("split", "split5", "unsplit", "launches"):
