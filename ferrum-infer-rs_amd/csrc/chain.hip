@@ -51,6 +51,7 @@ constexpr int CH_QKV_SLOT = 56, CH_QKV_R = 4;                           // q|k|v
 constexpr int CH_MAX_KVH = 16;
 constexpr int CH_SLOTS = CH_QKV_SLOT + CH_QKV_R * CH_MAX_KVH;
 constexpr int CH_GRAN = 10;              // granules per (token, router part): 8 candidates + max + Σexp
+constexpr int CH_O_KS = 2;                // o_proj: K parts per block, each a workgroup of its own (fp32 partial rows, role B adds them)
 constexpr int CH_MAX_SPLITS = 16;          // KV ranges per (sequence, kv head) in the attention role
 constexpr int CH_MAX_T = 128;
 constexpr int CH_GRAN_WORDS = CH_MAX_T * 4 * CH_GRAN * 2;      // T ≤ 64 tokens × Q ≤ 4 parts, 8-byte granules
@@ -96,6 +97,7 @@ struct ChainArgs {
 #ifdef FERRUM_HIP_EXPERIMENTS
     unsigned long long* tl;       // development: per-workgroup wall-clock stamps (tools/exp_timeline_chain.py)
 #endif
+    float* o_part;                // [CH_O_KS][T][H] fp32: o_proj's K parts
     int qkv_wide;                 // q|k|v in 128-column blocks (one head per workgroup)
     // (behind everything else: the one-range kernel's argument layout is the one it was tuned with)
     int attn_splits;              // KV ranges per (sequence, kv head): > 1 → partial states meet by ticket, the last arriver merges them
@@ -249,17 +251,20 @@ struct ChainEdge { unsigned* base; int shards, reps; unsigned total; };      // 
 
 // NTL = 16-column tiles of the 64-column supertile a workgroup takes (NST = 1): 4, or 2 — a 32-column block `cb` = supertile cb / 2,
 // half cb % 2: half the weight bytes per workgroup, twice the workgroups (the stage is as long as its slowest workgroup's fetch).
-template <int NST, int GPW, bool HAS_ZP, int NTL = 4>
+// F32OUT: the workgroup covers only the quant groups from g_base on (8·GPW of them) and leaves its fp32 partial sums in `out32`
+// ([K part][T][N]) — o_proj split over two workgroups per block: the rows a workgroup reads behind its wait (T·K·2 B through one CU)
+// are what its stage takes, and role B adds the two parts
+template <int NST, int GPW, bool HAS_ZP, int NTL = 4, bool F32OUT = false>
 __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int rb, const __half* x_in, __half* out, int T,
                                                 const ChainEdge& wait, unsigned* sig_base, int sig_shard, int sig_reps,
-                                                unsigned* timeout, unsigned char* smem, const ChainArgs& p) {
+                                                unsigned* timeout, unsigned char* smem, const ChainArgs& p, int g_base = 0, float* out32 = nullptr) {
     static_assert(NTL == 4 || (NTL == 2 && NST == 1), "half supertiles only for single-supertile blocks");
     constexpr int V = NST * NTL * 4, CPR = NST * NTL * 2;                       // accumulator floats per lane; 16-byte chunks per output row
     float* red = reinterpret_cast<float*>(smem);                     // [8][V][64]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int a = lane >> 4, b = lane & 15;
     CH_TL(0);
-    const int g0 = wave * GPW;                                        // G = 8·GPW (checked by the launcher)
+    const int g0 = g_base + wave * GPW;                               // G = 8·GPW (· 2 with F32OUT; checked by the launcher)
     const int nt0 = NTL == 2 ? (cb & 1) * 2 : 0;                      // first tile of the block inside its supertile
     u32x4 wq[GPW][NST][NTL];
     uint2 scv[GPW][NST], zpv[GPW][NST];
@@ -328,13 +333,22 @@ __device__ __forceinline__ void chain_role_gemm(const ChainGemm& w, int cb, int 
 #pragma unroll
             for (int j = 0; j < 4; j++) { sum[j] += lo[j]; sum[4 + j] += hi[j]; }
         }
-        half8 o;
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = (_Float16)sum[j];
         const int r_out = rb * 16 + row;
-        if (r_out < T) {
-            const __amdgpu_buffer_rsrc_t r_o = chain_rsrc(out, (long)T * w.N * 2);
-            store16_sc1(r_o, (r_out * w.N + cb * 16 * NTL * NST + c8) * 2, o);
+        if constexpr (F32OUT) {
+            if (r_out < T) {
+                const __amdgpu_buffer_rsrc_t r_o = chain_rsrc(out32, (long)T * w.N * 4);
+                const int off = (r_out * w.N + cb * 16 * NTL * NST + c8) * 4;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (float4v){sum[0], sum[1], sum[2], sum[3]}), r_o, off, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (float4v){sum[4], sum[5], sum[6], sum[7]}), r_o, off + 16, 0, 16);
+            }
+        } else {
+            half8 o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) o[j] = (_Float16)sum[j];
+            if (r_out < T) {
+                const __amdgpu_buffer_rsrc_t r_o = chain_rsrc(out, (long)T * w.N * 2);
+                store16_sc1(r_o, (r_out * w.N + cb * 16 * NTL * NST + c8) * 2, o);
+            }
         }
     }
     CH_TL(2);
@@ -656,7 +670,7 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
     CH_TL(1);
     float* red = part + tiles_q * 16 * (ksplit + 1);                  // [8] behind the logits
     unsigned long long* cand_s = reinterpret_cast<unsigned long long*>(red + 8);     // [8]
-    const __amdgpu_buffer_rsrc_t r_x = chain_rsrc(p.o_out, (long)p.T * H * 2), r_res = chain_rsrc(p.res_a, (long)p.T * H * 2);
+    const __amdgpu_buffer_rsrc_t r_x = chain_rsrc(p.o_part, (long)CH_O_KS * p.T * H * 4), r_res = chain_rsrc(p.res_a, (long)p.T * H * 2);
     half8 v[CH];
     float ss = 0.f;
 #pragma unroll
@@ -664,7 +678,19 @@ __device__ __forceinline__ void chain_role_b(const ChainArgs& p, int wg, unsigne
         const int i = threadIdx.x + c * 512;
         if (i < nvec) {
             const int off = (int)((row * H + i * 8) * 2);
-            const half8 xv = load16_sc1(r_x, off);
+            // o_proj's row: its K parts (fp32) added in part order, rounded to the fp16 the projection's output is
+            float xs32[8];
+#pragma unroll
+            for (int ks = 0; ks < CH_O_KS; ks++) {
+                const int o32 = (int)((((long)ks * p.T + row) * H + i * 8) * 4);
+                const float4v lo = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(r_x, o32, 0, 16));
+                const float4v hi = __builtin_bit_cast(float4v, __builtin_amdgcn_raw_buffer_load_b128(r_x, o32 + 16, 0, 16));
+#pragma unroll
+                for (int j = 0; j < 4; j++) { xs32[j] = ks ? xs32[j] + lo[j] : lo[j]; xs32[4 + j] = ks ? xs32[4 + j] + hi[j] : hi[j]; }
+            }
+            half8 xv;
+#pragma unroll
+            for (int j = 0; j < 8; j++) xv[j] = (_Float16)xs32[j];
             half8 rv = load16_sc1(r_res, off);
 #pragma unroll
             for (int j = 0; j < 8; j++) rv[j] = (_Float16)((float)rv[j] + (float)xv[j]);
@@ -845,7 +871,7 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[CH_SMEM];
     const int RH = (p.T + 15) >> 4;                                   // 16-row blocks
     const int QB = WIDE ? 128 : (p.qkv_half ? 32 : 64);             // q|k|v block width
-    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * (KVS ? p.attn_splits : 1), n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH;
+    const int n_a = p.has_a ? p.T : 0, n_qkv = p.qkv.N / QB * RH, n_attn = p.T * p.nkv * (KVS ? p.attn_splits : 1), n_o = p.o.N / (p.o_half ? 32 : 64 * CH_O_NST) * RH * CH_O_KS;
     int wg = blockIdx.x;
     if (wg == 0) {                                                    // re-arm the other half: counters and route granules
         if (threadIdx.x < CH_QKV_SLOT + CH_QKV_R * p.nkv) p.cnt_next[threadIdx.x * CH_STRIDE] = 0u;
@@ -876,12 +902,16 @@ __global__ __launch_bounds__(512, 2) void decode_chain_kernel(ChainArgs p) {
     wg -= n_attn;
     if (wg < n_o) {
         const ChainEdge e{p.cnt + CH_ATTN_SLOT * CH_STRIDE, CH_ATTN_SH, CH_ATTN_R, (unsigned)(p.T * p.nkv)};      // (one arrival per (sequence, kv head): its last split's)
+        // (K part fastest: the two workgroups of a block are neighbours)
+        static_assert(GPW_O % CH_O_KS == 0, "o_proj's quant groups per wave divide over its K parts");
+        const int ks = wg % CH_O_KS, blk = wg / CH_O_KS;
+        float* part = p.o_part + (long)ks * p.T * p.o.N;
         if (p.o_half)
-            chain_role_gemm<1, GPW_O, HAS_ZP, 2>(p.o, wg / RH, wg % RH, p.attn_out, p.o_out, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
-                                                 wg % CH_O_SH, CH_O_R, p.timeout, smem, p);
+            chain_role_gemm<1, GPW_O / CH_O_KS, HAS_ZP, 2, true>(p.o, blk / RH, blk % RH, p.attn_out, nullptr, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
+                                                                 wg % CH_O_SH, CH_O_R, p.timeout, smem, p, ks * (p.o.G / CH_O_KS), part);
         else
-            chain_role_gemm<CH_O_NST, GPW_O, HAS_ZP>(p.o, wg / RH, wg % RH, p.attn_out, p.o_out, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
-                                                     wg % CH_O_SH, CH_O_R, p.timeout, smem, p);
+            chain_role_gemm<CH_O_NST, GPW_O / CH_O_KS, HAS_ZP, 4, true>(p.o, blk / RH, blk % RH, p.attn_out, nullptr, p.T, e, p.cnt + CH_O_SLOT * CH_STRIDE,
+                                                                        wg % CH_O_SH, CH_O_R, p.timeout, smem, p, ks * (p.o.G / CH_O_KS), part);
         return;
     }
     wg -= n_o;
@@ -903,6 +933,7 @@ bool decode_chain_supports(const DecodeChainDesc& d) {
     };
     if (!d.qkv || !d.o || !gemm_ok(*d.qkv) || !gemm_ok(*d.o)) return false;
     if (d.o->G / 8 != 4) return false;              // (the instantiated forms: o_proj's K slice per wave is four groups)
+    if (!d.o_part) return false;
     if (d.attn_splits > CH_MAX_SPLITS || (d.attn_splits > 1 && (!d.attn_partial || !d.attn_tickets))) return false;
     if (d.T < 1 || d.T > CH_MAX_T || d.head_dim != 128 || d.nkv < 1 || d.nq % d.nkv != 0 || d.nq / d.nkv > 14 || d.nkv > CH_MAX_KVH) return false;
     if (d.H % 32 != 0 || d.H > 8192 || d.qkv->k != d.H || d.qkv->n != (d.nq + 2 * d.nkv) * 128 || d.o->k != d.nq * 128 || d.o->n != d.H) return false;
@@ -951,13 +982,14 @@ int decode_chain_f16(const DecodeChainDesc& d, hipStream_t stream) {
     // 128-column q|k|v blocks (hidden 2048 only: the two-group weight ring): where the 64-column blocks + the attention role do not fit
     // the chip's resident workgroups, the role's last workgroups enter behind the projection (≈ 2.7 µs of K/V round trips on the
     // critical path, profiles/r03_decode_chain_timeline.txt) — c=32 4.025 → 3.995 ms per step, c=64 4.83 → 4.69; c=20–24 (where they fit) 3 % slower
+    a.o_part = d.o_part;
     a.qkv_wide = 0;
     if (!a.qkv_half && d.qkv->G / 8 == 2 && a.attn_splits == 1) {
         const int wide = knobs().chain_qkv_wide;
         const int n64 = d.qkv->n / 64 * rh, n_at = d.T * d.nkv * a.attn_splits;
         a.qkv_wide = wide >= 0 ? (wide > 0) : (n64 + n_at > knobs().chain_slots);
     }
-    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : (a.qkv_wide ? 128 : 64)) * rh + d.T * d.nkv * a.attn_splits + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh + d.T * d.Q;
+    const int blocks = (d.has_a ? d.T : 0) + d.qkv->n / (a.qkv_half ? 32 : (a.qkv_wide ? 128 : 64)) * rh + d.T * d.nkv * a.attn_splits + d.o->n / (a.o_half ? 32 : 64 * CH_O_NST) * rh * CH_O_KS + d.T * d.Q;
     form_hit(FORM_DECODE_CHAIN);
     if (a.attn_splits > 1) form_hit(FORM_CHAIN_ATTN_KV_SPLITS);
     if (a.qkv_wide) form_hit(FORM_CHAIN_QKV_WIDE);

@@ -255,6 +255,7 @@ struct DecodeChainDesc {
     int E = 0, r_top_k = 0, Q = 0, norm_topk = 0;
     bool defer_merge = false;    // role B stops at the per-part candidate lists (cand / stats); the grouped GEMM that follows merges them
     RouteCand* cand = nullptr; float* stats = nullptr; unsigned* route_arrive = nullptr; int32_t* ids = nullptr; float* weights = nullptr;
+    float* o_part = nullptr;       // [2][T][H] fp32: o_proj's two K parts (one workgroup each per block; role B adds them)
     int attn_splits = 1;           // KV ranges per (sequence, kv head) in the attention role (≤ 16); > 1 needs the two buffers below
     float* attn_partial = nullptr; // [T·nkv·attn_splits][16][head_dim + 4] fp32
     unsigned* attn_tickets = nullptr;   // [T·nkv] zeroed words (self-resetting)

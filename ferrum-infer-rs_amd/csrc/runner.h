@@ -76,6 +76,7 @@ struct FerrumHipModel {
            *o_out = nullptr, *gate_up_out = nullptr, *act_out = nullptr, *mlp_out = nullptr, *sampled_hidden = nullptr,
            *moe_act = nullptr, *moe_down = nullptr, *moe_gather_x = nullptr, *moe_gather_h = nullptr;
     __half* residual2 = nullptr;          // ping-pong partner of `residual` for the Q-part route kernel
+    float* chain_o_part = nullptr;        // decode chain: o_proj's two K parts, [2][128][H] fp32
     float* chain_attn_partial = nullptr;  // decode chain, attention role with KV splits: [≤ 1024 (unit, split)][16][head_dim + 4] states
     unsigned* chain_attn_tickets = nullptr;   // [4096] one self-resetting ticket per (sequence, kv head)
     fh::RouteCand* route_cand = nullptr;  // [T ≤ 64][Q][8]

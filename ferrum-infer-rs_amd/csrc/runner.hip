@@ -399,7 +399,7 @@ int ferrum_hip_model_destroy(FerrumHipModel* m) {
                     (void*)m->sampled_hidden, (void*)m->moe_act, (void*)m->moe_down, (void*)m->moe_gather_x, (void*)m->moe_gather_h, (void*)m->router_logits,
                     (void*)m->expert_ids, (void*)m->sorted_ids, (void*)m->block_ids, (void*)m->total_post_pad,
                     (void*)m->expert_w, (void*)m->logits, (void*)m->out_tokens, (void*)m->workspace, (void*)m->taps,
-                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2, (void*)m->chain_attn_partial, (void*)m->chain_attn_tickets,
+                    (void*)m->idx_dev, (void*)m->history, (void*)m->step_counter, (void*)m->residual2, (void*)m->chain_o_part, (void*)m->chain_attn_partial, (void*)m->chain_attn_tickets,
                     (void*)m->route_cand, (void*)m->route_stats, (void*)m->route_arrive, (void*)m->cos_local,
                     (void*)m->sin_local, (void*)m->residual_f32, (void*)m->gather_scratch, (void*)m->greedy_opts_dev, (void*)m->tp_tmp,
                     (void*)m->expert_ids_local, (void*)m->ones, m->vp_pairs, m->vp_gathered})
@@ -808,6 +808,7 @@ int ferrum_hip_model_finalize(FerrumHipModel* m) {
             *m->inlaunch_timeouts = 0u;
         }
     }
+    if (!rc && m->em2_arrive) rc |= dev_alloc(&m->chain_o_part, (size_t)4 * 128 * H);
     if (!rc && m->em2_arrive && c.head_dim == 128) {
         rc |= dev_alloc(&m->chain_attn_partial, (size_t)CHAIN_MAX_ATTN_WGS * 16 * (c.head_dim + 4));
         rc |= dev_alloc(&m->chain_attn_tickets, (size_t)4096);
@@ -1278,7 +1279,7 @@ int enqueue_forward(FerrumHipModel* m, const StepShape& sh, bool greedy, const G
         d.cos_t = (!is_global && m->cos_local) ? m->cos_local : m->cos_t;
         d.sin_t = (!is_global && m->sin_local) ? m->sin_local : m->sin_t;
         d.qk_mode = qk_mode; d.max_blocks = m->max_blocks_per_seq;
-        d.attn_out = m->attn_out; d.o = &L.o; d.o_out = m->o_out;
+        d.attn_out = m->attn_out; d.o = &L.o; d.o_out = m->o_out; d.o_part = m->chain_o_part;
         d.res_b_out = m->residual2; d.post_ln = L.post_ln; d.norm2 = m->norm_out; d.router_w = L.router;
         d.E = c.num_experts; d.r_top_k = c.top_k; d.norm_topk = c.norm_topk_prob;
         int Q = m->route_parts;

@@ -34,7 +34,7 @@ rh = (c + 15) // 16
 half = c <= 16                                   # ≤ 16 rows: 32-column blocks in the GEMM roles
 qkv_cols = (cfg["num_heads"] + 2 * cfg["num_kv_heads"]) * 128
 wide = (not half) and (int(os.environ.get("FERRUM_HIP_CHAIN_QKV_WIDE", "-1")) > 0 or (int(os.environ.get("FERRUM_HIP_CHAIN_QKV_WIDE", "-1")) < 0 and qkv_cols // 64 * rh + c * cfg["num_kv_heads"] > 256))   # 128-column q|k|v blocks (chain.hip decode_chain_f16)
-n_a, n_qkv, n_attn, n_o, n_b = c, qkv_cols // (32 if half else (128 if wide else 64)) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // (32 if half else 64) * rh, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
+n_a, n_qkv, n_attn, n_o, n_b = c, qkv_cols // (32 if half else (128 if wide else 64)) * rh, c * cfg["num_kv_heads"], cfg["hidden"] // (32 if half else 64) * rh * 2, c * int(os.environ.get("FERRUM_HIP_ROUTE_PARTS", "4"))
 tot = n_a + n_qkv + n_attn + n_o + n_b
 t = t[:tot]
 t0 = t[:, 0].min()
